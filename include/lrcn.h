@@ -1,0 +1,154 @@
+/*
+ * lrcn.h -- C ABI of liblrcn_hip.so: the MI355X (gfx950) implementation of the LRCN hot path of
+ * ekinakyurek/Long-Term-Recurrent-Convolutional-NN (reference file: lrcn.jl).
+ *
+ * The reference has no FFI; its seam is a handful of Julia functions over dense arrays.  Each entry point
+ * below replaces one of them (cited per function) and takes the SAME arrays: dense COLUMN-MAJOR float32 with
+ * the reference's shapes, so a Julia `ccall` passes KnetArray/Array pointers without copying.  All array
+ * pointers are DEVICE pointers (hipMalloc'd, or obtained from lrcn_malloc) unless marked "host".
+ *
+ * Conventions
+ *   - Token ids are int32 and 0-based: eos=0, bos=1, unk=2 (= the reference's 1,2,3, lrcn.jl:248-255, minus 1).
+ *     tokens are laid out [T][B] (the reference's sequence[t][i]).
+ *   - "params" / "grads" / "mom" / "var" are arrays of 9 device pointers in initweights order (lrcn.jl:489-510):
+ *       [0] W1 (E+H1) x 4H1   [1] b1 1 x 4H1   [2] W2 (2h+H2) x 4H2   [3] b2 1 x 4H2   [4] Wproj H1 x h
+ *       [5] Wcnn 4096 x h     [6] Wembed V x E [7] Wout H2 x V        [8] bout 1 x V          h = ceil(H2/2), 2h == H2
+ *     gate column blocks are [forget | in | out | change] (lrcn.jl:531-534).
+ *   - The caller owns every array it passes; the context owns only scratch.  No pointer is retained across
+ *     calls except the VGG weights repacked (copied) by lrcn_vgg_load.
+ *   - Every function returns 0 on success or a negative LRCN_E* code; lrcn_last_error() gives the message.
+ *     Nothing aborts or throws across the boundary (the reference signals errors with Julia exceptions,
+ *     lrcn.jl:395, 603; a binding turns non-zero into error(msg)).
+ *   - A context is bound to one device and is not thread-safe.  Work is queued on the context's stream
+ *     (lrcn_set_stream; default = the device's null stream) and a call returns without synchronising unless it
+ *     hands back a host scalar (loss_host != NULL, lrcn_beam_search, lrcn_last_loss, lrcn_sync).
+ *   - Arithmetic type: LRCN_F32 = exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere; LRCN_BF16 = bf16
+ *     operands with fp32 accumulation in the GEMMs/convolutions, fp32 master weights, fp32 cell state,
+ *     fp32 softmax/loss, fp32 Adam.
+ */
+#ifndef LRCN_H
+#define LRCN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LRCN_CNNOUT 4096 /* lrcn.jl:28 */
+#define LRCN_EOS 0
+#define LRCN_BOS 1
+#define LRCN_UNK 2
+#define LRCN_MAX_T 28 /* captions longer than 28 tokens are skipped by the reference, lrcn.jl:353, 438 */
+
+enum { LRCN_OK = 0, LRCN_EINVAL = -1, LRCN_ENOMEM = -2, LRCN_EHIP = -3, LRCN_ESTATE = -4 };
+enum { LRCN_F32 = 0, LRCN_BF16 = 1 };
+
+typedef struct lrcn_ctx lrcn_ctx;
+
+typedef struct {
+    int device;     /* HIP device ordinal */
+    int E, H1, H2;  /* --embed, --hidden (lrcn.jl:39-40); H2 must be even (lrcn.jl:496-505) */
+    int V;          /* vocabulary size incl. eos/bos/unk */
+    int max_B;      /* largest per-call batch (rows on this device) */
+    int max_T;      /* largest caption length T (<= LRCN_MAX_T); the loop runs T+1 steps */
+    int lstm_dtype; /* LRCN_F32 | LRCN_BF16 */
+    int vgg_dtype;  /* LRCN_F32 | LRCN_BF16 */
+    int max_images; /* VGG batch capacity; 0 = no VGG in this context */
+} lrcn_config;
+
+/* ---- lifetime / plumbing ---- */
+int lrcn_create(const lrcn_config *cfg, lrcn_ctx **out);
+void lrcn_destroy(lrcn_ctx *ctx);
+const char *lrcn_last_error(const lrcn_ctx *ctx); /* ctx may be NULL: last creation error */
+int lrcn_set_stream(lrcn_ctx *ctx, void *hip_stream);  /* hipStream_t; NULL = null stream */
+int lrcn_sync(lrcn_ctx *ctx);
+int lrcn_malloc(void **dev_ptr, size_t bytes);
+int lrcn_free(void *dev_ptr);
+int lrcn_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
+int lrcn_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
+const char *lrcn_version(void);
+
+/* ---- model ---- */
+/* Element counts of the 9 tensors. */
+int lrcn_param_sizes(int E, int H1, int H2, int V, int64_t sizes[9]);
+/* initweights (lrcn.jl:489-510): xavier-uniform +-sqrt(2/(fanin+fanout)), zero biases, forget-gate bias 1.
+ * Julia's RNG stream is not reproducible; the generator is a counter-based hash keyed by (seed, tensor, index). */
+int lrcn_init_weights(lrcn_ctx *ctx, float *const params[9], uint64_t seed);
+
+/* lstm (lrcn.jl:528-538). x: B x X, h/c: B x H, W: (X+H) x 4H, b: 1 x 4H -> h_out/c_out: B x H (may alias h/c). */
+int lrcn_lstm(lrcn_ctx *ctx, const float *W, const float *b, int X, int H, int B, const float *x, const float *h,
+              const float *c, float *h_out, float *c_out);
+
+/* lrcn (lrcn.jl:540-551): one timestep. state[4] = {h1,c1,h2,c2} (B x H, updated in place as s[1..4] are);
+ * x_cnn: B x h, x_lstm: B x E, mask1 (B x E) / mask2 (B x H2): dropout multipliers or NULL; logits: B x V. */
+int lrcn_step(lrcn_ctx *ctx, const float *const params[9], float *const state[4], int B, const float *x_cnn,
+              const float *x_lstm, const float *mask1, const float *mask2, float *logits);
+
+/* Dropout specification for loss/lossgradient. pdrop == 0: none (what average_loss uses, lrcn.jl:233).
+ * pdrop > 0 and mask1 == NULL: masks are generated on device from (seed) [Philox-style counter hash];
+ * mask1/mask2 != NULL: caller-supplied multipliers, (T+1) blocks of B x E / B x H2 (for parity runs). */
+typedef struct {
+    float pdrop;
+    uint64_t seed;
+    const float *mask1;
+    const float *mask2;
+} lrcn_dropout;
+
+/* loss (lrcn.jl:553-581). feats: B x 4096. norm_B: the reference's global `batchsize` that the loss is divided by
+ * (lrcn.jl:564-568): B for one device, the global batch under data parallelism.
+ * loss_host (host double*, may be NULL): -sum logp / (norm_B*(T+1)). */
+int lrcn_loss(lrcn_ctx *ctx, const float *const params[9], const float *feats, const int32_t *tokens, int T, int B,
+              int norm_B, const lrcn_dropout *drop, double *loss_host);
+
+/* lossgradient = grad(loss) (lrcn.jl:583): as lrcn_loss, plus d loss / d params into grads[9] (overwritten). */
+int lrcn_loss_grad(lrcn_ctx *ctx, const float *const params[9], const float *feats, const int32_t *tokens, int T,
+                   int B, int norm_B, const lrcn_dropout *drop, float *const grads[9], double *loss_host);
+
+/* The loss of the most recent lrcn_loss/_loss_grad/_train_step call (synchronises). */
+int lrcn_last_loss(lrcn_ctx *ctx, double *loss_host);
+
+/* Per-step logits of the loss forward pass (parity probe): logits_out = (T+1) blocks of B x V. */
+int lrcn_forward_logits(lrcn_ctx *ctx, const float *const params[9], const float *feats, const int32_t *tokens,
+                        int T, int B, float *logits_out);
+
+/* update!(param, gloss, optim) with one Adam() per tensor (lrcn.jl:394, 399-405; Knet defaults lr 1e-3,
+ * beta1 0.9, beta2 0.999, eps 1e-8). step = 1-based count of this update. One launch for all 9 tensors. */
+int lrcn_adam_update(lrcn_ctx *ctx, float *const params[9], const float *const grads[9], float *const mom[9],
+                     float *const var[9], int step, float lr, float beta1, float beta2, float eps);
+
+/* Body of train1's loop (lrcn.jl:369-394) on one device: lossgradient + update!.  feats: B x 4096. */
+int lrcn_train_step(lrcn_ctx *ctx, float *const params[9], float *const grads[9], float *const mom[9],
+                    float *const var[9], const float *feats, const int32_t *tokens, int T, int B, int norm_B,
+                    const lrcn_dropout *drop, int step, float lr, float beta1, float beta2, float eps,
+                    double *loss_host);
+
+/* generate + beam_search (lrcn.jl:585-678): feat 1 x 4096 (normalise beforehand if wanted, lrcn.jl:597).
+ * out_tokens (host, >= nword+2 ints) receives the best hypothesis INCLUDING the leading bos; *out_len its length;
+ * *out_prob its probability (linear float32 product, no length normalisation). */
+int lrcn_beam_search(lrcn_ctx *ctx, const float *const params[9], const float *feat, int K, int nword,
+                     int32_t *out_tokens, int *out_len, float *out_prob);
+
+/* ---- VGG-16 to fc7 (lrcn.jl:697-748) ---- */
+/* get_params_cnn (lrcn.jl:697-721): conv_w[l] (3,3,Cin,Cout), conv_b[l] Cout, fc6_w 4096 x 25088, fc7_w 4096 x 4096
+ * (the transposed `mat` of :712), biases 4096.  Weights are repacked (copied) into the context. */
+int lrcn_vgg_load(lrcn_ctx *ctx, const float *const conv_w[13], const float *const conv_b[13], const float *fc6_w,
+                  const float *fc6_b, const float *fc7_w, const float *fc7_b);
+/* convnet (lrcn.jl:733-748): x (224,224,3,N) preprocessed -> feats N x 4096 (pre-ReLU fc7). */
+int lrcn_vgg_forward(lrcn_ctx *ctx, const float *x, int N, float *feats);
+/* read_image_data's arithmetic (lrcn.jl:766-772) on decoded 224x224 RGB uint8 crops img[n][row][col][c]:
+ * out (224,224,3,N), out(i,j,c,n) = pixel(row i, col j, c) - mean[c].  mean: host float[3]. */
+int lrcn_preprocess_u8(lrcn_ctx *ctx, const uint8_t *img, int N, const float mean[3], float *out);
+/* Both of the above fused (no (224,224,3,N) float round trip): the training-path entry. */
+int lrcn_vgg_forward_u8(lrcn_ctx *ctx, const uint8_t *img, int N, const float mean[3], float *feats);
+
+/* Parity probes for the VGG operators (lrcn.jl:724-728), reference layouts, any small size:
+ * x (W,H,Cin,N) -> y (W,H,Cout,N) [or (W/2,H/2,Cout,N) with pool]; Cin, Cout multiples of 32. */
+int lrcn_conv3x3(lrcn_ctx *ctx, const float *x, int W, int H, int Cin, int N, const float *w, const float *b,
+                 int Cout, int relu, int pool, float *y);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

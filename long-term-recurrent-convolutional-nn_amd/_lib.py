@@ -1,0 +1,107 @@
+"""ctypes binding of liblrcn_hip.so (the C ABI declared in include/lrcn.h).
+
+There is NO fallback: if the shared library is missing or a symbol is absent this module raises, and every
+compute entry point needs a visible MI355X.  Nothing here imports or calls the CPU oracle.
+"""
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "liblrcn_hip.so")
+HEADER = os.path.normpath(os.path.join(HERE, "..", "include", "lrcn.h"))
+
+LRCN_F32, LRCN_BF16 = 0, 1
+EOS, BOS, UNK = 0, 1, 2
+CNNOUT = 4096
+MAX_T = 28
+
+
+class LrcnError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [("device", C.c_int), ("E", C.c_int), ("H1", C.c_int), ("H2", C.c_int), ("V", C.c_int),
+                ("max_B", C.c_int), ("max_T", C.c_int), ("lstm_dtype", C.c_int), ("vgg_dtype", C.c_int),
+                ("max_images", C.c_int)]
+
+
+class Dropout(C.Structure):
+    _fields_ = [("pdrop", C.c_float), ("seed", C.c_uint64), ("mask1", C.c_void_p), ("mask2", C.c_void_p)]
+
+
+P9 = C.c_void_p * 9
+P4 = C.c_void_p * 4
+P13 = C.c_void_p * 13
+
+# name -> (restype, argtypes); exactly the symbols include/lrcn.h declares
+SIGNATURES = {
+    "lrcn_create": (C.c_int, [C.POINTER(Config), C.POINTER(C.c_void_p)]),
+    "lrcn_destroy": (None, [C.c_void_p]),
+    "lrcn_last_error": (C.c_char_p, [C.c_void_p]),
+    "lrcn_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "lrcn_sync": (C.c_int, [C.c_void_p]),
+    "lrcn_malloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "lrcn_free": (C.c_int, [C.c_void_p]),
+    "lrcn_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "lrcn_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "lrcn_version": (C.c_char_p, []),
+    "lrcn_param_sizes": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
+    "lrcn_init_weights": (C.c_int, [C.c_void_p, P9, C.c_uint64]),
+    "lrcn_lstm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                            C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lrcn_step": (C.c_int, [C.c_void_p, P9, P4, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lrcn_loss": (C.c_int, [C.c_void_p, P9, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(Dropout),
+                            C.POINTER(C.c_double)]),
+    "lrcn_loss_grad": (C.c_int, [C.c_void_p, P9, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(Dropout),
+                                 P9, C.POINTER(C.c_double)]),
+    "lrcn_last_loss": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "lrcn_forward_logits": (C.c_int, [C.c_void_p, P9, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "lrcn_adam_update": (C.c_int, [C.c_void_p, P9, P9, P9, P9, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]),
+    "lrcn_train_step": (C.c_int, [C.c_void_p, P9, P9, P9, P9, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                  C.POINTER(Dropout), C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
+                                  C.POINTER(C.c_double)]),
+    "lrcn_beam_search": (C.c_int, [C.c_void_p, P9, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32),
+                                   C.POINTER(C.c_int), C.POINTER(C.c_float)]),
+    "lrcn_vgg_load": (C.c_int, [C.c_void_p, P13, P13, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lrcn_vgg_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "lrcn_preprocess_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_void_p]),
+    "lrcn_vgg_forward_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_void_p]),
+    "lrcn_conv3x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                               C.c_int, C.c_int, C.c_int, C.c_void_p]),
+}
+
+
+def build(force=False):
+    """hipcc --offload-arch=gfx950 -> csrc/liblrcn_hip.so (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))] + [HEADER]
+    stale = force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs)
+    if stale:
+        subprocess.check_call(["make", "-s", "-j4", "-C", CSRC, "-f", os.path.join(CSRC, "Makefile")])
+    return LIB_PATH
+
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise LrcnError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(there is no CPU fallback)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def check(ctx_handle, rc):
+    if rc != 0:
+        msg = lib().lrcn_last_error(ctx_handle)
+        raise LrcnError("liblrcn_hip error %d: %s" % (rc, msg.decode() if msg else "?"))

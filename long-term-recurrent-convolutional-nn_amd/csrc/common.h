@@ -1,0 +1,45 @@
+// common.h -- shared device/host helpers for liblrcn_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define LRCN_WAVE 64
+
+template <typename T> struct TypeInfo;
+template <> struct TypeInfo<float> { static constexpr int chunk = 4; static constexpr int bk = 32; };
+template <> struct TypeInfo<bf16_t> { static constexpr int chunk = 8; static constexpr int bk = 64; };
+
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(bf16_t x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { return (bf16_t)x; }
+
+static inline int64_t round_up64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// Window-major pixel order used by every convolution's GEMM row index m (see DESIGN.md "conv rows"):
+//   m = ((n*(H/2) + wy)*(W/2) + wx)*4 + dy*2 + dx   <->  pixel (n, y = 2wy+dy, x = 2wx+dx)
+// so the four pixels of one 2x2 max-pool window are four consecutive rows (= four consecutive accumulator
+// registers of one lane in the 32x32 MFMA C layout) and the pooled output is simply row m/4.
+struct PixDecode {
+    int n, y, x;
+};
+__device__ __forceinline__ PixDecode decode_pixel(int m, int H, int W) {
+    const int sub = m & 3;
+    int w = m >> 2;
+    const int W2 = W >> 1, H2 = H >> 1;
+    const int wx = w % W2;
+    w /= W2;
+    const int wy = w % H2;
+    PixDecode p;
+    p.n = w / H2;
+    p.y = 2 * wy + (sub >> 1);
+    p.x = 2 * wx + (sub & 1);
+    return p;
+}

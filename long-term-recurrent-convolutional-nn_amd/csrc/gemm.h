@@ -1,0 +1,30 @@
+// gemm.h -- the one contraction engine of liblrcn_hip: C[M][N] (+)= A[M][K] * B[N][K]^T  ("NT", both operands
+// K-contiguous), MFMA on gfx950, with an implicit-GEMM 3x3 convolution A-operand mode.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+enum { GEMM_A_PLAIN = 0, GEMM_A_CONV3 = 1 };
+enum { GEMM_OUT_PLAIN = 0, GEMM_OUT_CONV = 1, GEMM_OUT_POOL = 2 };
+enum { GEMM_T_F32 = 0, GEMM_T_BF16 = 1 };
+
+struct GemmArgs {
+    int dtype;      // GEMM_T_*: element type of A and B
+    const void *A;  // PLAIN: [M][lda]; CONV3: NHWC activations [n][H][W][Cin]
+    int64_t lda;    // elements (PLAIN only)
+    const void *B;  // [N][ldb], K-contiguous (weights)
+    int64_t ldb;
+    void *C;        // [M][ldc] (or conv/pool mapped), float if c_f32 else same type as A
+    int64_t ldc;
+    int M, N, K;    // CONV3: M = n*H*W output pixels (window-major order), K = 9*Cin
+    const float *bias;  // per output column, or NULL
+    int c_f32;
+    int beta;       // 1: C += result (reads C)
+    int relu;
+    int a_mode, out_mode;
+    int H, W, Cin;  // conv geometry (square-agnostic; H, W even)
+};
+
+// Requirements (checked): A/B base 16-byte aligned, lda/ldb multiples of the 16-byte chunk (4 f32 / 8 bf16),
+// CONV3: Cin a multiple of 32 (f32) / 64 (bf16).  Returns hipSuccess or an error; never faults on bad shapes.
+hipError_t launch_gemm(hipStream_t stream, const GemmArgs &g);

@@ -1,0 +1,100 @@
+// kernels.h -- launchers of the non-GEMM kernels of liblrcn_hip (gfx950).  dtype: GEMM_T_F32 / GEMM_T_BF16 selects
+// the element type "T" of activation/shadow buffers; everything marked f32 is always float.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct DropSpec {
+    float p;            // drop probability (0 = identity)
+    uint64_t seed;      // counter-hash key
+    const float *mask;  // caller-supplied multipliers ((T+1) blocks of B x ncols, column-major) or NULL
+    int which;          // 1 = the mask of lrcn.jl:542, 2 = the mask of lrcn.jl:547
+};
+
+// tok_in[s][b] = bos (s==0) | tokens[s-1][b];  tok_tgt[s][b] = tokens[s][b] (s<T) | eos.   (lrcn.jl:556,565,569,576)
+void k_build_tokens(hipStream_t st, const int32_t *tokens, int T, int B, int V, int32_t *tok_in, int32_t *tok_tgt);
+
+// Xemb[m][e] = WembT[tok_in[m]][e] * dropmask   (lrcn.jl:556/569 gather + :542 dropout), m = s*B+b.
+void k_embed_gather(hipStream_t st, int dtype, const void *wembT, int64_t ld_w, const int32_t *tok_in, int S, int B,
+                    int E, DropSpec d, void *xemb, int64_t ld_x);
+// dWembed(tok, e) += dXemb[m][e] * dropmask   (AutoGrad dual of the gather; Wembed is V x E column-major f32).
+void k_embed_scatter(hipStream_t st, const float *dxemb, int64_t ld_dx, const int32_t *tok_in, int S, int B, int E,
+                     int V, DropSpec d, float *dwembed);
+
+// LSTM cell, one timestep (lrcn.jl:531-536).  G f32 [B][4H] = pre-activations incl. bias; c_prev f32 [B][H] or NULL.
+// Writes activated gates [f|i|o|g] (T), c_new (f32), h_new (T) and optionally h_new as f32.
+void k_lstm_fwd(hipStream_t st, int dtype, const float *G, int64_t ld_g, const float *c_prev, int B, int H, void *acts,
+                int64_t ld_a, float *c_new, void *h_new, int64_t ld_h, float *h_new_f32);
+// Reverse of the cell.  dh_a (+ dh_b, may be NULL) f32 [B][H]; dc f32 [B][H] is read and replaced by
+// dc_prev.  Writes dZ (T) [B][4H].
+void k_lstm_bwd(hipStream_t st, int dtype, const void *acts, int64_t ld_a, const float *c_prev, const float *c_new,
+                const float *dh_a, int64_t ld_dha, const float *dh_b, float *dc, int B, int H, void *dz,
+                int64_t ld_dz);
+
+// X2[m][j<h] *= mask ; X2[m][h+j] = xcnn[b][j] * mask      (lrcn.jl:546-547)
+void k_concat_x2(hipStream_t st, int dtype, void *x2, int64_t ld_x2, const float *xcnn, int64_t ld_xc, int S, int B,
+                 int h, DropSpec d);
+// dX2[m][j] *= mask (all 2h columns, in place);  dxcnn[b][j] = sum_s dX2[s*B+b][h+j]
+void k_dx2_mask_reduce(hipStream_t st, int dtype, void *dx2, int64_t ld, int S, int B, int h, DropSpec d,
+                       float *dxcnn, int64_t ld_dxc);
+
+// Row-wise log-softmax + target pick + (optional) dlogits = (softmax - onehot) * scale   (lrcn.jl:562-567 and dual).
+// logits f32 [M][ld_l]; accumulates sum of log p(target) into *logp_sum (double).  dlog (T) may be NULL.
+void k_softmax_xent(hipStream_t st, int dtype, const float *logits, int64_t ld_l, const int32_t *tgt, int M, int V,
+                    float scale, double *logp_sum, void *dlog, int64_t ld_d);
+// prob[v] = exp(logp) for one row each (beam search, lrcn.jl:652).
+void k_softmax_rows(hipStream_t st, const float *logits, int64_t ld_l, int M, int V, float *prob, int64_t ld_p);
+
+// out[c][r + shift] = in[r][c] (0<=r<R, 0<=c<C), out[c][0..shift) = 0.  in_f32/out types: in is f32 if in_f32 else T;
+// out is always T.   (builds the K-contiguous transposed operands of the weight-gradient GEMMs)
+void k_transpose(hipStream_t st, int dtype, int in_f32, const void *in, int64_t ld_in, int R, int C, void *out,
+                 int64_t ld_out, int shift);
+// out_f32[c][r] = in[r][c], f32 -> f32 (boundary layout changes)
+void k_transpose_f32(hipStream_t st, const float *in, int64_t ld_in, int R, int C, float *out, int64_t ld_out);
+// out[r][c] = (T) in[r*ld_in + c]  (f32 -> T copy of a sub-matrix; pads [C, ld_out) with zeros)
+void k_cast_rows(hipStream_t st, int dtype, const float *in, int64_t ld_in, int R, int C, void *out, int64_t ld_out);
+// out_f32[r][c] = in[r][c] (T -> f32)
+void k_uncast_rows(hipStream_t st, int dtype, const void *in, int64_t ld_in, int R, int C, float *out, int64_t ld_out);
+
+// db[n] = sum_m Z[m][n]   (Z is T [M][ld]); f32 output, overwritten.
+void k_colsum(hipStream_t st, int dtype, const void *z, int64_t ld, int M, int N, float *out);
+
+struct AdamTensors {
+    float *w[9];
+    const float *g[9];
+    float *m[9];
+    float *v[9];
+    int64_t n[9];
+};
+// update! with Adam (lrcn.jl:394; Knet defaults), all 9 tensors in one launch.
+void k_adam(hipStream_t st, const AdamTensors &t, int step, float lr, float b1, float b2, float eps);
+// xavier-uniform / constant fill (initweights, lrcn.jl:489-510)
+void k_init_uniform(hipStream_t st, float *w, int64_t n, float scale, uint64_t seed, int tensor);
+void k_fill(hipStream_t st, float *w, int64_t n, float v);
+
+// ---- VGG side ----
+// conv weight (3,3,Cin,Cout) column-major f32 -> [Cout][tap = b*3+a][Cin_pad] T (zero padded channels)
+void k_repack_conv_w(hipStream_t st, int dtype, const float *w, int Cin, int Cout, int Cin_pad, void *out);
+// conv1_1 weight -> [64][ld] T with k = tap*3 + c (27 real, rest zero)
+void k_repack_conv11_w(hipStream_t st, int dtype, const float *w, int Cout, void *out, int64_t ld);
+// fc6 weight (4096 x 25088 column-major, k_ref = x + 7y + 49c) -> [4096][25088] T with k = (y*7+x)*512 + c
+void k_repack_fc6_w(hipStream_t st, int dtype, const float *w, void *out);
+// conv1_1 im2col from uint8 crops img[n][row][col][3]: A[m][k = tap*3+c] (T, ld), m window-major over (y=col, x=row);
+// value = pixel - mean[c], zero outside the image.                               (lrcn.jl:766-772 + :724)
+void k_im2col11_u8(hipStream_t st, int dtype, const uint8_t *img, int N, int S, float m0, float m1, float m2, void *out,
+                   int64_t ld);
+// same from the preprocessed float tensor x (S,S,3,N) column-major
+void k_im2col11_f32(hipStream_t st, int dtype, const float *x, int N, int S, void *out, int64_t ld);
+// out(i,j,c,n) = img[n][i][j][c] - mean[c]   (lrcn.jl:766-772)
+void k_preprocess_u8(hipStream_t st, const uint8_t *img, int N, int S, float m0, float m1, float m2, float *out);
+// reference (W,H,C,N) column-major f32 <-> internal NHWC [n][y][x][C_ld] T   (x = dim 1, y = dim 2)
+void k_ref_to_nhwc(hipStream_t st, int dtype, const float *x, int W, int H, int C, int N, void *out, int C_ld);
+void k_nhwc_to_ref(hipStream_t st, int dtype, const void *in, int W, int H, int C, int N, int C_ld, float *out);
+
+// ---- beam search (lrcn.jl:644-678) ----
+// For each of R rows of prob [R][ld]: the K largest entries in descending order, ties to the lower index.
+void k_topk_rows(hipStream_t st, const float *prob, int64_t ld, int R, int V, int K, int32_t *idx, float *val);
+// out[r][0..C) = in[src_row[r]][0..C)  (beam search parent-state gather, lrcn.jl:673-676); in != out.
+void k_gather_rows_f32(hipStream_t st, const float *in, int64_t ld, const int32_t *src_row, int R, int C, float *out);
+// out[i] = a[i] * b[i]
+void k_mul_f32(hipStream_t st, const float *a, const float *b, int64_t n, float *out);

@@ -1,0 +1,574 @@
+// kernels.hip -- the HBM-bound kernels around the MFMA contractions: embedding gather/scatter, fused LSTM cell
+// forward/backward, fused log-softmax + NLL + dlogits, dropout (counter hash), layout transposes, multi-tensor Adam,
+// VGG weight repacks / im2col for conv1_1 / preprocessing, top-K for beam search.  One wave = 64 lanes everywhere.
+#include "kernels.h"
+
+#include "common.h"
+#include "gemm.h"
+
+#define DISPATCH_T(dtype, ...)                    \
+    do {                                          \
+        if ((dtype) == GEMM_T_BF16) {             \
+            using T = bf16_t;                     \
+            __VA_ARGS__;                          \
+        } else {                                  \
+            using T = float;                      \
+            __VA_ARGS__;                          \
+        }                                         \
+    } while (0)
+
+namespace {
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ float hash_uniform(uint64_t seed, uint64_t stream, uint64_t idx) {
+    const uint64_t h = mix64(mix64(seed ^ (stream * 0xD1342543DE82EF95ull)) ^ idx);
+    return (float)(h >> 40) * (1.0f / 16777216.0f);
+}
+// Dropout multiplier of element (s, b, j) of a (T+1) x [B x ncols] tensor  (Knet dropout: x .* (rand .> p) ./ (1-p)).
+__device__ __forceinline__ float drop_mult(const DropSpec &d, int s, int b, int j, int B, int ncols) {
+    if (d.mask) return d.mask[((int64_t)s * ncols + j) * B + b];
+    if (d.p <= 0.0f) return 1.0f;
+    const uint64_t idx = ((uint64_t)s * B + b) * (uint64_t)ncols + j;
+    return hash_uniform(d.seed, (uint64_t)d.which, idx) > d.p ? 1.0f / (1.0f - d.p) : 0.0f;
+}
+
+__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ void build_tokens_kernel(const int32_t *tokens, int T, int B, int V, int32_t *tok_in, int32_t *tok_tgt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int S = T + 1;
+    if (i >= S * B) return;
+    const int s = i / B, b = i - s * B;
+    int in = (s == 0) ? 1 : tokens[(s - 1) * B + b];
+    int tg = (s < T) ? tokens[s * B + b] : 0;
+    // out-of-range ids would fault the gather: clamp to unk (the reference would raise BoundsError)
+    if ((unsigned)in >= (unsigned)V) in = 2;
+    if ((unsigned)tg >= (unsigned)V) tg = 2;
+    tok_in[i] = in;
+    tok_tgt[i] = tg;
+}
+
+template <typename T>
+__global__ void embed_gather_kernel(const T *wembT, int64_t ld_w, const int32_t *tok_in, int S, int B, int E, DropSpec d,
+                                    T *xemb, int64_t ld_x) {
+    const int m = blockIdx.x;
+    const int s = m / B, b = m - s * B;
+    const T *src = wembT + (int64_t)tok_in[m] * ld_w;
+    T *dst = xemb + (int64_t)m * ld_x;
+    for (int e = threadIdx.x; e < E; e += blockDim.x) dst[e] = from_f32<T>(to_f32(src[e]) * drop_mult(d, s, b, e, B, E));
+}
+
+__global__ void embed_scatter_kernel(const float *dxemb, int64_t ld_dx, const int32_t *tok_in, int S, int B, int E, int V,
+                                     DropSpec d, float *dwembed) {
+    const int m = blockIdx.x;
+    const int s = m / B, b = m - s * B;
+    const int tok = tok_in[m];
+    const float *src = dxemb + (int64_t)m * ld_dx;
+    for (int e = threadIdx.x; e < E; e += blockDim.x) {
+        const float v = src[e] * drop_mult(d, s, b, e, B, E);
+        if (v != 0.0f) atomicAdd(dwembed + (int64_t)e * V + tok, v);
+    }
+}
+
+template <typename T>
+__global__ void lstm_fwd_kernel(const float *G, int64_t ld_g, const float *c_prev, int B, int H, T *acts, int64_t ld_a,
+                                float *c_new, T *h_new, int64_t ld_h, float *h_new_f32) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (j >= H) return;
+    const float *g = G + (int64_t)b * ld_g;
+    const float f = sigm(g[j]), i = sigm(g[H + j]), o = sigm(g[2 * H + j]), ch = tanhf(g[3 * H + j]);
+    const float cp = c_prev ? c_prev[(int64_t)b * H + j] : 0.0f;
+    const float c = cp * f + i * ch;
+    const float h = o * tanhf(c);
+    T *a = acts + (int64_t)b * ld_a;
+    a[j] = from_f32<T>(f);
+    a[H + j] = from_f32<T>(i);
+    a[2 * H + j] = from_f32<T>(o);
+    a[3 * H + j] = from_f32<T>(ch);
+    c_new[(int64_t)b * H + j] = c;
+    h_new[(int64_t)b * ld_h + j] = from_f32<T>(h);
+    if (h_new_f32) h_new_f32[(int64_t)b * H + j] = h;
+}
+
+template <typename T>
+__global__ void lstm_bwd_kernel(const T *acts, int64_t ld_a, const float *c_prev, const float *c_new, const float *dh_a,
+                                int64_t ld_dha, const float *dh_b, float *dc, int B, int H, T *dz, int64_t ld_dz) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (j >= H) return;
+    const T *a = acts + (int64_t)b * ld_a;
+    const float f = to_f32(a[j]), i = to_f32(a[H + j]), o = to_f32(a[2 * H + j]), g = to_f32(a[3 * H + j]);
+    const float tc = tanhf(c_new[(int64_t)b * H + j]);
+    float dh = dh_a[(int64_t)b * ld_dha + j];
+    if (dh_b) dh += dh_b[(int64_t)b * H + j];
+    const float dov = dh * tc;
+    const float dcv = dc[(int64_t)b * H + j] + dh * o * (1.0f - tc * tc);
+    const float cp = c_prev ? c_prev[(int64_t)b * H + j] : 0.0f;
+    T *z = dz + (int64_t)b * ld_dz;
+    z[j] = from_f32<T>(dcv * cp * f * (1.0f - f));
+    z[H + j] = from_f32<T>(dcv * g * i * (1.0f - i));
+    z[2 * H + j] = from_f32<T>(dov * o * (1.0f - o));
+    z[3 * H + j] = from_f32<T>(dcv * i * (1.0f - g * g));
+    dc[(int64_t)b * H + j] = dcv * f;
+}
+
+template <typename T>
+__global__ void concat_x2_kernel(T *x2, int64_t ld_x2, const float *xcnn, int64_t ld_xc, int S, int B, int h, DropSpec d) {
+    const int m = blockIdx.x;
+    const int s = m / B, b = m - s * B;
+    T *row = x2 + (int64_t)m * ld_x2;
+    for (int j = threadIdx.x; j < 2 * h; j += blockDim.x) {
+        const float v = (j < h) ? to_f32(row[j]) : xcnn[(int64_t)b * ld_xc + (j - h)];
+        row[j] = from_f32<T>(v * drop_mult(d, s, b, j, B, 2 * h));
+    }
+}
+
+template <typename T>
+__global__ void dx2_mask_reduce_kernel(T *dx2, int64_t ld, int S, int B, int h, DropSpec d, float *dxcnn, int64_t ld_dxc) {
+    const int b = blockIdx.x;
+    for (int j = threadIdx.x; j < 2 * h; j += blockDim.x) {
+        float acc = 0.0f;
+        for (int s = 0; s < S; ++s) {
+            T *p = dx2 + (int64_t)(s * B + b) * ld + j;
+            const float v = to_f32(*p) * drop_mult(d, s, b, j, B, 2 * h);
+            *p = from_f32<T>(v);
+            acc += v;
+        }
+        if (j >= h) dxcnn[(int64_t)b * ld_dxc + (j - h)] = acc;
+    }
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float block_max(float v, float *sh) {
+    v = wave_max(v);
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    float r = sh[0];
+    for (int i = 1; i < nw; ++i) r = fmaxf(r, sh[i]);
+    return r;
+}
+__device__ __forceinline__ float block_sum(float v, float *sh) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    float r = 0.0f;
+    for (int i = 0; i < nw; ++i) r += sh[i];
+    return r;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_xent_kernel(const float *logits, int64_t ld_l, const int32_t *tgt, int M,
+                                                           int V, float scale, double *logp_sum, T *dlog, int64_t ld_d) {
+    __shared__ float sh[8];
+    const int m = blockIdx.x;
+    const float *row = logits + (int64_t)m * ld_l;
+    float mx = -INFINITY;
+    for (int v = threadIdx.x; v < V; v += blockDim.x) mx = fmaxf(mx, row[v]);
+    mx = block_max(mx, sh);
+    float se = 0.0f;
+    for (int v = threadIdx.x; v < V; v += blockDim.x) se += expf(row[v] - mx);
+    se = block_sum(se, sh);
+    const float lse = mx + logf(se);
+    const int t = tgt[m];
+    if (threadIdx.x == 0) atomicAdd(logp_sum, (double)(row[t] - lse));
+    if (dlog) {
+        T *drow = dlog + (int64_t)m * ld_d;
+        for (int v = threadIdx.x; v < V; v += blockDim.x) {
+            const float p = expf(row[v] - lse);
+            drow[v] = from_f32<T>((p - (v == t ? 1.0f : 0.0f)) * scale);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float *logits, int64_t ld_l, int M, int V, float *prob,
+                                                           int64_t ld_p) {
+    __shared__ float sh[8];
+    const int m = blockIdx.x;
+    const float *row = logits + (int64_t)m * ld_l;
+    float mx = -INFINITY;
+    for (int v = threadIdx.x; v < V; v += blockDim.x) mx = fmaxf(mx, row[v]);
+    mx = block_max(mx, sh);
+    float se = 0.0f;
+    for (int v = threadIdx.x; v < V; v += blockDim.x) se += expf(row[v] - mx);
+    se = block_sum(se, sh);
+    const float lse = mx + logf(se);
+    for (int v = threadIdx.x; v < V; v += blockDim.x) prob[(int64_t)m * ld_p + v] = expf(row[v] - lse);
+}
+
+template <typename Tin, typename Tout>
+__global__ void transpose_kernel(const Tin *in, int64_t ld_in, int R, int C, Tout *out, int64_t ld_out, int shift) {
+    __shared__ float tile[32][33];
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: ty 0..7
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < C) ? to_f32(in[(int64_t)r * ld_in + c]) : 0.0f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < C && r < R) out[(int64_t)c * ld_out + r + shift] = from_f32<Tout>(tile[tx][i]);
+    }
+    if (shift > 0 && blockIdx.y == 0) {
+        for (int i = ty; i < 32; i += 8) {
+            const int c = c0 + i;
+            if (c < C)
+                for (int r = tx; r < shift; r += 32) out[(int64_t)c * ld_out + r] = from_f32<Tout>(0.0f);
+        }
+    }
+}
+
+template <typename T>
+__global__ void cast_rows_kernel(const float *in, int64_t ld_in, int R, int C, T *out, int64_t ld_out) {
+    const int r = blockIdx.y;
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < ld_out; c += gridDim.x * blockDim.x)
+        out[(int64_t)r * ld_out + c] = from_f32<T>(c < C ? in[(int64_t)r * ld_in + c] : 0.0f);
+}
+template <typename T>
+__global__ void uncast_rows_kernel(const T *in, int64_t ld_in, int R, int C, float *out, int64_t ld_out) {
+    const int r = blockIdx.y;
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x)
+        out[(int64_t)r * ld_out + c] = to_f32(in[(int64_t)r * ld_in + c]);
+}
+
+template <typename T> __global__ void colsum_kernel(const T *z, int64_t ld, int M, int N, float *out) {
+    // block = 64 columns x 4 row groups
+    __shared__ float sh[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    float acc = 0.0f;
+    if (c < N)
+        for (int m = rg; m < M; m += 4) acc += to_f32(z[(int64_t)m * ld + c]);
+    sh[rg][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (rg == 0 && c < N) out[c] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+}
+
+__global__ void adam_kernel(AdamTensors t, float lr, float b1, float b2, float eps, float c1, float c2) {
+    const int k = blockIdx.y;
+    const int64_t n = t.n[k];
+    float *w = t.w[k], *m = t.m[k], *v = t.v[k];
+    const float *g = t.g[k];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        w[i] -= lr * (mi / c1) / (sqrtf(vi / c2) + eps);
+    }
+}
+
+__global__ void init_uniform_kernel(float *w, int64_t n, float scale, uint64_t seed, int tensor) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t h = mix64(mix64(seed ^ ((uint64_t)(tensor + 1) * 0xD1342543DE82EF95ull)) ^ (uint64_t)i);
+        const double u = (double)(h >> 11) * (1.0 / 9007199254740992.0);
+        w[i] = (float)(2.0 * (double)scale * u - (double)scale);
+    }
+}
+__global__ void fill_kernel(float *w, int64_t n, float v) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) w[i] = v;
+}
+
+// ---- VGG ----
+template <typename T> __global__ void repack_conv_w_kernel(const float *w, int Cin, int Cout, int Cin_pad, T *out) {
+    // w(a,b,ci,co) at a + 3*(b + 3*(ci + Cin*co));  out[co][tap=b*3+a][ci]
+    const int64_t total = (int64_t)Cout * 9 * Cin_pad;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % Cin_pad);
+        const int tap = (int)((i / Cin_pad) % 9);
+        const int co = (int)(i / ((int64_t)Cin_pad * 9));
+        const int b = tap / 3, a = tap - 3 * b;
+        out[i] = from_f32<T>(ci < Cin ? w[a + 3 * (b + 3 * ((int64_t)ci + (int64_t)Cin * co))] : 0.0f);
+    }
+}
+template <typename T> __global__ void repack_conv11_w_kernel(const float *w, int Cout, T *out, int64_t ld) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Cout * ld) return;
+    const int k = i % ld, co = i / ld;
+    float v = 0.0f;
+    if (k < 27) {
+        const int tap = k / 3, c = k - 3 * tap;
+        const int b = tap / 3, a = tap - 3 * b;
+        v = w[a + 3 * (b + 3 * (c + 3 * co))];
+    }
+    out[i] = from_f32<T>(v);
+}
+template <typename T> __global__ void repack_fc6_w_kernel(const float *w, T *out) {
+    // out[o][(y*7+x)*512 + c] = w(o, x + 7y + 49c) = w[o + 4096*(x + 7y + 49c)]; tiled through LDS for coalescing both ways
+    __shared__ float tile[32][33];
+    const int k0 = blockIdx.x * 32, o0 = blockIdx.y * 32;  // k = internal index
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int k = k0 + i;  // internal k -> ref k
+        const int c = k % 512, yx = k / 512, y = yx / 7, x = yx - 7 * y;
+        const int kref = x + 7 * y + 49 * c;
+        tile[i][tx] = w[(int64_t)(o0 + tx) + 4096ll * kref];
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) out[(int64_t)(o0 + i) * 25088 + k0 + tx] = from_f32<T>(tile[tx][i]);
+}
+
+template <typename T, bool U8>
+__global__ void im2col11_kernel(const void *src, int N, int S, float m0, float m1, float m2, T *out, int64_t ld) {
+    // one thread per (m, tap); writes 3 channels.  internal (y, x) = (dim 2, dim 1) of the reference tensor;
+    // for the uint8 path reference dim 1 = image row, dim 2 = image col (lrcn.jl:766-771).
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t M = (int64_t)N * S * S;
+    if (idx >= M * 9) return;  // columns [27, ld) are never read: the GEMM loader masks k >= K = 27
+    const int tap = (int)(idx % 9);
+    const int m = (int)(idx / 9);
+    T *row = out + (int64_t)m * ld;
+    const PixDecode p = decode_pixel(m, S, S);
+    const int kh = tap / 3, kw = tap - 3 * kh;
+    const int y = p.y + kh - 1, x = p.x + kw - 1;
+    float v[3] = {0.0f, 0.0f, 0.0f};
+    if ((unsigned)y < (unsigned)S && (unsigned)x < (unsigned)S) {
+        if (U8) {
+            const uint8_t *px = reinterpret_cast<const uint8_t *>(src) + (((int64_t)p.n * S + x) * S + y) * 3;  // row=x, col=y
+            v[0] = (float)px[0] - m0;
+            v[1] = (float)px[1] - m1;
+            v[2] = (float)px[2] - m2;
+        } else {
+            const float *f = reinterpret_cast<const float *>(src);
+            for (int c = 0; c < 3; ++c) v[c] = f[(int64_t)x + (int64_t)S * (y + (int64_t)S * (c + 3ll * p.n))];
+        }
+    }
+    for (int c = 0; c < 3; ++c) row[tap * 3 + c] = from_f32<T>(v[c]);
+}
+
+__global__ void preprocess_u8_kernel(const uint8_t *img, int N, int S, float m0, float m1, float m2, float *out) {
+    const int64_t total = (int64_t)N * 3 * S * S;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ii = (int)(i % S), j = (int)((i / S) % S), c = (int)((i / ((int64_t)S * S)) % 3);
+        const int n = (int)(i / (3ll * S * S));
+        const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2);
+        out[i] = (float)img[(((int64_t)n * S + ii) * S + j) * 3 + c] - mean;
+    }
+}
+
+template <typename T> __global__ void ref_to_nhwc_kernel(const float *x, int W, int H, int C, int N, T *out, int C_ld) {
+    const int64_t total = (int64_t)N * H * W * C_ld;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C_ld);
+        const int xx = (int)((i / C_ld) % W), yy = (int)((i / ((int64_t)C_ld * W)) % H);
+        const int n = (int)(i / ((int64_t)C_ld * W * H));
+        out[i] = from_f32<T>(c < C ? x[(int64_t)xx + (int64_t)W * (yy + (int64_t)H * (c + (int64_t)C * n))] : 0.0f);
+    }
+}
+template <typename T> __global__ void nhwc_to_ref_kernel(const T *in, int W, int H, int C, int N, int C_ld, float *out) {
+    const int64_t total = (int64_t)N * C * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int xx = (int)(i % W), yy = (int)((i / W) % H), c = (int)((i / ((int64_t)W * H)) % C);
+        const int n = (int)(i / ((int64_t)W * H * C));
+        out[i] = to_f32(in[(((int64_t)n * H + yy) * W + xx) * C_ld + c]);
+    }
+}
+
+// Top-K of each row, descending, ties to the lower index (Julia's stable sortperm(rev=true), lrcn.jl:655).
+// One 256-thread block per row; K rounds of block-wide argmax with the winners masked out. K <= 32.
+__global__ __launch_bounds__(256) void topk_rows_kernel(const float *prob, int64_t ld, int R, int V, int K, int32_t *idx,
+                                                        float *val) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    __shared__ int chosen[32];
+    const int r = blockIdx.x;
+    const float *row = prob + (int64_t)r * ld;
+    for (int k = 0; k < K; ++k) {
+        float bv = -INFINITY;
+        int bi = 0x7FFFFFFF;
+        for (int v = threadIdx.x; v < V; v += blockDim.x) {
+            bool taken = false;
+            for (int q = 0; q < k; ++q) taken |= (chosen[q] == v);
+            const float x = row[v];
+            if (!taken && (x > bv || (x == bv && v < bi))) {
+                bv = x;
+                bi = v;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o);
+            const int oi = __shfl_xor(bi, o);
+            if (ov > bv || (ov == bv && oi < bi)) {
+                bv = ov;
+                bi = oi;
+            }
+        }
+        if ((threadIdx.x & 63) == 0) {
+            sv[threadIdx.x >> 6] = bv;
+            si[threadIdx.x >> 6] = bi;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < 4; ++w)
+                if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) {
+                    bv = sv[w];
+                    bi = si[w];
+                }
+            chosen[k] = bi;
+            idx[r * K + k] = bi;
+            val[r * K + k] = bv;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void gather_rows_f32_kernel(const float *in, int64_t ld, const int32_t *src_row, int R, int C, float *out) {
+    const int r = blockIdx.x;
+    const float *s = in + (int64_t)src_row[r] * ld;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) out[(int64_t)r * ld + c] = s[c];
+}
+
+__global__ void mul_f32_kernel(const float *a, const float *b, int64_t n, float *out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = a[i] * b[i];
+}
+
+inline unsigned grid1d(int64_t n, int block = 256, int64_t cap = 8192) {
+    int64_t g = (n + block - 1) / block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------- launchers
+void k_build_tokens(hipStream_t st, const int32_t *tokens, int T, int B, int V, int32_t *tok_in, int32_t *tok_tgt) {
+    const int n = (T + 1) * B;
+    hipLaunchKernelGGL(build_tokens_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, tokens, T, B, V, tok_in, tok_tgt);
+}
+void k_embed_gather(hipStream_t st, int dtype, const void *wembT, int64_t ld_w, const int32_t *tok_in, int S, int B, int E,
+                    DropSpec d, void *xemb, int64_t ld_x) {
+    DISPATCH_T(dtype, hipLaunchKernelGGL(embed_gather_kernel<T>, dim3(S * B), dim3(256), 0, st, (const T *)wembT, ld_w,
+                                         tok_in, S, B, E, d, (T *)xemb, ld_x));
+}
+void k_embed_scatter(hipStream_t st, const float *dxemb, int64_t ld_dx, const int32_t *tok_in, int S, int B, int E, int V,
+                     DropSpec d, float *dwembed) {
+    hipLaunchKernelGGL(embed_scatter_kernel, dim3(S * B), dim3(256), 0, st, dxemb, ld_dx, tok_in, S, B, E, V, d, dwembed);
+}
+void k_lstm_fwd(hipStream_t st, int dtype, const float *G, int64_t ld_g, const float *c_prev, int B, int H, void *acts,
+                int64_t ld_a, float *c_new, void *h_new, int64_t ld_h, float *h_new_f32) {
+    DISPATCH_T(dtype, hipLaunchKernelGGL(lstm_fwd_kernel<T>, dim3(cdiv(H, 256), B), dim3(256), 0, st, G, ld_g, c_prev, B, H,
+                                         (T *)acts, ld_a, c_new, (T *)h_new, ld_h, h_new_f32));
+}
+void k_lstm_bwd(hipStream_t st, int dtype, const void *acts, int64_t ld_a, const float *c_prev, const float *c_new,
+                const float *dh_a, int64_t ld_dha, const float *dh_b, float *dc, int B, int H, void *dz, int64_t ld_dz) {
+    DISPATCH_T(dtype, hipLaunchKernelGGL(lstm_bwd_kernel<T>, dim3(cdiv(H, 256), B), dim3(256), 0, st, (const T *)acts, ld_a,
+                                         c_prev, c_new, dh_a, ld_dha, dh_b, dc, B, H, (T *)dz, ld_dz));
+}
+void k_concat_x2(hipStream_t st, int dtype, void *x2, int64_t ld_x2, const float *xcnn, int64_t ld_xc, int S, int B, int h,
+                 DropSpec d) {
+    DISPATCH_T(dtype, hipLaunchKernelGGL(concat_x2_kernel<T>, dim3(S * B), dim3(256), 0, st, (T *)x2, ld_x2, xcnn, ld_xc, S,
+                                         B, h, d));
+}
+void k_dx2_mask_reduce(hipStream_t st, int dtype, void *dx2, int64_t ld, int S, int B, int h, DropSpec d, float *dxcnn,
+                       int64_t ld_dxc) {
+    DISPATCH_T(dtype, hipLaunchKernelGGL(dx2_mask_reduce_kernel<T>, dim3(B), dim3(256), 0, st, (T *)dx2, ld, S, B, h, d,
+                                         dxcnn, ld_dxc));
+}
+void k_softmax_xent(hipStream_t st, int dtype, const float *logits, int64_t ld_l, const int32_t *tgt, int M, int V,
+                    float scale, double *logp_sum, void *dlog, int64_t ld_d) {
+    DISPATCH_T(dtype, hipLaunchKernelGGL(softmax_xent_kernel<T>, dim3(M), dim3(256), 0, st, logits, ld_l, tgt, M, V, scale,
+                                         logp_sum, (T *)dlog, ld_d));
+}
+void k_softmax_rows(hipStream_t st, const float *logits, int64_t ld_l, int M, int V, float *prob, int64_t ld_p) {
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(M), dim3(256), 0, st, logits, ld_l, M, V, prob, ld_p);
+}
+void k_transpose(hipStream_t st, int dtype, int in_f32, const void *in, int64_t ld_in, int R, int C, void *out,
+                 int64_t ld_out, int shift) {
+    const dim3 grid(cdiv(C, 32), cdiv(R, 32));
+    DISPATCH_T(dtype, {
+        if (in_f32)
+            hipLaunchKernelGGL((transpose_kernel<float, T>), grid, dim3(256), 0, st, (const float *)in, ld_in, R, C, (T *)out,
+                               ld_out, shift);
+        else
+            hipLaunchKernelGGL((transpose_kernel<T, T>), grid, dim3(256), 0, st, (const T *)in, ld_in, R, C, (T *)out, ld_out,
+                               shift);
+    });
+}
+void k_transpose_f32(hipStream_t st, const float *in, int64_t ld_in, int R, int C, float *out, int64_t ld_out) {
+    hipLaunchKernelGGL((transpose_kernel<float, float>), dim3(cdiv(C, 32), cdiv(R, 32)), dim3(256), 0, st, in, ld_in, R, C,
+                       out, ld_out, 0);
+}
+void k_cast_rows(hipStream_t st, int dtype, const float *in, int64_t ld_in, int R, int C, void *out, int64_t ld_out) {
+    const dim3 grid(cdiv(ld_out, 256) > 64 ? 64 : cdiv(ld_out, 256), R);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(cast_rows_kernel<T>, grid, dim3(256), 0, st, in, ld_in, R, C, (T *)out, ld_out));
+}
+void k_uncast_rows(hipStream_t st, int dtype, const void *in, int64_t ld_in, int R, int C, float *out, int64_t ld_out) {
+    const dim3 grid(cdiv(C, 256) > 64 ? 64 : cdiv(C, 256), R);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(uncast_rows_kernel<T>, grid, dim3(256), 0, st, (const T *)in, ld_in, R, C, out,
+                                         ld_out));
+}
+void k_colsum(hipStream_t st, int dtype, const void *z, int64_t ld, int M, int N, float *out) {
+    DISPATCH_T(dtype, hipLaunchKernelGGL(colsum_kernel<T>, dim3(cdiv(N, 64)), dim3(256), 0, st, (const T *)z, ld, M, N, out));
+}
+void k_adam(hipStream_t st, const AdamTensors &t, int step, float lr, float b1, float b2, float eps) {
+    const float c1 = (float)(1.0 - pow((double)b1, (double)step)), c2 = (float)(1.0 - pow((double)b2, (double)step));
+    hipLaunchKernelGGL(adam_kernel, dim3(1024, 9), dim3(256), 0, st, t, lr, b1, b2, eps, c1, c2);
+}
+void k_init_uniform(hipStream_t st, float *w, int64_t n, float scale, uint64_t seed, int tensor) {
+    hipLaunchKernelGGL(init_uniform_kernel, dim3(grid1d(n)), dim3(256), 0, st, w, n, scale, seed, tensor);
+}
+void k_fill(hipStream_t st, float *w, int64_t n, float v) {
+    hipLaunchKernelGGL(fill_kernel, dim3(grid1d(n)), dim3(256), 0, st, w, n, v);
+}
+void k_repack_conv_w(hipStream_t st, int dtype, const float *w, int Cin, int Cout, int Cin_pad, void *out) {
+    DISPATCH_T(dtype, hipLaunchKernelGGL(repack_conv_w_kernel<T>, dim3(grid1d((int64_t)Cout * 9 * Cin_pad)), dim3(256), 0, st,
+                                         w, Cin, Cout, Cin_pad, (T *)out));
+}
+void k_repack_conv11_w(hipStream_t st, int dtype, const float *w, int Cout, void *out, int64_t ld) {
+    DISPATCH_T(dtype, hipLaunchKernelGGL(repack_conv11_w_kernel<T>, dim3(cdiv(Cout * ld, 256)), dim3(256), 0, st, w, Cout,
+                                         (T *)out, ld));
+}
+void k_repack_fc6_w(hipStream_t st, int dtype, const float *w, void *out) {
+    DISPATCH_T(dtype, hipLaunchKernelGGL(repack_fc6_w_kernel<T>, dim3(25088 / 32, 4096 / 32), dim3(256), 0, st, w, (T *)out));
+}
+void k_im2col11_u8(hipStream_t st, int dtype, const uint8_t *img, int N, int S, float m0, float m1, float m2, void *out,
+                   int64_t ld) {
+    const int64_t n = (int64_t)N * S * S * 9;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((im2col11_kernel<T, true>), dim3(cdiv(n, 256)), dim3(256), 0, st, (const void *)img,
+                                         N, S, m0, m1, m2, (T *)out, ld));
+}
+void k_im2col11_f32(hipStream_t st, int dtype, const float *x, int N, int S, void *out, int64_t ld) {
+    const int64_t n = (int64_t)N * S * S * 9;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((im2col11_kernel<T, false>), dim3(cdiv(n, 256)), dim3(256), 0, st, (const void *)x, N,
+                                         S, 0.f, 0.f, 0.f, (T *)out, ld));
+}
+void k_preprocess_u8(hipStream_t st, const uint8_t *img, int N, int S, float m0, float m1, float m2, float *out) {
+    hipLaunchKernelGGL(preprocess_u8_kernel, dim3(grid1d((int64_t)N * 3 * S * S)), dim3(256), 0, st, img, N, S, m0, m1, m2,
+                       out);
+}
+void k_ref_to_nhwc(hipStream_t st, int dtype, const float *x, int W, int H, int C, int N, void *out, int C_ld) {
+    DISPATCH_T(dtype, hipLaunchKernelGGL(ref_to_nhwc_kernel<T>, dim3(grid1d((int64_t)N * H * W * C_ld)), dim3(256), 0, st, x,
+                                         W, H, C, N, (T *)out, C_ld));
+}
+void k_nhwc_to_ref(hipStream_t st, int dtype, const void *in, int W, int H, int C, int N, int C_ld, float *out) {
+    DISPATCH_T(dtype, hipLaunchKernelGGL(nhwc_to_ref_kernel<T>, dim3(grid1d((int64_t)N * C * H * W)), dim3(256), 0, st,
+                                         (const T *)in, W, H, C, N, C_ld, out));
+}
+void k_topk_rows(hipStream_t st, const float *prob, int64_t ld, int R, int V, int K, int32_t *idx, float *val) {
+    hipLaunchKernelGGL(topk_rows_kernel, dim3(R), dim3(256), 0, st, prob, ld, R, V, K, idx, val);
+}
+void k_gather_rows_f32(hipStream_t st, const float *in, int64_t ld, const int32_t *src_row, int R, int C, float *out) {
+    hipLaunchKernelGGL(gather_rows_f32_kernel, dim3(R), dim3(256), 0, st, in, ld, src_row, R, C, out);
+}
+void k_mul_f32(hipStream_t st, const float *a, const float *b, int64_t n, float *out) {
+    hipLaunchKernelGGL(mul_f32_kernel, dim3(grid1d(n)), dim3(256), 0, st, a, b, n, out);
+}

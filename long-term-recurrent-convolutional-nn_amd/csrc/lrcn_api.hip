@@ -1,0 +1,936 @@
+// lrcn_api.hip -- context, workspace and the C ABI of liblrcn_hip.so (include/lrcn.h).
+//
+// Orchestration of the hot path on one gfx950 device.  The reference runs lrcn() once per timestep with ~50 tiny
+// kernels and a blocking D2H per step (lrcn.jl:560-570); here everything that does not feed back through the
+// recurrence is time-batched over all S = T+1 steps (M = S*B rows, row m = s*B + b):
+//   forward : embedding gather (+dropout) -> input-side gate GEMM for all steps -> S x [recurrent GEMM (beta=1) + fused
+//             cell] -> projection GEMM -> concat/dropout -> LSTM-2 likewise -> ONE logits GEMM for all steps -> fused
+//             log-softmax / NLL / dlogits with on-device double accumulation (no per-step D2H).
+//   backward: dWout/dH2 GEMMs for all steps -> reverse recurrence (fused cell backward + one GEMM per step) ->
+//             time-batched weight-gradient GEMMs (K = S*B) -> projection/x_cnn/embedding duals.
+// Internal activations are row-major [row][feature] (K-contiguous) in the context's arithmetic type T (f32 or bf16);
+// the column-major f32 arrays of the ABI are converted at the boundary.  Every contraction is the NT MFMA kernel of
+// gemm.hip; operands that the math wants transposed are materialised K-contiguous by k_transpose.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/lrcn.h"
+#include "common.h"
+#include "gemm.h"
+#include "kernels.h"
+
+static thread_local std::string g_create_err;
+
+struct VggLayer {
+    void *w = nullptr;    // [Cout][9*Cin] T (conv) ; conv1_1: [64][32]
+    float *b = nullptr;   // [Cout] f32
+    int Cin = 0, Cout = 0, S = 0, pool = 0;
+};
+
+struct lrcn_ctx {
+    lrcn_config cfg{};
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::vector<void *> allocs;
+    int dt = 0, vdt = 0;
+    size_t esz = 4, vesz = 4;
+    int E = 0, H1 = 0, H2 = 0, h = 0, V = 0, maxB = 0, maxS = 0;
+    int64_t ldE = 0, ldH1 = 0, ldH2 = 0, ldh = 0, ld4H1 = 0, ld4H2 = 0, ldV = 0, ldM = 0, ldB = 0;
+    // shadow weights (T)
+    void *W1x = nullptr, *W1h = nullptr, *W1xT = nullptr, *W1hT = nullptr;
+    void *W2x = nullptr, *W2h = nullptr, *W2xT = nullptr, *W2hT = nullptr;
+    void *Wpd = nullptr, *WpT = nullptr, *Wcd = nullptr, *WeT = nullptr, *Wod = nullptr, *WoT = nullptr;
+    // activations
+    int32_t *tok = nullptr, *tok_in = nullptr, *tok_tgt = nullptr;
+    void *F = nullptr, *FT = nullptr;
+    float *xcnn = nullptr;
+    void *Xemb = nullptr, *A1 = nullptr, *H1all = nullptr, *X2 = nullptr, *A2 = nullptr, *H2all = nullptr;
+    float *G1 = nullptr, *C1 = nullptr, *G2 = nullptr, *C2 = nullptr, *Logits = nullptr;
+    void *dLog = nullptr, *dZ1 = nullptr, *dZ2 = nullptr, *dX2 = nullptr;
+    float *dH1all = nullptr, *dH2all = nullptr, *dXemb = nullptr, *dhrec = nullptr, *dc = nullptr, *dxcnn = nullptr;
+    void *TA = nullptr, *TB = nullptr;  // transposed-operand scratch: up to [max(4H,V)][ldM] and [max(E,H,4096)][ldM]
+    void *dxcT = nullptr;
+    double *logp = nullptr;
+    int last_norm = 1, last_S = 1;
+    // single-step scratch (lrcn_lstm / lrcn_step / beam search), row-major
+    float *st_f32[4] = {nullptr, nullptr, nullptr, nullptr};   // h1,c1,h2,c2 [B][H]
+    float *st2_f32[4] = {nullptr, nullptr, nullptr, nullptr};  // ping-pong for the beam gather
+    void *st_h1 = nullptr, *st_h2 = nullptr, *st_x = nullptr, *st_x2 = nullptr, *st_a = nullptr;
+    float *st_g = nullptr, *st_logits = nullptr, *st_prob = nullptr, *st_io = nullptr, *st_topv = nullptr;
+    int32_t *st_topi = nullptr, *st_parent = nullptr;
+    // VGG
+    bool vgg_loaded = false;
+    VggLayer conv[13];
+    void *fc6w = nullptr, *fc7w = nullptr;
+    float *fc6b = nullptr, *fc7b = nullptr;
+    void *actA = nullptr, *actB = nullptr, *im2col = nullptr, *f6 = nullptr;
+    float *featsRM = nullptr;  // [N][4096] f32 row-major
+};
+
+#define FAIL(ctx, code, ...)                          \
+    do {                                              \
+        char _b[512];                                 \
+        snprintf(_b, sizeof(_b), __VA_ARGS__);        \
+        (ctx)->err = _b;                              \
+        return (code);                                \
+    } while (0)
+#define HIPCHK(ctx, expr)                                                                        \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess) FAIL(ctx, LRCN_EHIP, "%s: %s", #expr, hipGetErrorString(_e));      \
+    } while (0)
+#define KCHK(ctx, what)                                                                          \
+    do {                                                                                         \
+        hipError_t _e = hipGetLastError();                                                       \
+        if (_e != hipSuccess) FAIL(ctx, LRCN_EHIP, "%s: %s", what, hipGetErrorString(_e));       \
+    } while (0)
+
+namespace {
+
+template <class P> int dalloc(lrcn_ctx *c, P *&p, size_t bytes) {
+    void *q = nullptr;
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) {
+        c->err = std::string("hipMalloc failed: ") + hipGetErrorString(e);
+        return LRCN_ENOMEM;
+    }
+    c->allocs.push_back(q);
+    p = reinterpret_cast<P *>(q);
+    return LRCN_OK;
+}
+#define DALLOC(c, p, bytes)                         \
+    do {                                            \
+        int _r = dalloc(c, p, (size_t)(bytes));     \
+        if (_r) return _r;                          \
+    } while (0)
+
+inline int64_t ld8(int64_t n) { return round_up64(n, 8); }
+inline char *boff(void *p, int64_t elems, size_t esz) { return reinterpret_cast<char *>(p) + elems * (int64_t)esz; }
+inline const char *boff(const void *p, int64_t elems, size_t esz) {
+    return reinterpret_cast<const char *>(p) + elems * (int64_t)esz;
+}
+
+// C[M][N] (+)= A[M][K] * B[N][K]^T
+int gemm(lrcn_ctx *c, int dtype, const void *A, int64_t lda, const void *B, int64_t ldb, void *C, int64_t ldc, int M, int N,
+         int K, const float *bias, bool c_f32, bool beta = false, bool relu = false) {
+    GemmArgs g{};
+    g.dtype = dtype;
+    g.A = A;
+    g.lda = lda;
+    g.B = B;
+    g.ldb = ldb;
+    g.C = C;
+    g.ldc = ldc;
+    g.M = M;
+    g.N = N;
+    g.K = K;
+    g.bias = bias;
+    g.c_f32 = c_f32;
+    g.beta = beta;
+    g.relu = relu;
+    g.a_mode = GEMM_A_PLAIN;
+    g.out_mode = GEMM_OUT_PLAIN;
+    hipError_t e = launch_gemm(c->stream, g);
+    if (e != hipSuccess) FAIL(c, LRCN_EHIP, "gemm M=%d N=%d K=%d: %s", M, N, K, hipGetErrorString(e));
+    return LRCN_OK;
+}
+#define GEMM(...)                     \
+    do {                              \
+        int _r = gemm(__VA_ARGS__);   \
+        if (_r) return _r;            \
+    } while (0)
+
+DropSpec make_drop(const lrcn_dropout *d, int which) {
+    DropSpec s{};
+    s.which = which;
+    if (d) {
+        s.p = d->pdrop;
+        s.seed = d->seed;
+        s.mask = which == 1 ? d->mask1 : d->mask2;
+        if (s.mask) s.p = 0.0f;
+    }
+    return s;
+}
+
+// f32 column-major params -> K-contiguous shadows in T (direct and transposed).  See DESIGN.md "shadow weights".
+int prepare_weights(lrcn_ctx *c, const float *const p[9], bool need_bwd) {
+    const int dt = c->dt, E = c->E, H1 = c->H1, H2 = c->H2, h = c->h, V = c->V;
+    hipStream_t st = c->stream;
+    // W1: memory [4H1][E+H1]
+    k_cast_rows(st, dt, p[0], E + H1, 4 * H1, E, c->W1x, c->ldE);
+    k_cast_rows(st, dt, p[0] + E, E + H1, 4 * H1, H1, c->W1h, c->ldH1);
+    k_cast_rows(st, dt, p[2], 2 * H2, 4 * H2, H2, c->W2x, c->ldH2);
+    k_cast_rows(st, dt, p[2] + H2, 2 * H2, 4 * H2, H2, c->W2h, c->ldH2);
+    k_cast_rows(st, dt, p[4], H1, h, H1, c->Wpd, c->ldH1);           // Wproj (H1 x h) memory [h][H1]
+    k_cast_rows(st, dt, p[5], LRCN_CNNOUT, h, LRCN_CNNOUT, c->Wcd, LRCN_CNNOUT);  // Wcnn memory [h][4096]
+    k_transpose(st, dt, 1, p[6], V, E, V, c->WeT, c->ldE, 0);        // Wembed (V x E) memory [E][V] -> [V][ldE]
+    k_cast_rows(st, dt, p[7], H2, V, H2, c->Wod, c->ldH2);           // Wout (H2 x V) memory [V][H2]
+    if (need_bwd) {
+        k_transpose(st, dt, 1, p[0], E + H1, 4 * H1, E, c->W1xT, c->ld4H1, 0);
+        k_transpose(st, dt, 1, p[0] + E, E + H1, 4 * H1, H1, c->W1hT, c->ld4H1, 0);
+        k_transpose(st, dt, 1, p[2], 2 * H2, 4 * H2, H2, c->W2xT, c->ld4H2, 0);
+        k_transpose(st, dt, 1, p[2] + H2, 2 * H2, 4 * H2, H2, c->W2hT, c->ld4H2, 0);
+        k_transpose(st, dt, 1, p[4], H1, h, H1, c->WpT, c->ldh, 0);   // -> [H1][ldh]
+        k_transpose(st, dt, 1, p[7], H2, V, H2, c->WoT, c->ldV, 0);   // -> [H2][ldV]
+    }
+    KCHK(c, "prepare_weights");
+    return LRCN_OK;
+}
+
+// One LSTM layer over all S steps.  Gx f32 [M][4H] holds the input-side pre-activations (+bias) on entry and the full
+// pre-activations on exit; acts/Call/Hall receive the per-step results.  (lrcn.jl:528-538, time-batched)
+int lstm_layer_fwd(lrcn_ctx *c, int S, int B, int H, int64_t ldH, int64_t ld4H, float *Gx, const void *Wh, void *acts,
+                   float *Call, void *Hall) {
+    const int dt = c->dt;
+    for (int s = 0; s < S; ++s) {
+        float *G = Gx + (int64_t)s * B * 4 * H;
+        if (s > 0)
+            GEMM(c, dt, boff(Hall, (int64_t)(s - 1) * B * ldH, c->esz), ldH, Wh, ldH, G, 4 * H, B, 4 * H, H, nullptr, true,
+                 true);
+        k_lstm_fwd(c->stream, dt, G, 4 * H, s ? Call + (int64_t)(s - 1) * B * H : nullptr, B, H,
+                   boff(acts, (int64_t)s * B * ld4H, c->esz), ld4H, Call + (int64_t)s * B * H,
+                   boff(Hall, (int64_t)s * B * ldH, c->esz), ldH, nullptr);
+    }
+    KCHK(c, "lstm_layer_fwd");
+    return LRCN_OK;
+}
+
+// Reverse recurrence of one layer: dHall f32 [M][H] (external dh per step) -> dZ (T) [M][ld4H].
+int lstm_layer_bwd(lrcn_ctx *c, int S, int B, int H, int64_t ld4H, const void *acts, const float *Call, const float *dHall,
+                   const void *WhT, void *dZ) {
+    const int dt = c->dt;
+    HIPCHK(c, hipMemsetAsync(c->dc, 0, sizeof(float) * (size_t)B * H, c->stream));
+    for (int s = S - 1; s >= 0; --s) {
+        k_lstm_bwd(c->stream, dt, boff(acts, (int64_t)s * B * ld4H, c->esz), ld4H, s ? Call + (int64_t)(s - 1) * B * H : nullptr,
+                   Call + (int64_t)s * B * H, dHall + (int64_t)s * B * H, H, (s < S - 1) ? c->dhrec : nullptr, c->dc, B, H,
+                   boff(dZ, (int64_t)s * B * ld4H, c->esz), ld4H);
+        if (s > 0)  // dh_prev = dZ[s] * Wh'   (Wh' K-contiguous = WhT [H][ld4H])
+            GEMM(c, dt, boff(dZ, (int64_t)s * B * ld4H, c->esz), ld4H, WhT, ld4H, c->dhrec, H, B, H, 4 * H, nullptr, true);
+    }
+    KCHK(c, "lstm_layer_bwd");
+    return LRCN_OK;
+}
+
+int check_shapes(lrcn_ctx *c, int T, int B, int norm_B) {
+    if (T < 0 || T + 1 > c->maxS) FAIL(c, LRCN_EINVAL, "T=%d outside [0,%d]", T, c->maxS - 1);
+    if (B < 1 || B > c->maxB) FAIL(c, LRCN_EINVAL, "B=%d outside [1,%d]", B, c->maxB);
+    if (norm_B < 1) FAIL(c, LRCN_EINVAL, "norm_B=%d must be >= 1", norm_B);
+    return LRCN_OK;
+}
+
+// loss / lossgradient on internal buffers. feats: B x 4096 column-major f32 (device).
+int loss_impl(lrcn_ctx *c, const float *const p[9], const float *feats, const int32_t *tokens, int T, int B, int norm_B,
+              const lrcn_dropout *drop, float *const grads[9], float *logits_out) {
+    int r = check_shapes(c, T, B, norm_B);
+    if (r) return r;
+    if (drop && (drop->pdrop < 0.0f || drop->pdrop >= 1.0f)) FAIL(c, LRCN_EINVAL, "pdrop=%g outside [0,1)", drop->pdrop);
+    if (drop && ((drop->mask1 == nullptr) != (drop->mask2 == nullptr))) FAIL(c, LRCN_EINVAL, "mask1/mask2 must both be set");
+    const int dt = c->dt, E = c->E, H1 = c->H1, H2 = c->H2, h = c->h, V = c->V;
+    const int S = T + 1, M = S * B;
+    const size_t es = c->esz;
+    hipStream_t st = c->stream;
+    const bool bwd = grads != nullptr;
+    const DropSpec d1 = make_drop(drop, 1), d2 = make_drop(drop, 2);
+
+    r = prepare_weights(c, p, bwd);
+    if (r) return r;
+    if (T > 0) HIPCHK(c, hipMemcpyAsync(c->tok, tokens, sizeof(int32_t) * (size_t)T * B, hipMemcpyDeviceToDevice, st));
+    k_build_tokens(st, c->tok, T, B, V, c->tok_in, c->tok_tgt);
+    // feats (B x 4096 column-major = memory [4096][B]) -> F [B][4096] (T)
+    k_transpose(st, dt, 1, feats, B, LRCN_CNNOUT, B, c->F, LRCN_CNNOUT, 0);
+    // input = input * param[end-3]   lrcn.jl:558
+    GEMM(c, dt, c->F, LRCN_CNNOUT, c->Wcd, LRCN_CNNOUT, c->xcnn, c->ldh, B, h, LRCN_CNNOUT, nullptr, true);
+    // embeddings of [bos, tokens...] with the :542 dropout
+    k_embed_gather(st, dt, c->WeT, c->ldE, c->tok_in, S, B, E, d1, c->Xemb, c->ldE);
+    // LSTM 1
+    GEMM(c, dt, c->Xemb, c->ldE, c->W1x, c->ldE, c->G1, 4 * H1, M, 4 * H1, E, p[1], true);
+    r = lstm_layer_fwd(c, S, B, H1, c->ldH1, c->ld4H1, c->G1, c->W1h, c->A1, c->C1, c->H1all);
+    if (r) return r;
+    // x = s[1]*w[end-4]; x = hcat(x, x_cnn); x = dropout(x)    lrcn.jl:544-547
+    GEMM(c, dt, c->H1all, c->ldH1, c->Wpd, c->ldH1, c->X2, c->ldH2, M, h, H1, nullptr, false);
+    k_concat_x2(st, dt, c->X2, c->ldH2, c->xcnn, c->ldh, S, B, h, d2);
+    // LSTM 2
+    GEMM(c, dt, c->X2, c->ldH2, c->W2x, c->ldH2, c->G2, 4 * H2, M, 4 * H2, H2, p[3], true);
+    r = lstm_layer_fwd(c, S, B, H2, c->ldH2, c->ld4H2, c->G2, c->W2h, c->A2, c->C2, c->H2all);
+    if (r) return r;
+    // logits for all steps: x * w[end-1] .+ w[end]   lrcn.jl:550
+    GEMM(c, dt, c->H2all, c->ldH2, c->Wod, c->ldH2, c->Logits, c->ldV, M, V, H2, p[8], true);
+    if (logits_out) {  // (T+1) blocks of B x V column-major: block s memory [V][B]
+        for (int s = 0; s < S; ++s)
+            k_transpose_f32(st, c->Logits + (int64_t)s * B * c->ldV, c->ldV, B, V, logits_out + (int64_t)s * B * V, B);
+    }
+    HIPCHK(c, hipMemsetAsync(c->logp, 0, sizeof(double), st));
+    const float scale = (float)(1.0 / ((double)norm_B * (double)S));
+    k_softmax_xent(st, dt, c->Logits, c->ldV, c->tok_tgt, M, V, scale, c->logp, bwd ? c->dLog : nullptr, c->ldV);
+    c->last_norm = norm_B;
+    c->last_S = S;
+    KCHK(c, "forward");
+    if (!bwd) return LRCN_OK;
+
+    const int64_t ldM = ld8(M), ldB = ld8(B);
+    // ---- logits layer: dWout, dbout, dH2 ----
+    k_transpose(st, dt, 0, c->dLog, c->ldV, M, V, c->TA, ldM, 0);        // dLog^T [V][ldM]
+    k_transpose(st, dt, 0, c->H2all, c->ldH2, M, H2, c->TB, ldM, 0);     // H2all^T [H2][ldM]
+    GEMM(c, dt, c->TA, ldM, c->TB, ldM, grads[7], H2, V, H2, M, nullptr, true);
+    k_colsum(st, dt, c->dLog, c->ldV, M, V, grads[8]);
+    GEMM(c, dt, c->dLog, c->ldV, c->WoT, c->ldV, c->dH2all, H2, M, H2, V, nullptr, true);
+    // ---- LSTM 2 ----
+    r = lstm_layer_bwd(c, S, B, H2, c->ld4H2, c->A2, c->C2, c->dH2all, c->W2hT, c->dZ2);
+    if (r) return r;
+    k_transpose(st, dt, 0, c->dZ2, c->ld4H2, M, 4 * H2, c->TA, ldM, 0);  // dZ2^T [4H2][ldM]
+    k_transpose(st, dt, 0, c->X2, c->ldH2, M, H2, c->TB, ldM, 0);        // X2^T [2h][ldM]
+    GEMM(c, dt, c->TA, ldM, c->TB, ldM, grads[2], 2 * H2, 4 * H2, H2, M, nullptr, true);
+    if (M > B)
+        k_transpose(st, dt, 0, c->H2all, c->ldH2, M - B, H2, c->TB, ldM, B);  // h2_prev^T (shifted one step)
+    else
+        HIPCHK(c, hipMemsetAsync(c->TB, 0, es * (size_t)H2 * ldM, st));
+    GEMM(c, dt, c->TA, ldM, c->TB, ldM, grads[2] + H2, 2 * H2, 4 * H2, H2, M, nullptr, true);
+    k_colsum(st, dt, c->dZ2, c->ld4H2, M, 4 * H2, grads[3]);
+    GEMM(c, dt, c->dZ2, c->ld4H2, c->W2xT, c->ld4H2, c->dX2, c->ldH2, M, H2, 4 * H2, nullptr, false);
+    k_dx2_mask_reduce(st, dt, c->dX2, c->ldH2, S, B, h, d2, c->dxcnn, c->ldh);
+    // ---- projection and image embedding ----
+    k_transpose(st, dt, 0, c->dX2, c->ldH2, M, h, c->TA, ldM, 0);        // dP^T [h][ldM]
+    k_transpose(st, dt, 0, c->H1all, c->ldH1, M, H1, c->TB, ldM, 0);     // H1all^T [H1][ldM]
+    GEMM(c, dt, c->TA, ldM, c->TB, ldM, grads[4], H1, h, H1, M, nullptr, true);
+    GEMM(c, dt, c->dX2, c->ldH2, c->WpT, c->ldh, c->dH1all, H1, M, H1, h, nullptr, true);
+    k_transpose(st, dt, 1, c->dxcnn, c->ldh, B, h, c->dxcT, ldB, 0);     // dxcnn^T [h][ldB]
+    k_cast_rows(st, dt, feats, B, LRCN_CNNOUT, B, c->FT, ldB);           // feats^T [4096][ldB] (it already is, in memory)
+    GEMM(c, dt, c->dxcT, ldB, c->FT, ldB, grads[5], LRCN_CNNOUT, h, LRCN_CNNOUT, B, nullptr, true);
+    // ---- LSTM 1 ----
+    r = lstm_layer_bwd(c, S, B, H1, c->ld4H1, c->A1, c->C1, c->dH1all, c->W1hT, c->dZ1);
+    if (r) return r;
+    k_transpose(st, dt, 0, c->dZ1, c->ld4H1, M, 4 * H1, c->TA, ldM, 0);
+    k_transpose(st, dt, 0, c->Xemb, c->ldE, M, E, c->TB, ldM, 0);
+    GEMM(c, dt, c->TA, ldM, c->TB, ldM, grads[0], E + H1, 4 * H1, E, M, nullptr, true);
+    if (M > B)
+        k_transpose(st, dt, 0, c->H1all, c->ldH1, M - B, H1, c->TB, ldM, B);
+    else
+        HIPCHK(c, hipMemsetAsync(c->TB, 0, es * (size_t)H1 * ldM, st));
+    GEMM(c, dt, c->TA, ldM, c->TB, ldM, grads[0] + E, E + H1, 4 * H1, H1, M, nullptr, true);
+    k_colsum(st, dt, c->dZ1, c->ld4H1, M, 4 * H1, grads[1]);
+    GEMM(c, dt, c->dZ1, c->ld4H1, c->W1xT, c->ld4H1, c->dXemb, c->ldE, M, E, 4 * H1, nullptr, true);
+    HIPCHK(c, hipMemsetAsync(grads[6], 0, sizeof(float) * (size_t)V * E, st));
+    k_embed_scatter(st, c->dXemb, c->ldE, c->tok_in, S, B, E, V, d1, grads[6]);
+    KCHK(c, "backward");
+    return LRCN_OK;
+}
+
+int fetch_loss(lrcn_ctx *c, double *out) {
+    double s = 0.0;
+    HIPCHK(c, hipMemcpyAsync(&s, c->logp, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *out = -s / ((double)c->last_norm * (double)c->last_S);
+    return LRCN_OK;
+}
+
+// lrcn() on internal single-step buffers: state st_f32 (f32 row-major), inputs st_x (T [B][ldE]) and xcnn (f32 [B][ldh]).
+// m2: dropout for the concatenated LSTM-2 input. Leaves logits in st_logits [B][ldV].
+int step_internal(lrcn_ctx *c, const float *const p[9], int B, const DropSpec &d2) {
+    const int dt = c->dt, E = c->E, H1 = c->H1, H2 = c->H2, h = c->h, V = c->V;
+    hipStream_t st = c->stream;
+    // LSTM 1: gates = x*W1x' + h1*W1h' + b1
+    k_cast_rows(st, dt, c->st_f32[0], H1, B, H1, c->st_h1, c->ldH1);
+    GEMM(c, dt, c->st_x, c->ldE, c->W1x, c->ldE, c->st_g, 4 * H1, B, 4 * H1, E, p[1], true);
+    GEMM(c, dt, c->st_h1, c->ldH1, c->W1h, c->ldH1, c->st_g, 4 * H1, B, 4 * H1, H1, nullptr, true, true);
+    k_lstm_fwd(st, dt, c->st_g, 4 * H1, c->st_f32[1], B, H1, c->st_a, c->ld4H1, c->st_f32[1], c->st_h1, c->ldH1, c->st_f32[0]);
+    // projection + concat + dropout
+    GEMM(c, dt, c->st_h1, c->ldH1, c->Wpd, c->ldH1, c->st_x2, c->ldH2, B, h, H1, nullptr, false);
+    k_concat_x2(st, dt, c->st_x2, c->ldH2, c->xcnn, c->ldh, 1, B, h, d2);
+    // LSTM 2
+    k_cast_rows(st, dt, c->st_f32[2], H2, B, H2, c->st_h2, c->ldH2);
+    GEMM(c, dt, c->st_x2, c->ldH2, c->W2x, c->ldH2, c->st_g, 4 * H2, B, 4 * H2, H2, p[3], true);
+    GEMM(c, dt, c->st_h2, c->ldH2, c->W2h, c->ldH2, c->st_g, 4 * H2, B, 4 * H2, H2, nullptr, true, true);
+    k_lstm_fwd(st, dt, c->st_g, 4 * H2, c->st_f32[3], B, H2, c->st_a, c->ld4H2, c->st_f32[3], c->st_h2, c->ldH2, c->st_f32[2]);
+    GEMM(c, dt, c->st_h2, c->ldH2, c->Wod, c->ldH2, c->st_logits, c->ldV, B, V, H2, p[8], true);
+    KCHK(c, "step");
+    return LRCN_OK;
+}
+
+}  // namespace
+
+// =====================================================================================================
+extern "C" {
+
+const char *lrcn_version(void) { return "lrcn-hip 0.1 (gfx950)"; }
+
+const char *lrcn_last_error(const lrcn_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int lrcn_param_sizes(int E, int H1, int H2, int V, int64_t s[9]) {
+    if (E < 1 || H1 < 1 || H2 < 2 || (H2 & 1) || V < 3 || !s) return LRCN_EINVAL;
+    const int h = H2 / 2;
+    s[0] = (int64_t)(E + H1) * 4 * H1;
+    s[1] = 4 * H1;
+    s[2] = (int64_t)(2 * H2) * 4 * H2;
+    s[3] = 4 * H2;
+    s[4] = (int64_t)H1 * h;
+    s[5] = (int64_t)LRCN_CNNOUT * h;
+    s[6] = (int64_t)V * E;
+    s[7] = (int64_t)H2 * V;
+    s[8] = V;
+    return LRCN_OK;
+}
+
+int lrcn_malloc(void **p, size_t bytes) { return hipMalloc(p, bytes ? bytes : 16) == hipSuccess ? LRCN_OK : LRCN_ENOMEM; }
+int lrcn_free(void *p) { return hipFree(p) == hipSuccess ? LRCN_OK : LRCN_EHIP; }
+int lrcn_memcpy_h2d(void *d, const void *s, size_t n) { return hipMemcpy(d, s, n, hipMemcpyHostToDevice) == hipSuccess ? LRCN_OK : LRCN_EHIP; }
+int lrcn_memcpy_d2h(void *d, const void *s, size_t n) { return hipMemcpy(d, s, n, hipMemcpyDeviceToHost) == hipSuccess ? LRCN_OK : LRCN_EHIP; }
+
+void lrcn_destroy(lrcn_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device);
+    (void)hipDeviceSynchronize();
+    for (void *p : c->allocs) (void)hipFree(p);
+    delete c;
+}
+
+int lrcn_create(const lrcn_config *cfg, lrcn_ctx **out) {
+    if (!cfg || !out) {
+        g_create_err = "null argument";
+        return LRCN_EINVAL;
+    }
+    *out = nullptr;
+    int64_t sz[9];
+    if (lrcn_param_sizes(cfg->E, cfg->H1, cfg->H2, cfg->V, sz) != LRCN_OK || cfg->max_B < 1 || cfg->max_T < 0 ||
+        cfg->max_T > LRCN_MAX_T || (cfg->lstm_dtype != LRCN_F32 && cfg->lstm_dtype != LRCN_BF16) ||
+        (cfg->vgg_dtype != LRCN_F32 && cfg->vgg_dtype != LRCN_BF16) || cfg->max_images < 0) {
+        g_create_err = "invalid lrcn_config (need E,H1>=1, even H2>=2, V>=3, max_B>=1, 0<=max_T<=28, dtype in {F32,BF16})";
+        return LRCN_EINVAL;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || cfg->device < 0 || cfg->device >= ndev) {
+        g_create_err = "no such HIP device (is a GPU visible?)";
+        return LRCN_EHIP;
+    }
+    if (hipSetDevice(cfg->device) != hipSuccess) {
+        g_create_err = "hipSetDevice failed";
+        return LRCN_EHIP;
+    }
+    lrcn_ctx *c = new lrcn_ctx();
+    c->cfg = *cfg;
+    c->dt = cfg->lstm_dtype == LRCN_BF16 ? GEMM_T_BF16 : GEMM_T_F32;
+    c->vdt = cfg->vgg_dtype == LRCN_BF16 ? GEMM_T_BF16 : GEMM_T_F32;
+    c->esz = c->dt == GEMM_T_BF16 ? 2 : 4;
+    c->vesz = c->vdt == GEMM_T_BF16 ? 2 : 4;
+    c->E = cfg->E; c->H1 = cfg->H1; c->H2 = cfg->H2; c->h = cfg->H2 / 2; c->V = cfg->V;
+    c->maxB = cfg->max_B; c->maxS = cfg->max_T + 1;
+    const int E = c->E, H1 = c->H1, H2 = c->H2, h = c->h, V = c->V, B = c->maxB, S = c->maxS;
+    const int64_t M = (int64_t)S * B;
+    c->ldE = ld8(E); c->ldH1 = ld8(H1); c->ldH2 = ld8(H2); c->ldh = ld8(h); c->ld4H1 = ld8(4 * H1); c->ld4H2 = ld8(4 * H2);
+    c->ldV = ld8(V); c->ldM = ld8(M); c->ldB = ld8(B);
+    const size_t es = c->esz;
+    int rc = [&]() -> int {
+        DALLOC(c, c->W1x, es * 4 * H1 * c->ldE);   DALLOC(c, c->W1h, es * 4 * H1 * c->ldH1);
+        DALLOC(c, c->W1xT, es * E * c->ld4H1);     DALLOC(c, c->W1hT, es * H1 * c->ld4H1);
+        DALLOC(c, c->W2x, es * 4 * H2 * c->ldH2);  DALLOC(c, c->W2h, es * 4 * H2 * c->ldH2);
+        DALLOC(c, c->W2xT, es * H2 * c->ld4H2);    DALLOC(c, c->W2hT, es * H2 * c->ld4H2);
+        DALLOC(c, c->Wpd, es * h * c->ldH1);       DALLOC(c, c->WpT, es * H1 * c->ldh);
+        DALLOC(c, c->Wcd, es * h * LRCN_CNNOUT);   DALLOC(c, c->WeT, es * V * c->ldE);
+        DALLOC(c, c->Wod, es * V * c->ldH2);       DALLOC(c, c->WoT, es * H2 * c->ldV);
+        DALLOC(c, c->tok, sizeof(int32_t) * M);    DALLOC(c, c->tok_in, sizeof(int32_t) * M);
+        DALLOC(c, c->tok_tgt, sizeof(int32_t) * M);
+        DALLOC(c, c->F, es * B * LRCN_CNNOUT);     DALLOC(c, c->FT, es * LRCN_CNNOUT * c->ldB);
+        DALLOC(c, c->xcnn, sizeof(float) * B * c->ldh);
+        DALLOC(c, c->Xemb, es * M * c->ldE);
+        DALLOC(c, c->G1, sizeof(float) * M * 4 * H1); DALLOC(c, c->A1, es * M * c->ld4H1);
+        DALLOC(c, c->C1, sizeof(float) * M * H1);     DALLOC(c, c->H1all, es * M * c->ldH1);
+        DALLOC(c, c->X2, es * M * c->ldH2);
+        DALLOC(c, c->G2, sizeof(float) * M * 4 * H2); DALLOC(c, c->A2, es * M * c->ld4H2);
+        DALLOC(c, c->C2, sizeof(float) * M * H2);     DALLOC(c, c->H2all, es * M * c->ldH2);
+        DALLOC(c, c->Logits, sizeof(float) * M * c->ldV);
+        DALLOC(c, c->dLog, es * M * c->ldV);
+        DALLOC(c, c->dZ1, es * M * c->ld4H1);      DALLOC(c, c->dZ2, es * M * c->ld4H2);
+        DALLOC(c, c->dX2, es * M * c->ldH2);
+        DALLOC(c, c->dH1all, sizeof(float) * M * H1); DALLOC(c, c->dH2all, sizeof(float) * M * H2);
+        DALLOC(c, c->dXemb, sizeof(float) * M * c->ldE);
+        const int Hm = H1 > H2 ? H1 : H2;
+        DALLOC(c, c->dhrec, sizeof(float) * B * Hm); DALLOC(c, c->dc, sizeof(float) * B * Hm);
+        DALLOC(c, c->dxcnn, sizeof(float) * B * c->ldh); DALLOC(c, c->dxcT, es * h * c->ldB);
+        int64_t ra = 4 * Hm; if (V > ra) ra = V;
+        int64_t rb = Hm; if (E > rb) rb = E;
+        DALLOC(c, c->TA, es * ra * c->ldM);        DALLOC(c, c->TB, es * rb * c->ldM);
+        DALLOC(c, c->logp, sizeof(double) * 2);
+        for (int i = 0; i < 4; ++i) {
+            DALLOC(c, c->st_f32[i], sizeof(float) * B * Hm);
+            DALLOC(c, c->st2_f32[i], sizeof(float) * B * Hm);
+        }
+        DALLOC(c, c->st_h1, es * B * c->ldH1);     DALLOC(c, c->st_h2, es * B * c->ldH2);
+        DALLOC(c, c->st_x, es * B * c->ldE);       DALLOC(c, c->st_x2, es * B * c->ldH2);
+        DALLOC(c, c->st_a, es * B * (c->ld4H1 > c->ld4H2 ? c->ld4H1 : c->ld4H2));
+        DALLOC(c, c->st_g, sizeof(float) * B * 4 * Hm);
+        DALLOC(c, c->st_logits, sizeof(float) * B * c->ldV); DALLOC(c, c->st_prob, sizeof(float) * B * c->ldV);
+        int64_t io = (int64_t)B * (V > 4 * Hm ? V : 4 * Hm); if (io < (int64_t)B * (E + Hm)) io = (int64_t)B * (E + Hm);
+        DALLOC(c, c->st_io, sizeof(float) * io);
+        DALLOC(c, c->st_topi, sizeof(int32_t) * B * 32); DALLOC(c, c->st_topv, sizeof(float) * B * 32);
+        DALLOC(c, c->st_parent, sizeof(int32_t) * B);
+        if (cfg->max_images > 0) {
+            const int64_t N = cfg->max_images;
+            const size_t ve = c->vesz;
+            DALLOC(c, c->im2col, ve * N * 224 * 224 * 32);
+            DALLOC(c, c->actA, ve * N * 224 * 224 * 64);
+            DALLOC(c, c->actB, ve * N * 112 * 112 * 128);  // largest tensor ever written to the second buffer (pool1 out = N*112*112*64; conv2_1 out = N*112*112*128)
+            DALLOC(c, c->f6, ve * N * 4096);
+            DALLOC(c, c->featsRM, sizeof(float) * N * 4096);
+        }
+        return LRCN_OK;
+    }();
+    if (rc) {
+        g_create_err = c->err;
+        lrcn_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return LRCN_OK;
+}
+
+int lrcn_set_stream(lrcn_ctx *c, void *s) {
+    if (!c) return LRCN_EINVAL;
+    c->stream = reinterpret_cast<hipStream_t>(s);
+    return LRCN_OK;
+}
+int lrcn_sync(lrcn_ctx *c) {
+    if (!c) return LRCN_EINVAL;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return LRCN_OK;
+}
+
+int lrcn_init_weights(lrcn_ctx *c, float *const p[9], uint64_t seed) {
+    if (!c || !p) return LRCN_EINVAL;
+    int64_t sz[9];
+    lrcn_param_sizes(c->E, c->H1, c->H2, c->V, sz);
+    const int E = c->E, H1 = c->H1, H2 = c->H2, h = c->h, V = c->V;
+    const int rows[9] = {E + H1, 1, 2 * H2, 1, H1, LRCN_CNNOUT, V, H2, 1};
+    const int cols[9] = {4 * H1, 4 * H1, 4 * H2, 4 * H2, h, h, E, V, V};
+    for (int k = 0; k < 9; ++k) {
+        if (k == 1 || k == 3 || k == 8) {
+            k_fill(c->stream, p[k], sz[k], 0.0f);
+            if (k != 8) k_fill(c->stream, p[k], k == 1 ? H1 : H2, 1.0f);  // forget-gate bias = 1 (lrcn.jl:501)
+        } else {
+            k_init_uniform(c->stream, p[k], sz[k], (float)std::sqrt(2.0 / ((double)rows[k] + (double)cols[k])), seed, k);
+        }
+    }
+    KCHK(c, "init_weights");
+    return LRCN_OK;
+}
+
+int lrcn_loss(lrcn_ctx *c, const float *const p[9], const float *feats, const int32_t *tokens, int T, int B, int norm_B,
+              const lrcn_dropout *drop, double *loss_host) {
+    if (!c || !p || !feats || (!tokens && T > 0)) return LRCN_EINVAL;
+    int r = loss_impl(c, p, feats, tokens, T, B, norm_B, drop, nullptr, nullptr);
+    if (r) return r;
+    return loss_host ? fetch_loss(c, loss_host) : LRCN_OK;
+}
+
+int lrcn_loss_grad(lrcn_ctx *c, const float *const p[9], const float *feats, const int32_t *tokens, int T, int B, int norm_B,
+                   const lrcn_dropout *drop, float *const grads[9], double *loss_host) {
+    if (!c || !p || !feats || (!tokens && T > 0) || !grads) return LRCN_EINVAL;
+    int r = loss_impl(c, p, feats, tokens, T, B, norm_B, drop, grads, nullptr);
+    if (r) return r;
+    return loss_host ? fetch_loss(c, loss_host) : LRCN_OK;
+}
+
+int lrcn_last_loss(lrcn_ctx *c, double *loss_host) {
+    if (!c || !loss_host) return LRCN_EINVAL;
+    return fetch_loss(c, loss_host);
+}
+
+int lrcn_forward_logits(lrcn_ctx *c, const float *const p[9], const float *feats, const int32_t *tokens, int T, int B,
+                        float *logits_out) {
+    if (!c || !p || !feats || (!tokens && T > 0) || !logits_out) return LRCN_EINVAL;
+    return loss_impl(c, p, feats, tokens, T, B, B, nullptr, nullptr, logits_out);
+}
+
+int lrcn_adam_update(lrcn_ctx *c, float *const p[9], const float *const g[9], float *const m[9], float *const v[9], int step,
+                     float lr, float b1, float b2, float eps) {
+    if (!c || !p || !g || !m || !v || step < 1) return LRCN_EINVAL;
+    AdamTensors t;
+    int64_t sz[9];
+    lrcn_param_sizes(c->E, c->H1, c->H2, c->V, sz);
+    for (int k = 0; k < 9; ++k) {
+        t.w[k] = p[k];
+        t.g[k] = g[k];
+        t.m[k] = m[k];
+        t.v[k] = v[k];
+        t.n[k] = sz[k];
+    }
+    k_adam(c->stream, t, step, lr, b1, b2, eps);
+    KCHK(c, "adam");
+    return LRCN_OK;
+}
+
+int lrcn_train_step(lrcn_ctx *c, float *const p[9], float *const g[9], float *const m[9], float *const v[9], const float *feats,
+                    const int32_t *tokens, int T, int B, int norm_B, const lrcn_dropout *drop, int step, float lr, float b1,
+                    float b2, float eps, double *loss_host) {
+    if (!c || !p || !g || !m || !v) return LRCN_EINVAL;
+    int r = lrcn_loss_grad(c, p, feats, tokens, T, B, norm_B, drop, g, nullptr);
+    if (r) return r;
+    r = lrcn_adam_update(c, p, g, m, v, step, lr, b1, b2, eps);
+    if (r) return r;
+    return loss_host ? fetch_loss(c, loss_host) : LRCN_OK;
+}
+
+int lrcn_lstm(lrcn_ctx *c, const float *W, const float *b, int X, int H, int B, const float *x, const float *h, const float *cc,
+              float *h_out, float *c_out) {
+    if (!c || !W || !b || !x || !h || !cc || !h_out || !c_out) return LRCN_EINVAL;
+    void *Wx, *Wh, *xb, *hb;
+    if (X == c->E && H == c->H1) {
+        Wx = c->W1x; Wh = c->W1h; xb = c->st_x; hb = c->st_h1;
+    } else if (X == c->H2 && H == c->H2) {
+        Wx = c->W2x; Wh = c->W2h; xb = c->st_x2; hb = c->st_h2;
+    } else {
+        FAIL(c, LRCN_EINVAL, "lrcn_lstm: (X=%d,H=%d) must be the context's (E,H1)=(%d,%d) or (H2,H2)=(%d,%d)", X, H, c->E, c->H1,
+             c->H2, c->H2);
+    }
+    if (B < 1 || B > c->maxB) FAIL(c, LRCN_EINVAL, "B=%d outside [1,%d]", B, c->maxB);
+    const int dt = c->dt;
+    hipStream_t st = c->stream;
+    const int64_t ldX = ld8(X), ldH = ld8(H);
+    // shadows of this W: memory [4H][X+H]
+    k_cast_rows(st, dt, W, X + H, 4 * H, X, Wx, ldX);
+    k_cast_rows(st, dt, W + X, X + H, 4 * H, H, Wh, ldH);
+    // x (B x X column-major = memory [X][B]) -> [B][ldX] T ; h likewise ; c -> f32 row-major
+    k_transpose(st, dt, 1, x, B, X, B, xb, ldX, 0);
+    k_transpose(st, dt, 1, h, B, H, B, hb, ldH, 0);
+    k_transpose_f32(st, cc, B, H, B, c->st_f32[1], H);
+    GEMM(c, dt, xb, ldX, Wx, ldX, c->st_g, 4 * H, B, 4 * H, X, b, true);
+    GEMM(c, dt, hb, ldH, Wh, ldH, c->st_g, 4 * H, B, 4 * H, H, nullptr, true, true);
+    k_lstm_fwd(st, dt, c->st_g, 4 * H, c->st_f32[1], B, H, c->st_a, ld8(4 * H), c->st_f32[1], hb, ldH, c->st_f32[0]);
+    k_transpose_f32(st, c->st_f32[0], H, B, H, h_out, B);
+    k_transpose_f32(st, c->st_f32[1], H, B, H, c_out, B);
+    KCHK(c, "lrcn_lstm");
+    return LRCN_OK;
+}
+
+int lrcn_step(lrcn_ctx *c, const float *const p[9], float *const state[4], int B, const float *x_cnn, const float *x_lstm,
+              const float *mask1, const float *mask2, float *logits) {
+    if (!c || !p || !state || !x_cnn || !x_lstm || !logits) return LRCN_EINVAL;
+    if (B < 1 || B > c->maxB) FAIL(c, LRCN_EINVAL, "B=%d outside [1,%d]", B, c->maxB);
+    const int dt = c->dt, E = c->E, H1 = c->H1, H2 = c->H2, h = c->h, V = c->V;
+    hipStream_t st = c->stream;
+    int r = prepare_weights(c, p, false);
+    if (r) return r;
+    const int Hs[4] = {H1, H1, H2, H2};
+    for (int i = 0; i < 4; ++i) k_transpose_f32(st, state[i], B, Hs[i], B, c->st_f32[i], Hs[i]);
+    k_transpose_f32(st, x_cnn, B, h, B, c->xcnn, c->ldh);
+    // x = dropout(x_lstm)  (lrcn.jl:542): both arrays are B x E column-major, multiply first, then lay out [B][ldE] (T)
+    DropSpec d2{};
+    d2.which = 2;
+    d2.mask = mask2;
+    const float *xsrc = x_lstm;
+    if (mask1) {
+        k_mul_f32(st, x_lstm, mask1, (int64_t)B * E, c->st_io);
+        xsrc = c->st_io;
+    }
+    k_transpose(st, dt, 1, xsrc, B, E, B, c->st_x, c->ldE, 0);
+    r = step_internal(c, p, B, d2);
+    if (r) return r;
+    for (int i = 0; i < 4; ++i) k_transpose_f32(st, c->st_f32[i], Hs[i], B, Hs[i], state[i], B);
+    k_transpose_f32(st, c->st_logits, c->ldV, B, V, logits, B);
+    KCHK(c, "lrcn_step");
+    return LRCN_OK;
+}
+
+int lrcn_beam_search(lrcn_ctx *c, const float *const p[9], const float *feat, int K, int nword, int32_t *out_tokens, int *out_len,
+                     float *out_prob) {
+    if (!c || !p || !feat || !out_tokens || !out_len) return LRCN_EINVAL;
+    if (K < 1 || K > 32 || K > c->maxB) FAIL(c, LRCN_EINVAL, "beam width K=%d must be in [1, min(32, max_B=%d)]", K, c->maxB);
+    if (nword < 1 || nword > 256) FAIL(c, LRCN_EINVAL, "nword=%d outside [1,256]", nword);
+    const int dt = c->dt, E = c->E, H1 = c->H1, H2 = c->H2, h = c->h, V = c->V;
+    hipStream_t st = c->stream;
+    int r = prepare_weights(c, p, false);
+    if (r) return r;
+    // input = input * param[end-3]  (lrcn.jl:611), replicated to K rows
+    k_cast_rows(st, dt, feat, LRCN_CNNOUT, 1, LRCN_CNNOUT, c->F, LRCN_CNNOUT);
+    for (int i = 1; i < K; ++i)
+        HIPCHK(c, hipMemcpyAsync(boff(c->F, (int64_t)i * LRCN_CNNOUT, c->esz), c->F, c->esz * LRCN_CNNOUT, hipMemcpyDeviceToDevice, st));
+    GEMM(c, dt, c->F, LRCN_CNNOUT, c->Wcd, LRCN_CNNOUT, c->xcnn, c->ldh, K, h, LRCN_CNNOUT, nullptr, true);
+    const int Hs[4] = {H1, H1, H2, H2};
+    for (int i = 0; i < 4; ++i) HIPCHK(c, hipMemsetAsync(c->st_f32[i], 0, sizeof(float) * (size_t)K * Hs[i], st));
+    struct Hyp {
+        std::vector<int32_t> seq;
+        float p;
+    };
+    std::vector<Hyp> x(K);
+    for (auto &hy : x) {
+        hy.seq = {LRCN_BOS};
+        hy.p = 1.0f;
+    }
+    std::vector<int32_t> last(K), topi((size_t)K * K), parent(K);
+    std::vector<float> topv((size_t)K * K);
+    DropSpec none{};
+    for (int current = 1;; ++current) {
+        for (int i = 0; i < K; ++i) last[i] = x[i].seq.back();
+        HIPCHK(c, hipMemcpyAsync(c->st_parent, last.data(), sizeof(int32_t) * K, hipMemcpyHostToDevice, st));
+        k_embed_gather(st, dt, c->WeT, c->ldE, c->st_parent, 1, K, E, none, c->st_x, c->ldE);  // lrcn.jl:650
+        r = step_internal(c, p, K, none);                                                    // lrcn.jl:651 (K hypotheses batched)
+        if (r) return r;
+        k_softmax_rows(st, c->st_logits, c->ldV, K, V, c->st_prob, c->ldV);                   // :652
+        k_topk_rows(st, c->st_prob, c->ldV, K, V, K, c->st_topi, c->st_topv);                 // :655-656 on device
+        HIPCHK(c, hipMemcpyAsync(topi.data(), c->st_topi, sizeof(int32_t) * K * K, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipMemcpyAsync(topv.data(), c->st_topv, sizeof(float) * K * K, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        // candidates (lrcn.jl:657-664): step 1 expands hypothesis 1 only
+        const int nexp = current == 1 ? 1 : K;
+        std::vector<Hyp> cand;
+        std::vector<int> cparent;
+        for (int i = 0; i < nexp; ++i)
+            for (int j = 0; j < K; ++j) {
+                Hyp hy;
+                hy.seq = x[i].seq;
+                hy.seq.push_back(topi[(size_t)i * K + j]);
+                hy.p = topv[(size_t)i * K + j] * x[i].p;
+                cand.push_back(std::move(hy));
+                cparent.push_back(i);
+            }
+        // stable descending sort by probability (lrcn.jl:667)
+        std::vector<int> order(cand.size());
+        for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cand[a].p > cand[b].p; });
+        std::vector<Hyp> xs(K);
+        for (int i = 0; i < K; ++i) xs[i] = cand[order[i]];
+        const bool done = xs[0].seq.back() == LRCN_EOS || current > nword;  // :670
+        if (done) {
+            x.swap(xs);
+            break;
+        }
+        for (int i = 0; i < K; ++i) parent[i] = cparent[order[i]];  // :673-676
+        HIPCHK(c, hipMemcpyAsync(c->st_parent, parent.data(), sizeof(int32_t) * K, hipMemcpyHostToDevice, st));
+        for (int i = 0; i < 4; ++i) {
+            k_gather_rows_f32(st, c->st_f32[i], Hs[i], c->st_parent, K, Hs[i], c->st2_f32[i]);
+            std::swap(c->st_f32[i], c->st2_f32[i]);
+        }
+        HIPCHK(c, hipStreamSynchronize(st));  // parent/last host vectors are reused next iteration
+        x.swap(xs);
+    }
+    const int n = (int)x[0].seq.size();
+    memcpy(out_tokens, x[0].seq.data(), sizeof(int32_t) * n);
+    *out_len = n;
+    if (out_prob) *out_prob = x[0].p;
+    return LRCN_OK;
+}
+
+// ------------------------------------------------------------------------------------------- VGG
+static const int kVggCout[13] = {64, 64, 128, 128, 256, 256, 256, 512, 512, 512, 512, 512, 512};
+static const int kVggPool[13] = {0, 1, 0, 1, 0, 0, 1, 0, 0, 1, 0, 0, 1};
+
+int lrcn_vgg_load(lrcn_ctx *c, const float *const cw[13], const float *const cb[13], const float *fc6_w, const float *fc6_b,
+                  const float *fc7_w, const float *fc7_b) {
+    if (!c || !cw || !cb || !fc6_w || !fc6_b || !fc7_w || !fc7_b) return LRCN_EINVAL;
+    if (c->cfg.max_images < 1) FAIL(c, LRCN_ESTATE, "context was created with max_images = 0");
+    if (c->vgg_loaded) FAIL(c, LRCN_ESTATE, "VGG weights already loaded");
+    const int vdt = c->vdt;
+    const size_t ve = c->vesz;
+    hipStream_t st = c->stream;
+    int Cin = 3, S = 224;
+    for (int l = 0; l < 13; ++l) {
+        VggLayer &L = c->conv[l];
+        L.Cin = Cin;
+        L.Cout = kVggCout[l];
+        L.S = S;
+        L.pool = kVggPool[l];
+        DALLOC(c, L.b, sizeof(float) * L.Cout);
+        HIPCHK(c, hipMemcpyAsync(L.b, cb[l], sizeof(float) * L.Cout, hipMemcpyDeviceToDevice, st));
+        if (l == 0) {
+            DALLOC(c, L.w, ve * 64 * 32);
+            k_repack_conv11_w(st, vdt, cw[0], 64, L.w, 32);
+        } else {
+            DALLOC(c, L.w, ve * (size_t)L.Cout * 9 * Cin);
+            k_repack_conv_w(st, vdt, cw[l], Cin, L.Cout, Cin, L.w);
+        }
+        Cin = L.Cout;
+        if (L.pool) S /= 2;
+    }
+    DALLOC(c, c->fc6w, ve * 4096ull * 25088ull);
+    DALLOC(c, c->fc7w, ve * 4096ull * 4096ull);
+    DALLOC(c, c->fc6b, sizeof(float) * 4096);
+    DALLOC(c, c->fc7b, sizeof(float) * 4096);
+    k_repack_fc6_w(st, vdt, fc6_w, c->fc6w);
+    k_transpose(st, vdt, 1, fc7_w, 4096, 4096, 4096, c->fc7w, 4096, 0);  // (o,k) at o + 4096k -> [o][k]
+    HIPCHK(c, hipMemcpyAsync(c->fc6b, fc6_b, sizeof(float) * 4096, hipMemcpyDeviceToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->fc7b, fc7_b, sizeof(float) * 4096, hipMemcpyDeviceToDevice, st));
+    KCHK(c, "vgg_load");
+    HIPCHK(c, hipStreamSynchronize(st));
+    c->vgg_loaded = true;
+    return LRCN_OK;
+}
+
+namespace {
+int conv_layer(lrcn_ctx *c, int dtype, const void *in, const VggLayer &L, int N, void *out) {
+    GemmArgs g{};
+    g.dtype = dtype;
+    g.A = in;
+    g.B = L.w;
+    g.ldb = 9 * L.Cin;
+    g.C = out;
+    g.ldc = L.Cout;
+    g.M = N * L.S * L.S;
+    g.N = L.Cout;
+    g.K = 9 * L.Cin;
+    g.bias = L.b;
+    g.relu = 1;
+    g.a_mode = GEMM_A_CONV3;
+    g.out_mode = L.pool ? GEMM_OUT_POOL : GEMM_OUT_CONV;
+    g.H = g.W = L.S;
+    g.Cin = L.Cin;
+    hipError_t e = launch_gemm(c->stream, g);
+    if (e != hipSuccess) FAIL(c, LRCN_EHIP, "conv layer S=%d Cin=%d Cout=%d: %s", L.S, L.Cin, L.Cout, hipGetErrorString(e));
+    return LRCN_OK;
+}
+
+// im2col (already in c->im2col) -> featsRM [N][4096] f32
+int vgg_body(lrcn_ctx *c, int N) {
+    const int vdt = c->vdt;
+    // conv1_1 as a plain GEMM over the explicit im2col (K = 27), scattered to NHWC
+    {
+        GemmArgs g{};
+        g.dtype = vdt;
+        g.A = c->im2col;
+        g.lda = 32;
+        g.B = c->conv[0].w;
+        g.ldb = 32;
+        g.C = c->actA;
+        g.ldc = 64;
+        g.M = N * 224 * 224;
+        g.N = 64;
+        g.K = 27;
+        g.bias = c->conv[0].b;
+        g.relu = 1;
+        g.a_mode = GEMM_A_PLAIN;
+        g.out_mode = GEMM_OUT_CONV;
+        g.H = g.W = 224;
+        hipError_t e = launch_gemm(c->stream, g);
+        if (e != hipSuccess) FAIL(c, LRCN_EHIP, "conv1_1: %s", hipGetErrorString(e));
+    }
+    void *cur = c->actA, *nxt = c->actB;
+    for (int l = 1; l < 13; ++l) {
+        int r = conv_layer(c, vdt, cur, c->conv[l], N, nxt);
+        if (r) return r;
+        std::swap(cur, nxt);
+    }
+    // cur = pool5 output [N][7*7*512]; fc6 + relu6; fc7 (no relu7: lrcn.jl:717)
+    GemmArgs g{};
+    g.dtype = vdt;
+    g.A = cur;
+    g.lda = 25088;
+    g.B = c->fc6w;
+    g.ldb = 25088;
+    g.C = c->f6;
+    g.ldc = 4096;
+    g.M = N;
+    g.N = 4096;
+    g.K = 25088;
+    g.bias = c->fc6b;
+    g.relu = 1;
+    hipError_t e = launch_gemm(c->stream, g);
+    if (e != hipSuccess) FAIL(c, LRCN_EHIP, "fc6: %s", hipGetErrorString(e));
+    g.A = c->f6;
+    g.lda = 4096;
+    g.B = c->fc7w;
+    g.ldb = 4096;
+    g.C = c->featsRM;
+    g.K = 4096;
+    g.bias = c->fc7b;
+    g.relu = 0;
+    g.c_f32 = 1;
+    e = launch_gemm(c->stream, g);
+    if (e != hipSuccess) FAIL(c, LRCN_EHIP, "fc7: %s", hipGetErrorString(e));
+    return LRCN_OK;
+}
+int vgg_check(lrcn_ctx *c, int N) {
+    if (!c->vgg_loaded) FAIL(c, LRCN_ESTATE, "lrcn_vgg_load has not been called");
+    if (N < 1 || N > c->cfg.max_images) FAIL(c, LRCN_EINVAL, "N=%d outside [1,%d]", N, c->cfg.max_images);
+    return LRCN_OK;
+}
+}  // namespace
+
+int lrcn_vgg_forward(lrcn_ctx *c, const float *x, int N, float *feats) {
+    if (!c || !x || !feats) return LRCN_EINVAL;
+    int r = vgg_check(c, N);
+    if (r) return r;
+    k_im2col11_f32(c->stream, c->vdt, x, N, 224, c->im2col, 32);
+    r = vgg_body(c, N);
+    if (r) return r;
+    k_transpose_f32(c->stream, c->featsRM, 4096, N, 4096, feats, N);  // return transpose(xs): N x 4096 column-major
+    KCHK(c, "vgg_forward");
+    return LRCN_OK;
+}
+
+int lrcn_vgg_forward_u8(lrcn_ctx *c, const uint8_t *img, int N, const float mean[3], float *feats) {
+    if (!c || !img || !feats || !mean) return LRCN_EINVAL;
+    int r = vgg_check(c, N);
+    if (r) return r;
+    k_im2col11_u8(c->stream, c->vdt, img, N, 224, mean[0], mean[1], mean[2], c->im2col, 32);
+    r = vgg_body(c, N);
+    if (r) return r;
+    k_transpose_f32(c->stream, c->featsRM, 4096, N, 4096, feats, N);
+    KCHK(c, "vgg_forward_u8");
+    return LRCN_OK;
+}
+
+int lrcn_preprocess_u8(lrcn_ctx *c, const uint8_t *img, int N, const float mean[3], float *out) {
+    if (!c || !img || !out || !mean || N < 1) return LRCN_EINVAL;
+    k_preprocess_u8(c->stream, img, N, 224, mean[0], mean[1], mean[2], out);
+    KCHK(c, "preprocess_u8");
+    return LRCN_OK;
+}
+
+int lrcn_conv3x3(lrcn_ctx *c, const float *x, int W, int H, int Cin, int N, const float *w, const float *b, int Cout, int relu,
+                 int pool, float *y) {
+    if (!c || !x || !w || !b || !y) return LRCN_EINVAL;
+    if (W < 2 || H < 2 || (W & 1) || (H & 1) || Cin < 1 || Cout < 1 || N < 1) FAIL(c, LRCN_EINVAL, "conv3x3: W,H must be even, sizes positive");
+    const int vdt = c->vdt;
+    const size_t ve = c->vesz;
+    const int bk = vdt == GEMM_T_BF16 ? 64 : 32;
+    const int Cp = (int)round_up64(Cin, bk);
+    void *xin = nullptr, *wp = nullptr, *out = nullptr;
+    float *bd = nullptr;
+    const int Wo = pool ? W / 2 : W, Ho = pool ? H / 2 : H;
+    auto cleanup = [&]() {
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipFree(xin);
+        (void)hipFree(wp);
+        (void)hipFree(out);
+        (void)hipFree(bd);
+    };
+    if (hipMalloc(&xin, ve * (size_t)N * H * W * Cp) != hipSuccess || hipMalloc(&wp, ve * (size_t)Cout * 9 * Cp) != hipSuccess ||
+        hipMalloc(&out, ve * (size_t)N * Ho * Wo * Cout) != hipSuccess || hipMalloc((void **)&bd, sizeof(float) * Cout) != hipSuccess) {
+        cleanup();
+        FAIL(c, LRCN_ENOMEM, "conv3x3 scratch");
+    }
+    (void)hipMemcpyAsync(bd, b, sizeof(float) * Cout, hipMemcpyDeviceToDevice, c->stream);
+    k_ref_to_nhwc(c->stream, vdt, x, W, H, Cin, N, xin, Cp);
+    k_repack_conv_w(c->stream, vdt, w, Cin, Cout, Cp, wp);
+    GemmArgs g{};
+    g.dtype = vdt;
+    g.A = xin;
+    g.B = wp;
+    g.ldb = 9 * Cp;
+    g.C = out;
+    g.ldc = Cout;
+    g.M = N * H * W;
+    g.N = Cout;
+    g.K = 9 * Cp;
+    g.bias = bd;
+    g.relu = relu;
+    g.a_mode = GEMM_A_CONV3;
+    g.out_mode = pool ? GEMM_OUT_POOL : GEMM_OUT_CONV;
+    g.H = H;
+    g.W = W;
+    g.Cin = Cp;
+    hipError_t e = launch_gemm(c->stream, g);
+    if (e == hipSuccess) {
+        k_nhwc_to_ref(c->stream, vdt, out, Wo, Ho, Cout, N, Cout, y);
+        e = hipGetLastError();
+    }
+    cleanup();
+    if (e != hipSuccess) FAIL(c, LRCN_EHIP, "conv3x3: %s", hipGetErrorString(e));
+    return LRCN_OK;
+}
+
+}  // extern "C"

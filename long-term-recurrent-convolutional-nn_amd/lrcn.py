@@ -1,0 +1,371 @@
+"""Host-side mirror of the reference's function surface (lrcn.jl) over the HIP C ABI (include/lrcn.h).
+
+Julia is not available in this image, so the host language above the C ABI is Python; names, argument meaning and
+error behaviour follow lrcn.jl so that a test written against the reference reads the same here:
+
+    initweights (lrcn.jl:489)   initstate (:512)   lstm (:528)   lrcn (:540)   loss (:553)   lossgradient (:583)
+    initparams / update! (:399, :394)   train1's body -> train_step (:369-394)   average_loss's body -> loss(pdrop=0)
+    generate / beam_search (:585-678)   get_convnet -> convnet (:733)   read_image_data's arithmetic (:766-772)
+
+Arrays are torch CUDA tensors holding the reference's COLUMN-MAJOR memory: a Julia R x C matrix is a tensor of
+shape (R, C) with strides (1, R) (see `jl_empty`), so `.data_ptr()` is exactly what a Julia `ccall` would pass.
+torch is used for device memory, streams and (in dp.py) torch.distributed only -- all arithmetic is in
+liblrcn_hip.so.  Token ids are 0-based at this layer (eos=0, bos=1, unk=2).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import BOS, CNNOUT, EOS, LRCN_BF16, LRCN_F32, UNK, LrcnError  # noqa: F401
+
+PARAM_NAMES = ("W1", "b1", "W2", "b2", "Wproj", "Wcnn", "Wembed", "Wout", "bout")
+VGG_COUT = (64, 64, 128, 128, 256, 256, 256, 512, 512, 512, 512, 512, 512)
+VGG_MEAN = (123.68, 116.779, 103.939)  # per-channel mean of the VGG-16 averageImage (lrcn.jl:113)
+
+
+# ------------------------------------------------------------------------------------------------ arrays
+def jl_empty(*dims, device="cuda", dtype=torch.float32):
+    """Uninitialised tensor of Julia shape `dims` in column-major memory (first index fastest)."""
+    t = torch.empty(tuple(reversed(dims)), device=device, dtype=dtype)
+    return t.permute(*reversed(range(len(dims))))
+
+
+def jl_zeros(*dims, device="cuda", dtype=torch.float32):
+    t = jl_empty(*dims, device=device, dtype=dtype)
+    t.zero_()
+    return t
+
+
+def to_jl(a, device="cuda"):
+    """numpy / tensor of logical shape dims -> column-major device tensor of the same logical shape."""
+    a = torch.as_tensor(np.asarray(a, dtype=np.float32) if not torch.is_tensor(a) else a)
+    out = jl_empty(*a.shape, device=device, dtype=torch.float32)
+    out.copy_(a)
+    return out
+
+
+def from_jl(t):
+    return t.detach().cpu().numpy()
+
+
+def _is_jl(t):
+    n = t.dim()
+    if n == 0 or t.numel() == 0:
+        return True
+    return t.permute(*reversed(range(n))).is_contiguous()
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise LrcnError("expected a CUDA (HIP) tensor")
+    if not _is_jl(t):
+        raise LrcnError("tensor is not in the reference's column-major memory order (use to_jl/jl_empty)")
+    return C.c_void_p(t.data_ptr())
+
+
+def _p9(ts):
+    if len(ts) != 9:
+        raise LrcnError("model must have 9 tensors (lrcn.jl:492)")
+    for t in ts:
+        if t.dtype != torch.float32:
+            raise LrcnError("model tensors must be float32")
+    return _lib.P9(*[_ptr(t).value for t in ts])
+
+
+def param_shapes(E, H1, H2, V):
+    h = (H2 + 1) // 2
+    return [(E + H1, 4 * H1), (1, 4 * H1), (H2 + H2, 4 * H2), (1, 4 * H2), (H1, h), (CNNOUT, h), (V, E), (H2, V), (1, V)]
+
+
+# ------------------------------------------------------------------------------------------------ context
+class Context:
+    """One lrcn_ctx (one device). Owns scratch only; the caller owns models, gradients, optimizer state."""
+
+    def __init__(self, E, H1, H2, V, max_B, max_T=_lib.MAX_T, lstm_dtype=LRCN_F32, vgg_dtype=LRCN_F32, max_images=0,
+                 device=None):
+        if not torch.cuda.is_available():
+            raise LrcnError("no MI355X visible: liblrcn_hip has no CPU path")
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        self.E, self.H1, self.H2, self.V = E, H1, H2, V
+        self.h = H2 // 2
+        self.max_B, self.max_T = max_B, max_T
+        self.lstm_dtype, self.vgg_dtype = lstm_dtype, vgg_dtype
+        cfg = _lib.Config(self.device, E, H1, H2, V, max_B, max_T, lstm_dtype, vgg_dtype, max_images)
+        h = C.c_void_p()
+        rc = _lib.lib().lrcn_create(C.byref(cfg), C.byref(h))
+        _lib.check(None, rc)
+        self._h = h
+        self._stream = None
+        self.use_stream(torch.cuda.current_stream(self.device))
+
+    def use_stream(self, stream):
+        self._stream = stream
+        _lib.check(self._h, _lib.lib().lrcn_set_stream(self._h, C.c_void_p(stream.cuda_stream)))
+
+    def sync(self):
+        _lib.check(self._h, _lib.lib().lrcn_sync(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _lib.lib().lrcn_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _call(self, name, *args):
+        _lib.check(self._h, getattr(_lib.lib(), name)(self._h, *args))
+
+
+def _dropout(pdrop, seed, mask1, mask2):
+    if (pdrop is None or pdrop == 0) and mask1 is None:
+        return None, None
+    d = _lib.Dropout(float(pdrop or 0.0), int(seed or 0), None, None)
+    keep = None
+    if mask1 is not None:
+        # masks: (T+1, B, E) / (T+1, B, H2) logical arrays; the ABI wants (T+1) column-major blocks
+        m1 = torch.as_tensor(np.ascontiguousarray(np.transpose(np.asarray(mask1, np.float32), (0, 2, 1)))).cuda()
+        m2 = torch.as_tensor(np.ascontiguousarray(np.transpose(np.asarray(mask2, np.float32), (0, 2, 1)))).cuda()
+        d.mask1, d.mask2 = m1.data_ptr(), m2.data_ptr()
+        keep = (m1, m2)
+    return d, keep
+
+
+def _tokens(tokens, device):
+    t = torch.as_tensor(np.ascontiguousarray(np.asarray(tokens, dtype=np.int32)) if not torch.is_tensor(tokens) else tokens)
+    if t.dim() != 2:
+        raise LrcnError("tokens must be [T][B]")
+    return t.to(device=device, dtype=torch.int32).contiguous()
+
+
+# ------------------------------------------------------------------------------------------------ model
+def initweights(ctx, seed=42):
+    """initweights(atype, hidden, vocab, embed) (lrcn.jl:489-510) -> list of 9 column-major tensors."""
+    model = [jl_empty(*s) for s in param_shapes(ctx.E, ctx.H1, ctx.H2, ctx.V)]
+    ctx._call("lrcn_init_weights", _p9(model), C.c_uint64(seed))
+    return model
+
+
+def model_from_arrays(arrays):
+    """dict name->array or list of 9 arrays (logical reference shapes) -> device model."""
+    if isinstance(arrays, dict):
+        arrays = [arrays[n] for n in PARAM_NAMES]
+    return [to_jl(a) for a in arrays]
+
+
+def zeros_like_model(model):
+    out = []
+    for t in model:
+        z = jl_empty(*t.shape)
+        z.zero_()
+        out.append(z)
+    return out
+
+
+def initstate(ctx, batch):
+    """initstate(model, batch) (lrcn.jl:512-526): zero (B x H) hidden/cell per layer -- without the reference's
+    spurious third layer and without aliasing all entries to one array."""
+    return [jl_zeros(batch, ctx.H1), jl_zeros(batch, ctx.H1), jl_zeros(batch, ctx.H2), jl_zeros(batch, ctx.H2)]
+
+
+def lstm(ctx, weight, bias, hidden, cell, input):
+    """lstm(weight,bias,hidden,cell,input) (lrcn.jl:528-538) -> (hidden, cell)."""
+    B, X = input.shape
+    H = hidden.shape[1]
+    h_out, c_out = jl_empty(B, H), jl_empty(B, H)
+    ctx._call("lrcn_lstm", _ptr(weight), _ptr(bias), X, H, B, _ptr(input), _ptr(hidden), _ptr(cell), _ptr(h_out), _ptr(c_out))
+    return h_out, c_out
+
+
+def lrcn(ctx, w, s, x_cnn, x_lstm, mask1=None, mask2=None):
+    """lrcn(w, s, x_cnn, x_lstm; pdrop) (lrcn.jl:540-551): one timestep; mutates s like the reference; returns logits.
+    Dropout enters as explicit multiplier arrays (B x E, B x H2) so a step is reproducible."""
+    B = x_lstm.shape[0]
+    logits = jl_empty(B, ctx.V)
+    st = _lib.P4(*[_ptr(t).value for t in s])
+    ctx._call("lrcn_step", _p9(w), st, B, _ptr(x_cnn), _ptr(x_lstm), _ptr(mask1), _ptr(mask2), _ptr(logits))
+    return logits
+
+
+def loss(ctx, param, feats, tokens, norm_B=None, pdrop=0.0, seed=0, mask1=None, mask2=None):
+    """loss(param,state,input,sequence,range; pdrop) (lrcn.jl:553-581).  feats: B x 4096 (column-major);
+    tokens: [T][B] = sequence[range]; norm_B = the reference's global `batchsize` (default B)."""
+    tok = _tokens(tokens, feats.device)
+    T, B = tok.shape
+    d, keep = _dropout(pdrop, seed, mask1, mask2)
+    out = C.c_double()
+    ctx._call("lrcn_loss", _p9(param), _ptr(feats), C.c_void_p(tok.data_ptr()), T, B, norm_B or B,
+              C.byref(d) if d else None, C.byref(out))
+    del keep
+    return out.value
+
+
+def lossgradient(ctx, param, feats, tokens, norm_B=None, pdrop=0.0, seed=0, mask1=None, mask2=None, grads=None,
+                 want_loss=True):
+    """lossgradient = grad(loss) (lrcn.jl:583) -> (grads, loss).  `grads` may be a preallocated 9-list."""
+    tok = _tokens(tokens, feats.device)
+    T, B = tok.shape
+    if grads is None:
+        grads = [jl_empty(*t.shape) for t in param]
+    d, keep = _dropout(pdrop, seed, mask1, mask2)
+    out = C.c_double()
+    ctx._call("lrcn_loss_grad", _p9(param), _ptr(feats), C.c_void_p(tok.data_ptr()), T, B, norm_B or B,
+              C.byref(d) if d else None, _p9(grads), C.byref(out) if want_loss else None)
+    del keep
+    return grads, (out.value if want_loss else None)
+
+
+def last_loss(ctx):
+    out = C.c_double()
+    ctx._call("lrcn_last_loss", C.byref(out))
+    return out.value
+
+
+def forward_logits(ctx, param, feats, tokens):
+    """Per-step logits of the loss forward pass: (T+1, B, V) numpy (parity probe)."""
+    tok = _tokens(tokens, feats.device)
+    T, B = tok.shape
+    out = torch.empty((T + 1, ctx.V, B), device=feats.device, dtype=torch.float32)  # blocks of B x V column-major
+    ctx._call("lrcn_forward_logits", _p9(param), _ptr(feats), C.c_void_p(tok.data_ptr()), T, B, C.c_void_p(out.data_ptr()))
+    return out.permute(0, 2, 1).cpu().numpy()
+
+
+class Adam:
+    """One Knet Adam() per tensor (initparams, lrcn.jl:399-405) with Knet's defaults."""
+
+    def __init__(self, model, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8):
+        self.lr, self.beta1, self.beta2, self.eps = lr, beta1, beta2, eps
+        self.t = 0
+        self.m = zeros_like_model(model)
+        self.v = zeros_like_model(model)
+
+
+def initparams(model):
+    return Adam(model)
+
+
+def update(ctx, param, grads, optim):
+    """update!(param, gloss, optim) (lrcn.jl:394)."""
+    optim.t += 1
+    ctx._call("lrcn_adam_update", _p9(param), _p9(grads), _p9(optim.m), _p9(optim.v), optim.t, optim.lr, optim.beta1,
+              optim.beta2, optim.eps)
+
+
+def train_step(ctx, param, optim, grads, feats, tokens, norm_B=None, pdrop=0.4, seed=0, want_loss=False):
+    """Body of train1's batch loop (lrcn.jl:369-394): lossgradient + update!, one C call."""
+    tok = _tokens(tokens, feats.device)
+    T, B = tok.shape
+    d, keep = _dropout(pdrop, seed, None, None)
+    optim.t += 1
+    out = C.c_double()
+    ctx._call("lrcn_train_step", _p9(param), _p9(grads), _p9(optim.m), _p9(optim.v), _ptr(feats), C.c_void_p(tok.data_ptr()),
+              T, B, norm_B or B, C.byref(d) if d else None, optim.t, optim.lr, optim.beta1, optim.beta2, optim.eps,
+              C.byref(out) if want_loss else None)
+    del keep
+    return out.value if want_loss else None
+
+
+def average_loss(ctx, param, batches):
+    """average_loss (lrcn.jl:407-486): forward-only NLL over batches [(feats, tokens), ...], pdrop 0, captions longer
+    than 28 tokens skipped (:438); returns -total/count with count = sum of B*(T+1)."""
+    total, count = 0.0, 0
+    for feats, tokens in batches:
+        T, B = np.asarray(tokens).shape if not torch.is_tensor(tokens) else tokens.shape
+        if T > 28:
+            continue
+        n = B * (T + 1)
+        total += loss(ctx, param, feats, tokens) * n
+        count += n
+    return total / max(count, 1)
+
+
+def beam_search(ctx, param, feat, beam_width, nword):
+    """generate's decode (lrcn.jl:609-633) + beam_search (:644-678) -> (token ids incl. bos, probability)."""
+    out = (C.c_int32 * (nword + 3))()
+    n = C.c_int()
+    p = C.c_float()
+    ctx._call("lrcn_beam_search", _p9(param), _ptr(feat), beam_width, nword, out, C.byref(n), C.byref(p))
+    return list(out[:n.value]), p.value
+
+
+def generate(ctx, param, feat, index_to_word, nword, beam_width, normalize=False):
+    """generate (lrcn.jl:585-642): caption text "w1 w2 ... ." -- words after bos up to the first eos (:634-640)."""
+    if normalize:
+        feat = to_jl(from_jl(feat) / from_jl(feat).sum())  # input/sum(input) (lrcn.jl:597)
+    seq, _ = beam_search(ctx, param, feat, beam_width, nword)
+    words = []
+    for t in seq[1:]:
+        if t == EOS:
+            break
+        words.append(index_to_word[t])
+    return " ".join(words + ["."])
+
+
+# ------------------------------------------------------------------------------------------------ VGG
+def vgg_load(ctx, conv_w, conv_b, fc6, fc7):
+    """get_params_cnn's output (lrcn.jl:697-721) -> the context. conv_w[l]: (3,3,Cin,Cout) column-major tensors."""
+    cw = _lib.P13(*[_ptr(t).value for t in conv_w])
+    cb = _lib.P13(*[_ptr(t).value for t in conv_b])
+    ctx._call("lrcn_vgg_load", cw, cb, _ptr(fc6[0]), _ptr(fc6[1]), _ptr(fc7[0]), _ptr(fc7[1]))
+
+
+def convnet(ctx, x):
+    """convnet(xs) (lrcn.jl:734-747): x (224,224,3,N) column-major -> feats N x 4096."""
+    N = x.shape[3]
+    feats = jl_empty(N, CNNOUT)
+    ctx._call("lrcn_vgg_forward", _ptr(x), N, _ptr(feats))
+    return feats
+
+
+def convnet_u8(ctx, img_u8, mean=VGG_MEAN, feats=None):
+    """Fused read_image_data arithmetic (lrcn.jl:766-772) + convnet on uint8 crops img[n][row][col][c]."""
+    N = img_u8.shape[0]
+    if feats is None:
+        feats = jl_empty(N, CNNOUT)
+    m = (C.c_float * 3)(*mean)
+    ctx._call("lrcn_vgg_forward_u8", C.c_void_p(img_u8.data_ptr()), N, m, _ptr(feats))
+    return feats
+
+
+def read_image_data_u8(ctx, img_u8, mean=VGG_MEAN):
+    """read_image_data's arithmetic tail (lrcn.jl:766-772) -> (224,224,3,N) column-major float tensor."""
+    N = img_u8.shape[0]
+    out = jl_empty(224, 224, 3, N)
+    m = (C.c_float * 3)(*mean)
+    ctx._call("lrcn_preprocess_u8", C.c_void_p(img_u8.data_ptr()), N, m, _ptr(out))
+    return out
+
+
+def conv3x3(ctx, x, w, b, relu=True, pool=False):
+    """convx/relux/poolx probe (lrcn.jl:724-726) in reference layouts."""
+    W, H, Cin, N = x.shape
+    Cout = w.shape[3]
+    y = jl_empty(W // 2 if pool else W, H // 2 if pool else H, Cout, N)
+    ctx._call("lrcn_conv3x3", _ptr(x), W, H, Cin, N, _ptr(w), _ptr(b), Cout, int(relu), int(pool), _ptr(y))
+    return y
+
+
+def synthetic_vgg_weights(seed=1, device="cuda"):
+    """He-normal(fan_in) VGG-16 weights, zero biases (no pretrained file offline)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    conv_w, conv_b = [], []
+    cin = 3
+    for cout in VGG_COUT:
+        w = jl_empty(3, 3, cin, cout, device=device)
+        w.copy_(torch.randn((3, 3, cin, cout), generator=g, device=device) * float(np.sqrt(2.0 / (9 * cin))))
+        conv_w.append(w)
+        conv_b.append(torch.zeros(cout, device=device))
+        cin = cout
+    fc6 = jl_empty(4096, 25088, device=device)
+    fc6.copy_(torch.randn((4096, 25088), generator=g, device=device) * float(np.sqrt(2.0 / 25088)))
+    fc7 = jl_empty(4096, 4096, device=device)
+    fc7.copy_(torch.randn((4096, 4096), generator=g, device=device) * float(np.sqrt(2.0 / 4096)))
+    return conv_w, conv_b, (fc6, torch.zeros(4096, device=device)), (fc7, torch.zeros(4096, device=device))

@@ -1,0 +1,182 @@
+"""GPU: the HIP LSTM/loss/gradient/Adam/beam path (through the C ABI) against the golden vectors and the CPU oracle.
+fp32 tolerances: loss |d|/loss <= 1e-5; gradients max-abs <= 1e-5 + 1e-3*|g|.
+bf16: loss <= 2e-2 relative."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import lrcn_amd
+from lrcn_amd import lrcn as L
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+CASES = ["lstm_tiny", "lstm_tiny_drop", "lstm_ragged", "lstm_mid"]
+
+
+def load_case(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    dims = tuple(int(z[k]) for k in ("E", "H1", "H2", "V"))
+    return z, dims
+
+
+def make_ctx(dims, B, T, dtype=lrcn_amd.LRCN_F32):
+    E, H1, H2, V = dims
+    return L.Context(E, H1, H2, V, max_B=B, max_T=T, lstm_dtype=dtype)
+
+
+def grads_close(got, ref, rtol=1e-3, atol=1e-5):
+    for n, g, r in zip(orc.PARAM_NAMES, got, ref):
+        np.testing.assert_allclose(L.from_jl(g), r, rtol=rtol, atol=atol, err_msg=n)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_loss_and_grads_vs_golden_fp32(golden_dir, name):
+    z, dims = load_case(golden_dir, name)
+    T, B = z["tokens"].shape
+    ctx = make_ctx(dims, B, T)
+    param = L.model_from_arrays({n: z["p_" + n] for n in orc.PARAM_NAMES})
+    m1 = z["mask1"] if "mask1" in z else None
+    m2 = z["mask2"] if "mask2" in z else None
+    feats = L.to_jl(z["feats"])
+    val = L.loss(ctx, param, feats, z["tokens"], norm_B=int(z["norm_B"]), mask1=m1, mask2=m2)
+    assert abs(val - float(z["loss"])) <= 1e-5 * abs(float(z["loss"]))
+    grads, val2 = L.lossgradient(ctx, param, feats, z["tokens"], norm_B=int(z["norm_B"]), mask1=m1, mask2=m2)
+    assert abs(val2 - float(z["loss"])) <= 1e-5 * abs(float(z["loss"]))
+    grads_close(grads, [z["g_" + n] for n in orc.PARAM_NAMES])
+
+
+@pytest.mark.parametrize("name", ["lstm_tiny", "lstm_mid"])
+def test_per_step_logits_vs_golden(golden_dir, name):
+    z, dims = load_case(golden_dir, name)
+    T, B = z["tokens"].shape
+    ctx = make_ctx(dims, B, T)
+    param = L.model_from_arrays({n: z["p_" + n] for n in orc.PARAM_NAMES})
+    got = L.forward_logits(ctx, param, L.to_jl(z["feats"]), z["tokens"])
+    np.testing.assert_allclose(got, z["logits"], rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("name", ["lstm_tiny", "lstm_ragged"])
+def test_adam_trajectory_vs_golden(golden_dir, name):
+    z, dims = load_case(golden_dir, name)
+    T, B = z["tokens"].shape
+    ctx = make_ctx(dims, B, T)
+    param = L.model_from_arrays({n: z["p_" + n] for n in orc.PARAM_NAMES})
+    opt = L.initparams(param)
+    feats = L.to_jl(z["feats"])
+    for ref_loss in z["adam_losses"]:
+        grads, val = L.lossgradient(ctx, param, feats, z["tokens"], norm_B=int(z["norm_B"]))
+        assert abs(val - ref_loss) <= 2e-5 * abs(ref_loss)
+        L.update(ctx, param, grads, opt)
+    for n, p in zip(orc.PARAM_NAMES, param):
+        np.testing.assert_allclose(L.from_jl(p), z["a_" + n], rtol=0, atol=5e-6, err_msg=n)
+
+
+@pytest.mark.parametrize("name", ["lstm_tiny", "lstm_ragged", "lstm_mid"])
+def test_beam_search_vs_golden(golden_dir, name):
+    z, dims = load_case(golden_dir, name)
+    K, nword = int(z["beam_K"]), int(z["beam_nword"])
+    ctx = make_ctx(dims, max(K, 4), 4)
+    param = L.model_from_arrays({n: z["p_" + n] for n in orc.PARAM_NAMES})
+    for i, (ref, rp) in enumerate(zip(z["beam_tokens"], z["beam_prob"])):
+        seq, p = L.beam_search(ctx, param, L.to_jl(z["feats"][i:i + 1]), K, nword)
+        assert seq == list(ref[ref >= 0]), (i, seq, ref)
+        assert abs(p - rp) <= 1e-4 * abs(rp)
+
+
+def test_single_lstm_and_lrcn_step_vs_oracle():
+    rng = np.random.default_rng(11)
+    E, H1, H2, V, B = 24, 32, 16, 57, 5
+    m = orc.init_weights(E, H1, H2, V, seed=9)
+    ctx = L.Context(E, H1, H2, V, max_B=B, max_T=2)
+    param = L.model_from_arrays(m.p)
+    x = rng.standard_normal((B, E)).astype(np.float32)
+    h = rng.standard_normal((B, H1)).astype(np.float32) * 0.5
+    c = rng.standard_normal((B, H1)).astype(np.float32) * 0.5
+    ho, co = L.lstm(ctx, param[0], param[1], L.to_jl(h), L.to_jl(c), L.to_jl(x))
+    rh, rc = orc.lstm(m.p["W1"], m.p["b1"], x, h, c)
+    np.testing.assert_allclose(L.from_jl(ho), rh, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(L.from_jl(co), rc, rtol=1e-5, atol=1e-6)
+    # one lrcn() step with explicit dropout masks, state carried across two calls
+    state_ref = [rng.standard_normal((B, H)).astype(np.float32) * 0.3 for H in (H1, H1, H2, H2)]
+    state = [L.to_jl(s) for s in state_ref]
+    state_ref = [orc.fa(s) for s in state_ref]
+    x_cnn = rng.standard_normal((B, H2 // 2)).astype(np.float32)
+    for _ in range(2):
+        x_lstm = rng.standard_normal((B, E)).astype(np.float32)
+        m1 = ((rng.random((B, E)) > 0.4) / 0.6).astype(np.float32)
+        m2 = ((rng.random((B, H2)) > 0.4) / 0.6).astype(np.float32)
+        got = L.lrcn(ctx, param, state, L.to_jl(x_cnn), L.to_jl(x_lstm), L.to_jl(m1), L.to_jl(m2))
+        ref = orc.lrcn_step(m, state_ref, x_cnn, x_lstm, m1, m2)
+        np.testing.assert_allclose(L.from_jl(got), ref, rtol=1e-4, atol=1e-5)
+        for a, b in zip(state, state_ref):
+            np.testing.assert_allclose(L.from_jl(a), b, rtol=1e-4, atol=1e-5)
+
+
+def test_config1_shape_vs_oracle_fp32_and_bf16():
+    # BASELINE config 1 shape (Flickr8k LSTM-only, B=16, E=H=512, V~2540, T=11): HIP vs the C oracle on seeded inputs.
+    rng = np.random.default_rng(5)
+    E = H1 = H2 = 512
+    V, B, T = 2540, 16, 11
+    m = orc.init_weights(E, H1, H2, V, seed=42)
+    feats = (rng.standard_normal((B, 4096)) * 0.01).astype(np.float32)
+    tokens = rng.integers(3, V, size=(T, B)).astype(np.int32)
+    ref_loss, ref_g = orc.loss(m, feats, tokens, want_grad=True)
+    ctx = L.Context(E, H1, H2, V, max_B=B, max_T=T)
+    param = L.model_from_arrays(m.p)
+    grads, val = L.lossgradient(ctx, param, L.to_jl(feats), tokens)
+    assert abs(val - ref_loss) <= 1e-5 * abs(ref_loss)
+    grads_close(grads, [ref_g.p[n] for n in orc.PARAM_NAMES], rtol=1e-3, atol=1e-5)
+    ctx.close()
+    ctx16 = L.Context(E, H1, H2, V, max_B=B, max_T=T, lstm_dtype=lrcn_amd.LRCN_BF16)
+    grads16, val16 = L.lossgradient(ctx16, param, L.to_jl(feats), tokens)
+    assert abs(val16 - ref_loss) <= 2e-2 * abs(ref_loss)
+    # bf16 gradients: direction agrees (cosine) -- the tolerance north_star states is on the loss
+    for n, g in zip(orc.PARAM_NAMES, grads16):
+        a, b = L.from_jl(g).ravel().astype(np.float64), ref_g.p[n].ravel().astype(np.float64)
+        cos = a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30)
+        assert cos > 0.99, (n, cos)
+
+
+def test_device_dropout_is_consistent_and_unbiased():
+    # device-generated masks: forward (loss) and backward (lossgradient) must see the same mask; E[mask] = 1
+    rng = np.random.default_rng(6)
+    E, H1, H2, V, B, T = 64, 64, 64, 211, 8, 5
+    m = orc.init_weights(E, H1, H2, V, seed=2)
+    ctx = L.Context(E, H1, H2, V, max_B=B, max_T=T)
+    param = L.model_from_arrays(m.p)
+    feats = L.to_jl((rng.standard_normal((B, 4096)) * 0.05).astype(np.float32))
+    tokens = rng.integers(0, V, size=(T, B)).astype(np.int32)
+    a = L.loss(ctx, param, feats, tokens, pdrop=0.4, seed=123)
+    _, b = L.lossgradient(ctx, param, feats, tokens, pdrop=0.4, seed=123)
+    c = L.loss(ctx, param, feats, tokens, pdrop=0.4, seed=124)
+    assert a == b and a != c
+    # finite-difference check of one bias gradient under a fixed device mask
+    g, _ = L.lossgradient(ctx, param, feats, tokens, pdrop=0.4, seed=123)
+    gb = L.from_jl(g[8])[0, 7]
+    bout = L.from_jl(param[8]).copy()
+    eps = 1e-2
+    bout[0, 7] += eps
+    param[8].copy_(torch.as_tensor(bout))
+    lp = L.loss(ctx, param, feats, tokens, pdrop=0.4, seed=123)
+    bout[0, 7] -= 2 * eps
+    param[8].copy_(torch.as_tensor(bout))
+    lm = L.loss(ctx, param, feats, tokens, pdrop=0.4, seed=123)
+    assert abs((lp - lm) / (2 * eps) - gb) < 2e-3 * max(1e-2, abs(gb)) + 1e-5
+
+
+def test_error_paths_do_not_abort():
+    ctx = L.Context(8, 8, 8, 17, max_B=4, max_T=3)
+    param = L.initweights(ctx)
+    feats = L.jl_zeros(4, 4096)
+    with pytest.raises(L.LrcnError):
+        L.loss(ctx, param, feats, np.zeros((9, 4), np.int32))  # T > max_T
+    with pytest.raises(L.LrcnError):
+        L.loss(ctx, param, L.jl_zeros(9, 4096), np.zeros((2, 9), np.int32))  # B > max_B
+    with pytest.raises(L.LrcnError):
+        L.Context(8, 8, 7, 17, max_B=4)  # odd H2
+    # out-of-range token ids are clamped to unk rather than faulting
+    v = L.loss(ctx, param, feats, np.full((2, 4), 1000, np.int32))
+    assert np.isfinite(v)
