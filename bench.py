@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py -- training images/sec of the LRCN step (VGG-16 -> fc7 forward + 2-layer LSTM fwd/bwd + Adam) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+Workload = BASELINE.json configs[3] / SURVEY.md 8(d) "C4": MS-COCO-shaped synthetic data, VGG-16 bf16 + LSTM
+E=H1=H2=1000 bf16 (fp32 accumulate / master weights / Adam), V=10640, T=11, GLOBAL batch 256 split by rows over the
+N ranks ("strong" scaling), dropout 0.4, one RCCL all-reduce(SUM) of the 39.8 M fp32 gradients per step.
+A step = [VGG fwd on B/N images] + lossgradient + all-reduce + update!; inputs (uint8 crops, tokens) resident in HBM.
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic work, SURVEY.md 8(d)
+VGG_CONV_GFLOP_PER_IMAGE = 30.693        # 13 conv layers
+CONV11_GFLOP_PER_IMAGE = 2 * 224 * 224 * 64 * 27 / 1e9   # conv1_1 runs as a separate (im2col GEMM) launch
+PEAK_BF16_TFLOPS = 2516.0                # MI355X dense bf16 MFMA (MI355X_MICROARCH.md: ~2.5 PF)
+PEAK_F32_TFLOPS = 157.3
+
+
+def cpu_baseline(vgg_w, E, H, V, T, rng):
+    """The oracle (kind "port": the reference is Julia/GPU-only and cannot run) timed on this box's host cores on a
+    bounded sample of the same workload: VGG forward on 4 images + lossgradient on 16 captions, float accumulation."""
+    import numpy as np
+    from oracle import oracle as orc
+    conv_w, conv_b, fc6, fc7 = vgg_w
+    n_img, n_cap = 4, 16
+    x = orc.preprocess_u8(rng.integers(0, 256, size=(n_img, 224, 224, 3), dtype=np.uint8), (123.68, 116.779, 103.939))
+    t0 = time.time()
+    orc.vgg_forward(conv_w, conv_b, fc6, fc7, x, fast=True)
+    t_vgg = (time.time() - t0) / n_img
+    m = orc.init_weights(E, H, H, V, seed=42)
+    feats = (rng.standard_normal((n_cap, 4096)) * 0.01).astype(np.float32)
+    tokens = rng.integers(3, V, size=(T, n_cap)).astype(np.int32)
+    t0 = time.time()
+    orc.loss(m, feats, tokens, want_grad=True, fast=True)
+    t_lstm = (time.time() - t0) / n_cap
+    return {"value": 1.0 / (t_vgg + t_lstm), "unit": "images/sec", "cores": orc.num_threads(), "kind": "port",
+            "sample": "oracle/lrcn_oracle.c (float accumulate, OpenMP): VGG-16 fwd on %d images (%.2f s/img) + LSTM "
+                      "lossgradient on %d captions of T=%d (%.3f s/caption); Adam excluded (<1%%)"
+                      % (n_img, t_vgg, n_cap, T, t_lstm)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--global-batch", type=int, default=256)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--hidden", type=int, default=1000)
+    ap.add_argument("--vocab", type=int, default=10640)
+    ap.add_argument("--T", type=int, default=11)
+    ap.add_argument("--pdrop", type=float, default=0.4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import lrcn_amd
+    from lrcn_amd import dp
+    from lrcn_amd import lrcn as L
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (a.gpus, a.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    dt = lrcn_amd.LRCN_BF16 if a.dtype == "bf16" else lrcn_amd.LRCN_F32
+    E = H = a.hidden
+    V, T, Bg = a.vocab, a.T, a.global_batch
+    rows = dp.shard_rows(Bg, world, rank)
+    B = rows.stop - rows.start
+
+    ctx = L.Context(E, H, H, V, max_B=B, max_T=T, lstm_dtype=dt, vgg_dtype=dt, max_images=B)
+    vgg_w = L.synthetic_vgg_weights(seed=1)
+    L.vgg_load(ctx, *vgg_w)
+    param = L.initweights(ctx, seed=42)          # identical on every rank (same seed)
+    optim = L.initparams(param)
+    trainer = dp.DataParallelTrainer(ctx, param, optim, Bg, world, rank, pdrop=a.pdrop, seed=7)
+
+    # synthetic inputs: uint8 crops uniform seed 1234; Zipf(1.0) word ids >= 3, seed 7; one T per batch
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1234)
+    n_sets = 2
+    imgs_all = [torch.randint(0, 256, (Bg, 224, 224, 3), generator=g, device="cuda", dtype=torch.uint8)[rows].contiguous()
+                for _ in range(n_sets)]
+    rng = np.random.default_rng(7)
+    pz = 1.0 / np.arange(1, V - 3 + 1)
+    pz /= pz.sum()
+    toks_all = [torch.as_tensor((rng.choice(V - 3, size=(T, Bg), p=pz) + 3).astype(np.int32)[:, rows.start:rows.stop]
+                                .copy()).cuda() for _ in range(n_sets)]
+
+    def run(nsteps, first_feats=None):
+        for k in range(nsteps):
+            nxt = imgs_all[(k + 1) % n_sets] if k + 1 < nsteps else None
+            trainer.step(imgs_all[k % n_sets], toks_all[k % n_sets], next_img_u8=nxt)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(a.warmup)
+    barrier()
+    _lib = lrcn_amd._lib
+    _lib.check(ctx._h, _lib.lib().lrcn_profile(ctx._h, 1))
+    t0 = time.perf_counter()
+    run(a.steps)
+    barrier()
+    dt_s = time.perf_counter() - t0
+    import ctypes as C
+    conv_ms, conv_n = C.c_double(), C.c_int64()
+    _lib.check(ctx._h, _lib.lib().lrcn_profile_get(ctx._h, C.byref(conv_ms), C.byref(conv_n)))
+    _lib.check(ctx._h, _lib.lib().lrcn_profile(ctx._h, 0))
+    loss = trainer.loss_value()
+    tt = torch.tensor([dt_s], device="cuda", dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt_s = float(tt.item())
+
+    if rank == 0:
+        ms_step = 1e3 * dt_s / a.steps
+        value = Bg * a.steps / dt_s
+        # dominant kernel: gemm_nt_kernel<T,128,128,CONV3> = the 12 implicit-GEMM convolutions conv1_2..conv5_3
+        flops_per_launch = (VGG_CONV_GFLOP_PER_IMAGE - CONV11_GFLOP_PER_IMAGE) * 1e9 * B / 12.0
+        avg_launch_s = conv_ms.value * 1e-3 / max(conv_n.value, 1)
+        achieved = flops_per_launch / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
+        peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
+        out = {
+            "metric": "training images/sec (VGG16+LSTM, COCO, batch 256) at 1/2/4/8 MI355X",
+            "value": value, "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[3] (C4): MS-COCO-shaped VGG-16 -> fc7 fwd + LRCN-2f LSTM "
+                                   "E=H=%d V=%d T=%d fwd/bwd + Adam, global batch %d, dp%d, dropout %.1f; synthetic uint8 "
+                                   "224x224 crops, He-normal VGG weights" % (H, V, T, Bg, world, a.pdrop),
+                       "global_batch": Bg, "per_gpu_batch": B, "seq_len": T + 1, "parallelism": "dp%d" % world,
+                       "last_loss": loss},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "traffic": None,
+                         "kernel": "gemm_nt_kernel<%s,128,128,CONV3> (conv1_2..conv5_3, 12 launches/step)" % a.dtype,
+                         "avg_launch_ms": 1e3 * avg_launch_s, "flops_per_launch": flops_per_launch},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            host_w = ([L.from_jl(w) for w in vgg_w[0]], [b.cpu().numpy() for b in vgg_w[1]],
+                      (L.from_jl(vgg_w[2][0]), vgg_w[2][1].cpu().numpy()), (L.from_jl(vgg_w[3][0]), vgg_w[3][1].cpu().numpy()))
+            out["cpu_baseline"] = cpu_baseline(host_w, E, H, V, T, np.random.default_rng(3))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

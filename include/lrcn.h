@@ -148,6 +148,13 @@ int lrcn_vgg_forward_u8(lrcn_ctx *ctx, const uint8_t *img, int N, const float me
 int lrcn_conv3x3(lrcn_ctx *ctx, const float *x, int W, int H, int Cin, int N, const float *w, const float *b,
                  int Cout, int relu, int pool, float *y);
 
+/* ---- measurement (bench.py "roofline") ----
+ * While enabled, every VGG forward brackets its 12 implicit-GEMM convolution launches (conv1_2..conv5_3: one kernel,
+ * gemm_nt_kernel<.,128,128,CONV3>, back to back on the context's stream) with a pair of HIP events.
+ * lrcn_profile_get synchronises and returns the accumulated milliseconds and launch count since lrcn_profile(ctx,1). */
+int lrcn_profile(lrcn_ctx *ctx, int enable);
+int lrcn_profile_get(lrcn_ctx *ctx, double *conv_ms, int64_t *conv_launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,6 +69,8 @@ SIGNATURES = {
     "lrcn_vgg_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "lrcn_preprocess_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_void_p]),
     "lrcn_vgg_forward_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_void_p]),
+    "lrcn_profile": (C.c_int, [C.c_void_p, C.c_int]),
+    "lrcn_profile_get": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "lrcn_conv3x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                C.c_int, C.c_int, C.c_int, C.c_void_p]),
 }
@@ -92,6 +94,9 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise LrcnError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                             "(there is no CPU fallback)" % LIB_PATH)
+        # torch ships its own libamdhip64; device pointers and streams are shared with it, so its HIP runtime must be
+        # the one this process uses: import torch BEFORE the library so the dynamic linker binds to that instance.
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the symbol is not exported

@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/lrcn.h"
@@ -71,6 +72,12 @@ struct lrcn_ctx {
     float *fc6b = nullptr, *fc7b = nullptr;
     void *actA = nullptr, *actB = nullptr, *im2col = nullptr, *f6 = nullptr;
     float *featsRM = nullptr;  // [N][4096] f32 row-major
+    // live timing of the dominant kernel (the 12 implicit-GEMM conv launches conv1_2..conv5_3), see lrcn_profile*
+    bool prof = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
+    size_t prof_used = 0;
+    double prof_ms = 0.0;
+    int64_t prof_launches = 0;
 };
 
 #define FAIL(ctx, code, ...)                          \
@@ -387,6 +394,10 @@ void lrcn_destroy(lrcn_ctx *c) {
     (void)hipSetDevice(c->cfg.device);
     (void)hipDeviceSynchronize();
     for (void *p : c->allocs) (void)hipFree(p);
+    for (auto &e : c->prof_ev) {
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
     delete c;
 }
 
@@ -808,11 +819,23 @@ int vgg_body(lrcn_ctx *c, int N) {
         if (e != hipSuccess) FAIL(c, LRCN_EHIP, "conv1_1: %s", hipGetErrorString(e));
     }
     void *cur = c->actA, *nxt = c->actB;
+    std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
+    if (c->prof) {
+        if (c->prof_used == c->prof_ev.size()) {
+            std::pair<hipEvent_t, hipEvent_t> e;
+            HIPCHK(c, hipEventCreate(&e.first));
+            HIPCHK(c, hipEventCreate(&e.second));
+            c->prof_ev.push_back(e);
+        }
+        ev = &c->prof_ev[c->prof_used++];
+        HIPCHK(c, hipEventRecord(ev->first, c->stream));
+    }
     for (int l = 1; l < 13; ++l) {
         int r = conv_layer(c, vdt, cur, c->conv[l], N, nxt);
         if (r) return r;
         std::swap(cur, nxt);
     }
+    if (ev) HIPCHK(c, hipEventRecord(ev->second, c->stream));
     // cur = pool5 output [N][7*7*512]; fc6 + relu6; fc7 (no relu7: lrcn.jl:717)
     GemmArgs g{};
     g.dtype = vdt;
@@ -848,6 +871,30 @@ int vgg_check(lrcn_ctx *c, int N) {
     return LRCN_OK;
 }
 }  // namespace
+
+int lrcn_profile(lrcn_ctx *c, int enable) {
+    if (!c) return LRCN_EINVAL;
+    c->prof = enable != 0;
+    c->prof_used = 0;
+    c->prof_ms = 0.0;
+    c->prof_launches = 0;
+    return LRCN_OK;
+}
+
+int lrcn_profile_get(lrcn_ctx *c, double *conv_ms, int64_t *conv_launches) {
+    if (!c || !conv_ms || !conv_launches) return LRCN_EINVAL;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < c->prof_used; ++i) {
+        float ms = 0.0f;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->prof_ev[i].first, c->prof_ev[i].second));
+        c->prof_ms += ms;
+        c->prof_launches += 12;
+    }
+    c->prof_used = 0;
+    *conv_ms = c->prof_ms;
+    *conv_launches = c->prof_launches;
+    return LRCN_OK;
+}
 
 int lrcn_vgg_forward(lrcn_ctx *c, const float *x, int N, float *feats) {
     if (!c || !x || !feats) return LRCN_EINVAL;
