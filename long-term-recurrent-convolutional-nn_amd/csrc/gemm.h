@@ -23,8 +23,14 @@ struct GemmArgs {
     int relu;
     int a_mode, out_mode;
     int H, W, Cin;  // conv geometry (square-agnostic; H, W even)
+    const void *zero_page;  // >= 256 zero bytes, 16-byte aligned (source of padding rows for the direct-to-LDS path) or NULL
 };
 
 // Requirements (checked): A/B base 16-byte aligned, lda/ldb multiples of the 16-byte chunk (4 f32 / 8 bf16),
 // CONV3: Cin a multiple of 32 (f32) / 64 (bf16).  Returns hipSuccess or an error; never faults on bad shapes.
 hipError_t launch_gemm(hipStream_t stream, const GemmArgs &g);
+
+// bf16 direct-to-LDS variant (gemm_glds.hip): 256-row tiles, global_load_lds staging, XOR-swizzled LDS.
+// launch_gemm routes to it when gemm_glds_eligible(g) and the grid is large enough to fill the chip.
+bool gemm_glds_eligible(const GemmArgs &g);
+hipError_t launch_gemm_glds(hipStream_t stream, const GemmArgs &g);

@@ -17,6 +17,8 @@
 // at lrcn.jl:724-726, fcx at lrcn.jl:728.
 #include "gemm.h"
 
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -269,6 +271,13 @@ template <typename T> hipError_t dispatch(hipStream_t s, const GemmArgs &g) {
 
 hipError_t launch_gemm(hipStream_t stream, const GemmArgs &g) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0 || !g.A || !g.B || !g.C) return hipErrorInvalidValue;
+    // LRCN_GLDS=0 disables the direct-to-LDS path, LRCN_GLDS=force uses it whenever eligible (tests); default: when
+    // the grid fills the chip.
+    const char *knob = getenv("LRCN_GLDS");
+    if (!(knob && knob[0] == '0') && gemm_glds_eligible(g)) {
+        const int bn = g.N <= 64 ? 64 : (g.N <= 128 ? 128 : 256);
+        if ((knob && knob[0] == 'f') || (int64_t)cdiv(g.M, 256) * cdiv(g.N, bn) >= 128) return launch_gemm_glds(stream, g);
+    }
     const int ce = g.dtype == GEMM_T_BF16 ? 8 : 4;
     if (((uintptr_t)g.A & 15) || ((uintptr_t)g.B & 15) || (g.ldb % ce)) return hipErrorInvalidValue;
     if (g.a_mode == GEMM_A_CONV3) {

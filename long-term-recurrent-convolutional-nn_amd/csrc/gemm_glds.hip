@@ -1,0 +1,261 @@
+// gemm_glds.hip -- the bf16 NT contraction / implicit-GEMM 3x3 convolution with direct-to-LDS staging (gfx950).
+//
+// Same math and epilogues as gemm.hip, restructured for the CDNA4 memory path (cdna guide section 5):
+//   * both operand tiles are staged HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR round trip, no ds_write);
+//     the per-lane SOURCE address makes the A tile a row gather, so the im2col row of a 3x3/pad-1 convolution is
+//     formed by the DMA itself: lane -> (row, 16-byte chunk), source = centre pixel + tap offset + channel slice,
+//     or a 256-byte zero page when the tap falls outside the image / the row is beyond M;
+//   * LDS rows are 128 bytes (64 bf16 of K) with NO padding (the DMA writes lane-linear 1 KiB pieces); bank conflicts
+//     are removed by an XOR swizzle applied on the source chunk index and again on the ds_read_b128 address:
+//     logical chunk j of row r lives at chunk position j ^ ((r >> 1) & 7)   (conflict-free for every 16-lane group);
+//   * 256-row tiles, 8 waves (2 per SIMD), 2 LDS buffers: the DMA of K-step t+1 is in flight while the MFMAs of K-step
+//     t run; one barrier per K-step;
+//   * workgroups are renumbered so that the N-tiles sharing one im2col panel run on the same XCD (same L2).
+// MFMA: v_mfma_f32_32x32x16_bf16; rows in window-major pixel order so 2x2 max-pool = max of 4 accumulator registers.
+#include "common.h"
+#include "gemm.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+template <int WM, int WN, int TM, int TN, int AMODE>
+__global__ __launch_bounds__(512) void gemm_glds_kernel(const GemmArgs g) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    static_assert(BM == 256 && WM * WN == 8, "8 waves, 256-row tiles");
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF = A_BYTES + B_BYTES;
+    constexpr int BQ = BN / 64;  // B staging instructions per wave per K-step
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int M = g.M, N = g.N;
+    const int tiles_n = (N + BN - 1) / BN;
+    // XCD-aware renumbering (bijective form, cdna guide T1): blocks b, b+8, ... share an XCD; give each XCD a contiguous
+    // run of logical tiles so the N-tiles of one M-panel (consecutive logical ids) hit the same L2.
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int nt = bid % tiles_n, mt = bid / tiles_n;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    const bf16_t *Ab = reinterpret_cast<const bf16_t *>(g.A);
+    const bf16_t *Bb = reinterpret_cast<const bf16_t *>(g.B);
+    const bf16_t *Zp = reinterpret_cast<const bf16_t *>(g.zero_page) + (lane & 7) * 8;
+
+    const int kpt = (AMODE == GEMM_A_CONV3) ? g.Cin / 64 : g.K / 64;
+    const int KT = (AMODE == GEMM_A_CONV3) ? 9 * kpt : kpt;
+
+    // ---- per-lane staging state ----
+    // A: wave w, instruction q stages rows w*32 + q*8 + (lane>>3), chunk position lane&7
+    int a_off[4];
+    unsigned a_mask[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = wave * 32 + q * 8 + (lane >> 3);
+        const int m = m0 + row;
+        const int src_chunk = (lane & 7) ^ ((row >> 1) & 7);
+        a_off[q] = 0;
+        a_mask[q] = 0;
+        if (m < M) {
+            if (AMODE == GEMM_A_CONV3) {
+                const PixDecode p = decode_pixel(m, g.H, g.W);
+                a_off[q] = ((p.n * g.H + p.y) * g.W + p.x) * g.Cin + src_chunk * 8;
+                unsigned mk = 0;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int y = p.y + t / 3 - 1, x = p.x + t % 3 - 1;
+                    if ((unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W) mk |= 1u << t;
+                }
+                a_mask[q] = mk;
+            } else {
+                a_off[q] = m * (int)g.lda + src_chunk * 8;
+                a_mask[q] = 1;
+            }
+        }
+    }
+    // B: instruction j = wave + 8*i stages rows j*8 + (lane>>3)
+    int b_off[BQ];
+    bool b_ok[BQ];
+#pragma unroll
+    for (int i = 0; i < BQ; ++i) {
+        const int row = (wave + 8 * i) * 8 + (lane >> 3);
+        const int n = n0 + row;
+        const int src_chunk = (lane & 7) ^ ((row >> 1) & 7);
+        b_ok[i] = n < N;
+        b_off[i] = b_ok[i] ? n * (int)g.ldb + src_chunk * 8 : 0;
+    }
+
+    auto stage = [&](int buf, int kt) {
+        unsigned char *As = smem + buf * BUF;
+        unsigned char *Bs = As + A_BYTES;
+        int tap = 0, koff;
+        if (AMODE == GEMM_A_CONV3) {
+            tap = kt / kpt;
+            const int kh = tap / 3, kw = tap - 3 * kh;
+            koff = ((kh - 1) * g.W + (kw - 1)) * g.Cin + (kt - tap * kpt) * 64;
+        } else {
+            koff = kt * 64;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool ok = (a_mask[q] >> tap) & 1u;
+            const bf16_t *src = ok ? Ab + (a_off[q] + koff) : Zp;
+            __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(As + (wave * 32 + q * 8) * 128), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < BQ; ++i) {
+            const bf16_t *src = b_ok[i] ? Bb + (b_off[i] + kt * 64) : Zp;
+            __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(Bs + (wave + 8 * i) * 8 * 128), 16, 0, 0);
+        }
+    };
+
+    // fragment read offsets: lane (r = lane&31, hh = lane>>5) reads logical chunks 4hh..4hh+3 of its row
+    int fo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fo[j] = (lane & 31) * 128 + ((((lane >> 5) * 4 + j) ^ (((lane & 31) >> 1) & 7)) << 4);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < KT; ++kt) {
+        if (kt + 1 < KT) stage(cur ^ 1, kt + 1);
+        const unsigned char *As = smem + cur * BUF + (wm * TM * 32) * 128;
+        const unsigned char *Bs = smem + cur * BUF + A_BYTES + (wn * TN * 32) * 128;
+        uint4 bfr[TN][4];
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[n][j] = *reinterpret_cast<const uint4 *>(Bs + n * 32 * 128 + fo[j]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            uint4 af[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) af[j] = *reinterpret_cast<const uint4 *>(As + i * 32 * 128 + fo[j]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+                    acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[j]),
+                                                                        __builtin_bit_cast(bf16x8, bfr[n][j]), acc[i][n], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue (C layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) ----
+    const int hh = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+            const int col = n0 + (wn * TN + n) * 32 + (lane & 31);
+            if (col >= N) continue;
+            const float bias = g.bias ? g.bias[col] : 0.0f;
+            const int rbase = m0 + (wm * TM + i) * 32 + 4 * hh;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = rbase + 8 * q;  // 4 consecutive rows row..row+3 = one 2x2 pool window
+                if (row >= M) continue;
+                if (g.out_mode == GEMM_OUT_POOL) {
+                    float v = fmaxf(fmaxf(acc[i][n][4 * q], acc[i][n][4 * q + 1]),
+                                    fmaxf(acc[i][n][4 * q + 2], acc[i][n][4 * q + 3])) + bias;
+                    if (g.relu) v = fmaxf(v, 0.0f);
+                    const int64_t off = (int64_t)(row >> 2) * g.ldc + col;
+                    if (g.c_f32)
+                        reinterpret_cast<float *>(g.C)[off] = v;
+                    else
+                        reinterpret_cast<bf16_t *>(g.C)[off] = (bf16_t)v;
+                    continue;
+                }
+                int64_t off0, dstep_x, dstep_y;
+                if (g.out_mode == GEMM_OUT_CONV) {
+                    const PixDecode p = decode_pixel(row, g.H, g.W);  // sub-pixel 0 of the window
+                    off0 = (((int64_t)p.n * g.H + p.y) * g.W + p.x) * g.ldc + col;
+                    dstep_x = g.ldc;
+                    dstep_y = (int64_t)g.W * g.ldc;
+                } else {
+                    off0 = (int64_t)row * g.ldc + col;
+                    dstep_x = g.ldc;
+                    dstep_y = 2 * g.ldc;
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    if (row + s >= M) continue;
+                    const int64_t off = off0 + (s & 1) * dstep_x + (s >> 1) * dstep_y;
+                    float v = acc[i][n][4 * q + s] + bias;
+                    if (g.c_f32) {
+                        float *c = reinterpret_cast<float *>(g.C) + off;
+                        if (g.beta) v += *c;
+                        if (g.relu) v = fmaxf(v, 0.0f);
+                        *c = v;
+                    } else {
+                        bf16_t *c = reinterpret_cast<bf16_t *>(g.C) + off;
+                        if (g.beta) v += (float)*c;
+                        if (g.relu) v = fmaxf(v, 0.0f);
+                        *c = (bf16_t)v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int WM, int WN, int TM, int TN, int AMODE> hipError_t launch_one(hipStream_t s, const GemmArgs &g) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int lds = 2 * (BM + BN) * 128;
+    static bool attr_done = false;
+    auto kern = gemm_glds_kernel<WM, WN, TM, TN, AMODE>;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    const int64_t blocks = (int64_t)cdiv(g.M, BM) * cdiv(g.N, BN);
+    if (blocks <= 0 || blocks > 0x7FFFFFFF) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, s, g);
+    return hipGetLastError();
+}
+
+template <int AMODE> hipError_t dispatch(hipStream_t s, const GemmArgs &g) {
+    if (g.N <= 64) return launch_one<4, 2, 2, 1, AMODE>(s, g);   // 256 x 64
+    if (g.N <= 128) return launch_one<4, 2, 2, 2, AMODE>(s, g);  // 256 x 128
+    return launch_one<2, 4, 4, 2, AMODE>(s, g);                  // 256 x 256
+}
+
+}  // namespace
+
+bool gemm_glds_eligible(const GemmArgs &g) {
+    if (g.dtype != GEMM_T_BF16 || !g.zero_page || g.M < 256) return false;
+    if (((uintptr_t)g.A & 15) || ((uintptr_t)g.B & 15) || (g.ldb % 8)) return false;
+    if ((int64_t)g.N * g.ldb >= (1ll << 31)) return false;
+    if (g.a_mode == GEMM_A_CONV3) {
+        if (g.Cin % 64 || g.K != 9 * g.Cin || (g.H & 1) || (g.W & 1) || g.M % (g.H * g.W)) return false;
+        if ((int64_t)g.M * g.Cin >= (1ll << 31)) return false;
+    } else {
+        if (g.K % 64 || g.lda % 8) return false;
+        if ((int64_t)g.M * g.lda >= (1ll << 31)) return false;
+    }
+    if (g.out_mode != GEMM_OUT_PLAIN && ((g.H & 1) || (g.W & 1) || g.H <= 0 || g.W <= 0)) return false;
+    if (g.out_mode == GEMM_OUT_POOL && (g.beta || (g.M & 3))) return false;
+    return true;
+}
+
+hipError_t launch_gemm_glds(hipStream_t stream, const GemmArgs &g) {
+    if (!gemm_glds_eligible(g)) return hipErrorInvalidValue;
+    return g.a_mode == GEMM_A_CONV3 ? dispatch<GEMM_A_CONV3>(stream, g) : dispatch<GEMM_A_PLAIN>(stream, g);
+}

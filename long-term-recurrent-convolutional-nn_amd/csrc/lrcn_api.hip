@@ -58,6 +58,7 @@ struct lrcn_ctx {
     void *TA = nullptr, *TB = nullptr;  // transposed-operand scratch: up to [max(4H,V)][ldM] and [max(E,H,4096)][ldM]
     void *dxcT = nullptr;
     double *logp = nullptr;
+    void *zero_page = nullptr;
     int last_norm = 1, last_S = 1;
     // single-step scratch (lrcn_lstm / lrcn_step / beam search), row-major
     float *st_f32[4] = {nullptr, nullptr, nullptr, nullptr};   // h1,c1,h2,c2 [B][H]
@@ -144,6 +145,7 @@ int gemm(lrcn_ctx *c, int dtype, const void *A, int64_t lda, const void *B, int6
     g.relu = relu;
     g.a_mode = GEMM_A_PLAIN;
     g.out_mode = GEMM_OUT_PLAIN;
+    g.zero_page = c->zero_page;
     hipError_t e = launch_gemm(c->stream, g);
     if (e != hipSuccess) FAIL(c, LRCN_EHIP, "gemm M=%d N=%d K=%d: %s", M, N, K, hipGetErrorString(e));
     return LRCN_OK;
@@ -467,6 +469,8 @@ int lrcn_create(const lrcn_config *cfg, lrcn_ctx **out) {
         int64_t rb = Hm; if (E > rb) rb = E;
         DALLOC(c, c->TA, es * ra * c->ldM);        DALLOC(c, c->TB, es * rb * c->ldM);
         DALLOC(c, c->logp, sizeof(double) * 2);
+        DALLOC(c, c->zero_page, 256);
+        if (hipMemset(c->zero_page, 0, 256) != hipSuccess) return LRCN_EHIP;
         for (int i = 0; i < 4; ++i) {
             DALLOC(c, c->st_f32[i], sizeof(float) * B * Hm);
             DALLOC(c, c->st2_f32[i], sizeof(float) * B * Hm);
@@ -789,6 +793,7 @@ int conv_layer(lrcn_ctx *c, int dtype, const void *in, const VggLayer &L, int N,
     g.out_mode = L.pool ? GEMM_OUT_POOL : GEMM_OUT_CONV;
     g.H = g.W = L.S;
     g.Cin = L.Cin;
+    g.zero_page = c->zero_page;
     hipError_t e = launch_gemm(c->stream, g);
     if (e != hipSuccess) FAIL(c, LRCN_EHIP, "conv layer S=%d Cin=%d Cout=%d: %s", L.S, L.Cin, L.Cout, hipGetErrorString(e));
     return LRCN_OK;
@@ -815,6 +820,7 @@ int vgg_body(lrcn_ctx *c, int N) {
         g.a_mode = GEMM_A_PLAIN;
         g.out_mode = GEMM_OUT_CONV;
         g.H = g.W = 224;
+        g.zero_page = c->zero_page;
         hipError_t e = launch_gemm(c->stream, g);
         if (e != hipSuccess) FAIL(c, LRCN_EHIP, "conv1_1: %s", hipGetErrorString(e));
     }
@@ -850,6 +856,7 @@ int vgg_body(lrcn_ctx *c, int N) {
     g.K = 25088;
     g.bias = c->fc6b;
     g.relu = 1;
+    g.zero_page = c->zero_page;
     hipError_t e = launch_gemm(c->stream, g);
     if (e != hipSuccess) FAIL(c, LRCN_EHIP, "fc6: %s", hipGetErrorString(e));
     g.A = c->f6;
@@ -970,6 +977,7 @@ int lrcn_conv3x3(lrcn_ctx *c, const float *x, int W, int H, int Cin, int N, cons
     g.H = H;
     g.W = W;
     g.Cin = Cp;
+    g.zero_page = c->zero_page;
     hipError_t e = launch_gemm(c->stream, g);
     if (e == hipSuccess) {
         k_nhwc_to_ref(c->stream, vdt, out, Wo, Ho, Cout, N, Cout, y);

@@ -32,9 +32,13 @@ def test_conv_pool_vs_golden_fp32(golden_dir):
     np.testing.assert_allclose(yp, z["yp"], rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("glds", ["0", "force"])
 @pytest.mark.parametrize("dtype,tol", [(lrcn_amd.LRCN_F32, 1e-5), (lrcn_amd.LRCN_BF16, 2e-2)])
-@pytest.mark.parametrize("shape", [(28, 64, 128, 3), (14, 128, 64, 5), (8, 96, 40, 2), (2, 32, 32, 1)])
-def test_conv_layers_vs_oracle(dtype, tol, shape):
+@pytest.mark.parametrize("shape", [(28, 64, 128, 3), (14, 128, 64, 5), (8, 96, 40, 2), (2, 32, 32, 1), (16, 64, 320, 3),
+                                   (12, 192, 64, 2)])
+def test_conv_layers_vs_oracle(dtype, tol, shape, glds, monkeypatch):
+    # glds: the bf16 direct-to-LDS kernel (gemm_glds.hip) forced on / off; both must agree with the oracle
+    monkeypatch.setenv("LRCN_GLDS", glds)
     S, Cin, Cout, N = shape
     rng = np.random.default_rng(S * 1000 + Cin)
     x = rng.standard_normal((S, S, Cin, N)).astype(np.float32)
