@@ -34,3 +34,4 @@ hipError_t launch_gemm(hipStream_t stream, const GemmArgs &g);
 // launch_gemm routes to it when gemm_glds_eligible(g) and the grid is large enough to fill the chip.
 bool gemm_glds_eligible(const GemmArgs &g);
 hipError_t launch_gemm_glds(hipStream_t stream, const GemmArgs &g);
+int64_t gemm_glds_blocks(const GemmArgs &g);  // workgroups the direct-to-LDS path would launch (0 = no config fits)

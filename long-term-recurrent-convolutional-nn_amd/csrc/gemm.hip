@@ -275,8 +275,8 @@ hipError_t launch_gemm(hipStream_t stream, const GemmArgs &g) {
     // the grid fills the chip.
     const char *knob = getenv("LRCN_GLDS");
     if (!(knob && knob[0] == '0') && gemm_glds_eligible(g)) {
-        const int bn = g.N <= 64 ? 64 : (g.N <= 128 ? 128 : 256);
-        if ((knob && knob[0] == 'f') || (int64_t)cdiv(g.M, 256) * cdiv(g.N, bn) >= 128) return launch_gemm_glds(stream, g);
+        const int64_t blocks = gemm_glds_blocks(g);
+        if (blocks > 0 && ((knob && knob[0] == 'f') || blocks >= 96)) return launch_gemm_glds(stream, g);
     }
     const int ce = g.dtype == GEMM_T_BF16 ? 8 : 4;
     if (((uintptr_t)g.A & 15) || ((uintptr_t)g.B & 15) || (g.ldb % ce)) return hipErrorInvalidValue;

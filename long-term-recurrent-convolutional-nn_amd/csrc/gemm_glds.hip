@@ -20,12 +20,18 @@ namespace {
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
-template <int WM, int WN, int TM, int TN, int AMODE>
-__global__ __launch_bounds__(512) void gemm_glds_kernel(const GemmArgs g) {
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int WM, int WN, int TM, int TN, int AMODE, int NBUF>
+__global__ __launch_bounds__(WM *WN * 64) void gemm_glds_kernel(const GemmArgs g) {
+    constexpr int NW = WM * WN;  // waves per workgroup (4 or 8); each wave stages 32 A rows, so BM = 32 NW
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    static_assert(BM == 256 && WM * WN == 8, "8 waves, 256-row tiles");
+    static_assert(BM == NW * 32 && (NW == 8 || NW == 4), "each wave stages 32 rows of A");
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF = A_BYTES + B_BYTES;
-    constexpr int BQ = BN / 64;  // B staging instructions per wave per K-step
+    constexpr int BQ = BN / (8 * NW);  // B staging instructions per wave per K-step
+    static_assert(BQ >= 1 && BQ * 8 * NW == BN, "B tile must split evenly over the waves");
+    constexpr int IPT = 4 + BQ;        // DMA instructions per wave per K-step
+    static_assert((NBUF - 2) * IPT <= 48, "vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -48,7 +54,10 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(const GemmArgs g) {
     const bf16_t *Zp = reinterpret_cast<const bf16_t *>(g.zero_page) + (lane & 7) * 8;
 
     const int kpt = (AMODE == GEMM_A_CONV3) ? g.Cin / 64 : g.K / 64;
-    const int KT = (AMODE == GEMM_A_CONV3) ? 9 * kpt : kpt;
+    const int KT_all = (AMODE == GEMM_A_CONV3) ? 9 * kpt : kpt;
+    // split-K: blockIdx.y owns K-steps [kbeg, kbeg + KT); partial sums are combined by f32 atomics in the epilogue
+    const int kbeg = (int)((int64_t)KT_all * blockIdx.y / gridDim.y);
+    const int KT = (int)((int64_t)KT_all * (blockIdx.y + 1) / gridDim.y) - kbeg;
 
     // ---- per-lane staging state ----
     // A: wave w, instruction q stages rows w*32 + q*8 + (lane>>3), chunk position lane&7
@@ -83,7 +92,7 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(const GemmArgs g) {
     bool b_ok[BQ];
 #pragma unroll
     for (int i = 0; i < BQ; ++i) {
-        const int row = (wave + 8 * i) * 8 + (lane >> 3);
+        const int row = (wave + NW * i) * 8 + (lane >> 3);
         const int n = n0 + row;
         const int src_chunk = (lane & 7) ^ ((row >> 1) & 7);
         b_ok[i] = n < N;
@@ -110,7 +119,7 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(const GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < BQ; ++i) {
             const bf16_t *src = b_ok[i] ? Bb + (b_off[i] + kt * 64) : Zp;
-            __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(Bs + (wave + 8 * i) * 8 * 128), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(Bs + (wave + NW * i) * 8 * 128), 16, 0, 0);
         }
     };
 
@@ -127,12 +136,20 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(const GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int cur = 0;
+    // NBUF-deep ring: the DMA of K-steps kt+1 .. kt+NBUF-1 is in flight while K-step kt is multiplied.  A K-step's
+    // data is ordered for every wave's ds_read by: each wave's counted vmcnt for its own pieces, then the barrier.
+    // (raw s_barrier: __syncthreads() would drain vmcnt to 0 -- cdna guide "Pipelining across barriers")
+#pragma unroll
+    for (int t = 0; t < NBUF - 1; ++t)
+        if (t < KT) stage(t, kbeg + t);
     for (int kt = 0; kt < KT; ++kt) {
-        if (kt + 1 < KT) stage(cur ^ 1, kt + 1);
+        if (kt + NBUF - 2 < KT)
+            wait_vmcnt<(NBUF - 2) * IPT>();
+        else
+            wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + NBUF - 1 < KT) stage((kt + NBUF - 1) % NBUF, kbeg + kt + NBUF - 1);
+        const int cur = kt % NBUF;
         const unsigned char *As = smem + cur * BUF + (wm * TM * 32) * 128;
         const unsigned char *Bs = smem + cur * BUF + A_BYTES + (wn * TN * 32) * 128;
         uint4 bfr[TN][4];
@@ -152,9 +169,6 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(const GemmArgs g) {
                     acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[j]),
                                                                         __builtin_bit_cast(bf16x8, bfr[n][j]), acc[i][n], 0, 0, 0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        cur ^= 1;
     }
 
     // ---- epilogue (C layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) ----
@@ -165,7 +179,7 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(const GemmArgs g) {
         for (int n = 0; n < TN; ++n) {
             const int col = n0 + (wn * TN + n) * 32 + (lane & 31);
             if (col >= N) continue;
-            const float bias = g.bias ? g.bias[col] : 0.0f;
+            const float bias = (g.bias && blockIdx.y == 0) ? g.bias[col] : 0.0f;
             const int rbase = m0 + (wm * TM + i) * 32 + 4 * hh;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -198,7 +212,9 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(const GemmArgs g) {
                     if (row + s >= M) continue;
                     const int64_t off = off0 + (s & 1) * dstep_x + (s >> 1) * dstep_y;
                     float v = acc[i][n][4 * q + s] + bias;
-                    if (g.c_f32) {
+                    if (gridDim.y > 1) {  // split-K (launcher guarantees c_f32, PLAIN, no relu, C pre-zeroed unless beta)
+                        atomicAdd(reinterpret_cast<float *>(g.C) + off, v);
+                    } else if (g.c_f32) {
                         float *c = reinterpret_cast<float *>(g.C) + off;
                         if (g.beta) v += *c;
                         if (g.relu) v = fmaxf(v, 0.0f);
@@ -215,11 +231,12 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(const GemmArgs g) {
     }
 }
 
-template <int WM, int WN, int TM, int TN, int AMODE> hipError_t launch_one(hipStream_t s, const GemmArgs &g) {
+template <int WM, int WN, int TM, int TN, int AMODE, int NBUF> hipError_t launch_one(hipStream_t s, const GemmArgs &g, int splitk) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int lds = 2 * (BM + BN) * 128;
+    constexpr int lds = NBUF * (BM + BN) * 128;
+    static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_done = false;
-    auto kern = gemm_glds_kernel<WM, WN, TM, TN, AMODE>;
+    auto kern = gemm_glds_kernel<WM, WN, TM, TN, AMODE, NBUF>;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
@@ -227,20 +244,69 @@ template <int WM, int WN, int TM, int TN, int AMODE> hipError_t launch_one(hipSt
     }
     const int64_t blocks = (int64_t)cdiv(g.M, BM) * cdiv(g.N, BN);
     if (blocks <= 0 || blocks > 0x7FFFFFFF) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, s, g);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)splitk), dim3(WM * WN * 64), lds, s, g);
     return hipGetLastError();
 }
 
+// Tile choice: the largest tile that still gives the chip >= 2 workgroups' worth of parallelism per 2 CUs (>= 200 blocks),
+// else the candidate with the most blocks.  Returns the block count of the chosen config (0 = none fits).
+struct Cfg {
+    int bm, bn;
+};
+const Cfg kCfgs[4] = {{256, 256}, {256, 128}, {256, 64}, {128, 64}};
+int choose_cfg(const GemmArgs &g, int64_t *blocks_out) {
+    int best = -1;
+    int64_t best_blocks = 0;
+    for (int i = 0; i < 4; ++i) {
+        if (g.M < kCfgs[i].bm) continue;
+        if (kCfgs[i].bn > 64 && g.N <= kCfgs[i].bn / 2) continue;  // do not waste more than half a tile of columns
+        const int64_t b = (int64_t)cdiv(g.M, kCfgs[i].bm) * cdiv(g.N, kCfgs[i].bn);
+        if (b >= 200) {
+            *blocks_out = b;
+            return i;
+        }
+        if (b > best_blocks) {
+            best_blocks = b;
+            best = i;
+        }
+    }
+    *blocks_out = best_blocks;
+    return best;
+}
+
+// Split-K for skinny problems (few output tiles, long K): enough slices to give every CU a workgroup, each slice at
+// least 4 K-steps.  Needs an f32 PLAIN output without ReLU; C is zeroed first unless the call accumulates (beta).
+int choose_splitk(const GemmArgs &g, int64_t blocks) {
+    if (!g.c_f32 || g.out_mode != GEMM_OUT_PLAIN || g.relu || g.a_mode != GEMM_A_PLAIN) return 1;
+    if (!g.beta && g.ldc != g.N) return 1;
+    const int kt = g.K / 64;
+    int s = (int)(256 / (blocks > 0 ? blocks : 1));
+    if (s > kt / 4) s = kt / 4;
+    if (s > 16) s = 16;
+    return s < 2 ? 1 : s;
+}
+
 template <int AMODE> hipError_t dispatch(hipStream_t s, const GemmArgs &g) {
-    if (g.N <= 64) return launch_one<4, 2, 2, 1, AMODE>(s, g);   // 256 x 64
-    if (g.N <= 128) return launch_one<4, 2, 2, 2, AMODE>(s, g);  // 256 x 128
-    return launch_one<2, 4, 4, 2, AMODE>(s, g);                  // 256 x 256
+    int64_t blocks = 0;
+    const int cfg = choose_cfg(g, &blocks);
+    const int sk = (AMODE == GEMM_A_PLAIN) ? choose_splitk(g, blocks) : 1;
+    if (sk > 1 && !g.beta) {
+        hipError_t e = hipMemsetAsync(g.C, 0, sizeof(float) * (size_t)g.M * g.N, s);
+        if (e != hipSuccess) return e;
+    }
+    switch (cfg) {
+        case 0: return launch_one<2, 4, 4, 2, AMODE, 2>(s, g, sk);  // 256 x 256, 2 x 64 KiB
+        case 1: return launch_one<4, 2, 2, 2, AMODE, 3>(s, g, sk);  // 256 x 128, 3 x 48 KiB
+        case 2: return launch_one<4, 2, 2, 1, AMODE, 2>(s, g, sk);  // 256 x 64,  2 x 40 KiB (two workgroups per CU)
+        case 3: return launch_one<2, 2, 2, 1, AMODE, 3>(s, g, sk);  // 128 x 64 (4 waves), 3 x 24 KiB (two per CU)
+        default: return hipErrorInvalidValue;
+    }
 }
 
 }  // namespace
 
 bool gemm_glds_eligible(const GemmArgs &g) {
-    if (g.dtype != GEMM_T_BF16 || !g.zero_page || g.M < 256) return false;
+    if (g.dtype != GEMM_T_BF16 || !g.zero_page || g.M < 128) return false;
     if (((uintptr_t)g.A & 15) || ((uintptr_t)g.B & 15) || (g.ldb % 8)) return false;
     if ((int64_t)g.N * g.ldb >= (1ll << 31)) return false;
     if (g.a_mode == GEMM_A_CONV3) {
@@ -258,4 +324,10 @@ bool gemm_glds_eligible(const GemmArgs &g) {
 hipError_t launch_gemm_glds(hipStream_t stream, const GemmArgs &g) {
     if (!gemm_glds_eligible(g)) return hipErrorInvalidValue;
     return g.a_mode == GEMM_A_CONV3 ? dispatch<GEMM_A_CONV3>(stream, g) : dispatch<GEMM_A_PLAIN>(stream, g);
+}
+
+int64_t gemm_glds_blocks(const GemmArgs &g) {
+    int64_t b = 0;
+    if (choose_cfg(g, &b) < 0) return 0;
+    return b * choose_splitk(g, b);
 }

@@ -98,3 +98,7 @@ void k_topk_rows(hipStream_t st, const float *prob, int64_t ld, int R, int V, in
 void k_gather_rows_f32(hipStream_t st, const float *in, int64_t ld, const int32_t *src_row, int R, int C, float *out);
 // out[i] = a[i] * b[i]
 void k_mul_f32(hipStream_t st, const float *a, const float *b, int64_t n, float *out);
+// conv1_1 + preprocessing fused, bf16 (conv11.hip): src = uint8 crops img[n][row][col][3] or float (S,S,3,N);
+// w [64][32] bf16 (k = tap*3+c), out NHWC bf16 [n][y][x][64] with bias + ReLU.
+void k_conv11_fused(hipStream_t st, int src_is_u8, const void *src, int N, int S, float m0, float m1, float m2, const void *w,
+                    const float *bias, void *out);

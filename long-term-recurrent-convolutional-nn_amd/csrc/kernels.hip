@@ -233,6 +233,13 @@ __global__ void transpose_kernel(const Tin *in, int64_t ld_in, int R, int C, Tou
                 for (int r = tx; r < shift; r += 32) out[(int64_t)c * ld_out + r] = from_f32<Tout>(0.0f);
         }
     }
+    if (blockIdx.y == gridDim.y - 1) {  // zero the K-padding [R + shift, ld_out) of every output row
+        for (int i = ty; i < 32; i += 8) {
+            const int c = c0 + i;
+            if (c < C)
+                for (int r = R + shift + tx; r < ld_out; r += 32) out[(int64_t)c * ld_out + r] = from_f32<Tout>(0.0f);
+        }
+    }
 }
 
 template <typename T>
@@ -249,15 +256,16 @@ __global__ void uncast_rows_kernel(const T *in, int64_t ld_in, int R, int C, flo
 }
 
 template <typename T> __global__ void colsum_kernel(const T *z, int64_t ld, int M, int N, float *out) {
-    // block = 64 columns x 4 row groups
+    // block = 64 columns x 4 row groups over a 256-row slab (blockIdx.y); slabs are combined with f32 atomics (out zeroed)
     __shared__ float sh[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    const int m1 = min(M, (int)(blockIdx.y + 1) * 256);
     float acc = 0.0f;
     if (c < N)
-        for (int m = rg; m < M; m += 4) acc += to_f32(z[(int64_t)m * ld + c]);
+        for (int m = blockIdx.y * 256 + rg; m < m1; m += 4) acc += to_f32(z[(int64_t)m * ld + c]);
     sh[rg][threadIdx.x & 63] = acc;
     __syncthreads();
-    if (rg == 0 && c < N) out[c] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+    if (rg == 0 && c < N) atomicAdd(out + c, sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]);
 }
 
 __global__ void adam_kernel(AdamTensors t, float lr, float b1, float b2, float eps, float c1, float c2) {
@@ -517,7 +525,9 @@ void k_uncast_rows(hipStream_t st, int dtype, const void *in, int64_t ld_in, int
                                          ld_out));
 }
 void k_colsum(hipStream_t st, int dtype, const void *z, int64_t ld, int M, int N, float *out) {
-    DISPATCH_T(dtype, hipLaunchKernelGGL(colsum_kernel<T>, dim3(cdiv(N, 64)), dim3(256), 0, st, (const T *)z, ld, M, N, out));
+    (void)hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, st);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(colsum_kernel<T>, dim3(cdiv(N, 64), cdiv(M, 256)), dim3(256), 0, st, (const T *)z, ld,
+                                         M, N, out));
 }
 void k_adam(hipStream_t st, const AdamTensors &t, int step, float lr, float b1, float b2, float eps) {
     const float c1 = (float)(1.0 - pow((double)b1, (double)step)), c2 = (float)(1.0 - pow((double)b2, (double)step));

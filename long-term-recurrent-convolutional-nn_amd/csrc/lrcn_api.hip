@@ -111,6 +111,10 @@ template <class P> int dalloc(lrcn_ctx *c, P *&p, size_t bytes) {
     }
     c->allocs.push_back(q);
     p = reinterpret_cast<P *>(q);
+    if (hipMemset(q, 0, bytes) != hipSuccess) {  // K-padding columns must hold zeros (never NaN) from the start
+        c->err = "hipMemset failed";
+        return LRCN_EHIP;
+    }
     return LRCN_OK;
 }
 #define DALLOC(c, p, bytes)                         \
@@ -119,7 +123,8 @@ template <class P> int dalloc(lrcn_ctx *c, P *&p, size_t bytes) {
         if (_r) return _r;                          \
     } while (0)
 
-inline int64_t ld8(int64_t n) { return round_up64(n, 8); }
+// leading dimensions: whole 64-element K-steps, so the direct-to-LDS GEMM can run with K rounded up (pads are zero)
+inline int64_t ld8(int64_t n) { return round_up64(n, 64); }
 inline char *boff(void *p, int64_t elems, size_t esz) { return reinterpret_cast<char *>(p) + elems * (int64_t)esz; }
 inline const char *boff(const void *p, int64_t elems, size_t esz) {
     return reinterpret_cast<const char *>(p) + elems * (int64_t)esz;
@@ -138,7 +143,9 @@ int gemm(lrcn_ctx *c, int dtype, const void *A, int64_t lda, const void *B, int6
     g.ldc = ldc;
     g.M = M;
     g.N = N;
-    g.K = K;
+    // bf16: K rounded up to whole 128-byte K-steps.  Every internal operand has ld >= that and zero (weights: written
+    // zeros; activations: zero or stale-but-finite values that meet a zero on the other side) in the padding.
+    g.K = (dtype == GEMM_T_BF16 && lda >= round_up64(K, 64) && ldb >= round_up64(K, 64)) ? (int)round_up64(K, 64) : K;
     g.bias = bias;
     g.c_f32 = c_f32;
     g.beta = beta;
@@ -487,7 +494,7 @@ int lrcn_create(const lrcn_config *cfg, lrcn_ctx **out) {
         if (cfg->max_images > 0) {
             const int64_t N = cfg->max_images;
             const size_t ve = c->vesz;
-            DALLOC(c, c->im2col, ve * N * 224 * 224 * 32);
+            if (c->vdt != GEMM_T_BF16) DALLOC(c, c->im2col, ve * N * 224 * 224 * 32);  // bf16 fuses conv1_1's im2col
             DALLOC(c, c->actA, ve * N * 224 * 224 * 64);
             DALLOC(c, c->actB, ve * N * 112 * 112 * 128);  // largest tensor ever written to the second buffer (pool1 out = N*112*112*64; conv2_1 out = N*112*112*128)
             DALLOC(c, c->f6, ve * N * 4096);
@@ -799,11 +806,19 @@ int conv_layer(lrcn_ctx *c, int dtype, const void *in, const VggLayer &L, int N,
     return LRCN_OK;
 }
 
-// im2col (already in c->im2col) -> featsRM [N][4096] f32
-int vgg_body(lrcn_ctx *c, int N) {
+// source image (uint8 crops or the preprocessed float tensor) -> featsRM [N][4096] f32
+int vgg_body(lrcn_ctx *c, int N, const void *src, bool src_u8, const float *mean) {
     const int vdt = c->vdt;
-    // conv1_1 as a plain GEMM over the explicit im2col (K = 27), scattered to NHWC
-    {
+    const float m0 = mean ? mean[0] : 0.f, m1 = mean ? mean[1] : 0.f, m2 = mean ? mean[2] : 0.f;
+    if (vdt == GEMM_T_BF16) {
+        // conv1_1 fused with the preprocessing arithmetic (conv11.hip): HBM-bound, no im2col in memory
+        k_conv11_fused(c->stream, src_u8 ? 1 : 0, src, N, 224, m0, m1, m2, c->conv[0].w, c->conv[0].b, c->actA);
+    } else {
+        // f32: conv1_1 as a plain GEMM over an explicit im2col (K = 27), scattered to NHWC
+        if (src_u8)
+            k_im2col11_u8(c->stream, vdt, reinterpret_cast<const uint8_t *>(src), N, 224, m0, m1, m2, c->im2col, 32);
+        else
+            k_im2col11_f32(c->stream, vdt, reinterpret_cast<const float *>(src), N, 224, c->im2col, 32);
         GemmArgs g{};
         g.dtype = vdt;
         g.A = c->im2col;
@@ -907,8 +922,7 @@ int lrcn_vgg_forward(lrcn_ctx *c, const float *x, int N, float *feats) {
     if (!c || !x || !feats) return LRCN_EINVAL;
     int r = vgg_check(c, N);
     if (r) return r;
-    k_im2col11_f32(c->stream, c->vdt, x, N, 224, c->im2col, 32);
-    r = vgg_body(c, N);
+    r = vgg_body(c, N, x, false, nullptr);
     if (r) return r;
     k_transpose_f32(c->stream, c->featsRM, 4096, N, 4096, feats, N);  // return transpose(xs): N x 4096 column-major
     KCHK(c, "vgg_forward");
@@ -919,8 +933,7 @@ int lrcn_vgg_forward_u8(lrcn_ctx *c, const uint8_t *img, int N, const float mean
     if (!c || !img || !feats || !mean) return LRCN_EINVAL;
     int r = vgg_check(c, N);
     if (r) return r;
-    k_im2col11_u8(c->stream, c->vdt, img, N, 224, mean[0], mean[1], mean[2], c->im2col, 32);
-    r = vgg_body(c, N);
+    r = vgg_body(c, N, img, true, mean);
     if (r) return r;
     k_transpose_f32(c->stream, c->featsRM, 4096, N, 4096, feats, N);
     KCHK(c, "vgg_forward_u8");
