@@ -27,6 +27,19 @@ PEAK_BF16_TFLOPS = 2516.0                # MI355X dense bf16 MFMA (MI355X_MICROA
 PEAK_F32_TFLOPS = 157.3
 
 
+def pmc_traffic(dtype, per_gpu_batch):
+    """HBM-side bytes per launch of the dominant kernel family, from the committed rocprofv3 PMC passes of this same
+    command (tools/pmc_traffic.py -> profiles/*.json; FETCH_SIZE/WRITE_SIZE cannot be read from inside the process).
+    Only valid for the configuration it was measured on; otherwise null."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic_bench_bf16_b256.json")
+    if dtype != "bf16" or per_gpu_batch != 256 or not os.path.exists(path):
+        return None
+    try:
+        return float(json.load(open(path))["traffic_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def cpu_baseline(vgg_w, E, H, V, T, rng):
     """The oracle (kind "port": the reference is Julia/GPU-only and cannot run) timed on this box's host cores on a
     bounded sample of the same workload: VGG forward on 4 images + lossgradient on 16 captions, float accumulation."""
@@ -156,8 +169,9 @@ def main():
                        "global_batch": Bg, "per_gpu_batch": B, "seq_len": T + 1, "parallelism": "dp%d" % world,
                        "last_loss": loss},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": None,
-                         "kernel": "gemm_nt_kernel<%s,128,128,CONV3> (conv1_2..conv5_3, 12 launches/step)" % a.dtype,
+                         "traffic": pmc_traffic(a.dtype, B),
+                         "kernel": "gemm_glds_kernel<*,CONV3,*> (implicit-GEMM conv1_2..conv5_3, 12 launches/step)"
+                                   if a.dtype == "bf16" else "gemm_nt_kernel<float,*,CONV3> (conv1_2..conv5_3)",
                          "avg_launch_ms": 1e3 * avg_launch_s, "flops_per_launch": flops_per_launch},
         }
         if world == 1 and not a.no_cpu_baseline:

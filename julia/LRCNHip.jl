@@ -1,0 +1,104 @@
+# LRCNHip.jl -- the binding a maintainer of lrcn.jl would add to route the hot path through liblrcn_hip.so.
+#
+# UNTESTED: Julia is not available in the build environment of this repository (SURVEY.md section 0.2).  It is written
+# for Julia >= 1.6 with plain `ccall`; arrays are device buffers owned by the caller (e.g. AMDGPU.jl ROCArray{Float32}
+# or raw pointers from lrcn_malloc).  Julia arrays are column-major, which is exactly what include/lrcn.h expects, so
+# nothing is copied or transposed.  Token ids: the reference is 1-based (eos/bos/unk = 1/2/3, lrcn.jl:248-255); the ABI
+# is 0-based, so the shim subtracts 1.
+module LRCNHip
+
+const lib = get(ENV, "LRCN_HIP_LIB", "liblrcn_hip.so")
+
+struct Config
+    device::Cint; E::Cint; H1::Cint; H2::Cint; V::Cint
+    max_B::Cint; max_T::Cint; lstm_dtype::Cint; vgg_dtype::Cint; max_images::Cint
+end
+struct Dropout
+    pdrop::Cfloat; seed::UInt64; mask1::Ptr{Cfloat}; mask2::Ptr{Cfloat}
+end
+const F32 = Cint(0); const BF16 = Cint(1)
+
+mutable struct Context
+    h::Ptr{Cvoid}
+end
+
+function check(ctx, rc)
+    rc == 0 && return
+    msg = unsafe_string(ccall((:lrcn_last_error, lib), Cstring, (Ptr{Cvoid},), ctx === nothing ? C_NULL : ctx.h))
+    error("liblrcn_hip: $msg")          # the reference's convention: Julia exceptions (lrcn.jl:395, 603)
+end
+
+function Context(; device=0, embed=1000, hidden=[1000, 1000], vocab, batchsize=25, maxlen=28, dtype=BF16, images=0)
+    cfg = Ref(Config(device, embed, hidden[1], hidden[2], vocab, batchsize, maxlen, dtype, dtype, images))
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    check(nothing, ccall((:lrcn_create, lib), Cint, (Ref{Config}, Ref{Ptr{Cvoid}}), cfg, out))
+    ctx = Context(out[])
+    finalizer(c -> ccall((:lrcn_destroy, lib), Cvoid, (Ptr{Cvoid},), c.h), ctx)
+    ctx
+end
+
+ptrs(v) = Ptr{Cfloat}[Ptr{Cfloat}(pointer(a)) for a in v]      # model / grads: Vector of 9 device arrays
+
+# lstm(weight,bias,hidden,cell,input)                                                    lrcn.jl:528-538
+function lstm(ctx, weight, bias, hidden, cell, input)
+    B, X = size(input); H = size(hidden, 2)
+    h2 = similar(hidden); c2 = similar(cell)
+    check(ctx, ccall((:lrcn_lstm, lib), Cint,
+        (Ptr{Cvoid}, Ptr{Cfloat}, Ptr{Cfloat}, Cint, Cint, Cint, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}),
+        ctx.h, pointer(weight), pointer(bias), X, H, B, pointer(input), pointer(hidden), pointer(cell), pointer(h2), pointer(c2)))
+    (h2, c2)
+end
+
+# lrcn(w, s, x_cnn, x_lstm; pdrop) -- dropout enters as explicit mask arrays               lrcn.jl:540-551
+function lrcn(ctx, w, s, x_cnn, x_lstm; mask1=nothing, mask2=nothing)
+    B = size(x_lstm, 1); V = size(w[end], 2)
+    logits = similar(x_lstm, B, V)
+    m1 = mask1 === nothing ? Ptr{Cfloat}(C_NULL) : Ptr{Cfloat}(pointer(mask1))
+    m2 = mask2 === nothing ? Ptr{Cfloat}(C_NULL) : Ptr{Cfloat}(pointer(mask2))
+    check(ctx, ccall((:lrcn_step, lib), Cint,
+        (Ptr{Cvoid}, Ptr{Ptr{Cfloat}}, Ptr{Ptr{Cfloat}}, Cint, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}),
+        ctx.h, ptrs(w), ptrs(s), B, pointer(x_cnn), pointer(x_lstm), m1, m2, pointer(logits)))
+    logits
+end
+
+# tokens: the reference's sequence[range] as a device Int32 array [T][B] (already minus 1)
+function loss(ctx, param, input, tokens, T, B; batchsize=B, pdrop=0.0, seed=0)                 # lrcn.jl:553-581
+    d = Ref(Dropout(pdrop, seed, C_NULL, C_NULL)); out = Ref{Cdouble}(0)
+    check(ctx, ccall((:lrcn_loss, lib), Cint,
+        (Ptr{Cvoid}, Ptr{Ptr{Cfloat}}, Ptr{Cfloat}, Ptr{Int32}, Cint, Cint, Cint, Ref{Dropout}, Ref{Cdouble}),
+        ctx.h, ptrs(param), pointer(input), pointer(tokens), T, B, batchsize, d, out))
+    out[]
+end
+
+function lossgradient(ctx, param, input, tokens, T, B, grads; batchsize=B, pdrop=0.0, seed=0)  # lrcn.jl:583
+    d = Ref(Dropout(pdrop, seed, C_NULL, C_NULL))
+    check(ctx, ccall((:lrcn_loss_grad, lib), Cint,
+        (Ptr{Cvoid}, Ptr{Ptr{Cfloat}}, Ptr{Cfloat}, Ptr{Int32}, Cint, Cint, Cint, Ref{Dropout}, Ptr{Ptr{Cfloat}}, Ptr{Cdouble}),
+        ctx.h, ptrs(param), pointer(input), pointer(tokens), T, B, batchsize, d, ptrs(grads), C_NULL))
+    grads
+end
+
+# update!(param, gloss, optim): optim = (m, v, t) with Knet's Adam defaults                lrcn.jl:394, 399-405
+function update!(ctx, param, grads, m, v, t; lr=1f-3, beta1=0.9f0, beta2=0.999f0, eps=1f-8)
+    check(ctx, ccall((:lrcn_adam_update, lib), Cint,
+        (Ptr{Cvoid}, Ptr{Ptr{Cfloat}}, Ptr{Ptr{Cfloat}}, Ptr{Ptr{Cfloat}}, Ptr{Ptr{Cfloat}}, Cint, Cfloat, Cfloat, Cfloat, Cfloat),
+        ctx.h, ptrs(param), ptrs(grads), ptrs(m), ptrs(v), t, lr, beta1, beta2, eps))
+end
+
+# convnet(xs): (224,224,3,N) -> N x 4096                                                   lrcn.jl:733-748
+function convnet(ctx, xs)
+    N = size(xs, 4); feats = similar(xs, N, 4096)
+    check(ctx, ccall((:lrcn_vgg_forward, lib), Cint, (Ptr{Cvoid}, Ptr{Cfloat}, Cint, Ptr{Cfloat}), ctx.h, pointer(xs), N, pointer(feats)))
+    feats
+end
+
+# beam_search as generate drives it: returns 1-based ids after bos, up to eos              lrcn.jl:585-678
+function beam_search(ctx, param, feat, beam_width, nword)
+    out = Vector{Int32}(undef, nword + 3); n = Ref{Cint}(0); p = Ref{Cfloat}(0)
+    check(ctx, ccall((:lrcn_beam_search, lib), Cint,
+        (Ptr{Cvoid}, Ptr{Ptr{Cfloat}}, Ptr{Cfloat}, Cint, Cint, Ptr{Int32}, Ref{Cint}, Ref{Cfloat}),
+        ctx.h, ptrs(param), pointer(feat), beam_width, nword, out, n, p))
+    (out[1:n[]] .+ Int32(1), p[])
+end
+
+end # module
