@@ -154,6 +154,9 @@ int lrcn_conv3x3(lrcn_ctx *ctx, const float *x, int W, int H, int Cin, int N, co
  * lrcn_profile_get synchronises and returns the accumulated milliseconds and launch count since lrcn_profile(ctx,1). */
 int lrcn_profile(lrcn_ctx *ctx, int enable);
 int lrcn_profile_get(lrcn_ctx *ctx, double *conv_ms, int64_t *conv_launches);
+/* Diagnostic: average milliseconds of one bf16 3x3 convolution layer (N images of S x S x Cin -> Cout, optional fused
+ * pool) on random data, `iters` back-to-back launches timed with HIP events.  Kernel-development aid, not the product path. */
+int lrcn_bench_conv(lrcn_ctx *ctx, int N, int S, int Cin, int Cout, int pool, int iters, double *ms_out);
 
 #ifdef __cplusplus
 }

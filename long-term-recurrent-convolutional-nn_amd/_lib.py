@@ -71,6 +71,7 @@ SIGNATURES = {
     "lrcn_vgg_forward_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_void_p]),
     "lrcn_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "lrcn_profile_get": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "lrcn_bench_conv": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "lrcn_conv3x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                C.c_int, C.c_int, C.c_int, C.c_void_p]),
 }

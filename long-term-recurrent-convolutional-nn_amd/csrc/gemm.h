@@ -23,6 +23,7 @@ struct GemmArgs {
     int relu;
     int a_mode, out_mode;
     int H, W, Cin;  // conv geometry (square-agnostic; H, W even)
+    int dbg;                // kernel-development ablation flags (LRCN_DBG env): 1 = skip steady-state DMA, 2 = skip LDS reads + MFMA
     const void *zero_page;  // >= 256 zero bytes, 16-byte aligned (source of padding rows for the direct-to-LDS path) or NULL
 };
 

@@ -12,6 +12,8 @@
 //     t run; one barrier per K-step;
 //   * workgroups are renumbered so that the N-tiles sharing one im2col panel run on the same XCD (same L2).
 // MFMA: v_mfma_f32_32x32x16_bf16; rows in window-major pixel order so 2x2 max-pool = max of 4 accumulator registers.
+#include <cstdlib>
+
 #include "common.h"
 #include "gemm.h"
 
@@ -99,26 +101,39 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_glds_kernel(const GemmArgs g
         b_off[i] = b_ok[i] ? n * (int)g.ldb + src_chunk * 8 : 0;
     }
 
-    auto stage = [&](int buf, int kt) {
+    // One DMA piece (1 KiB = 8 rows x 128 B) of the K-step `kt` tile into ring slot `buf`: p < 4 -> A piece p of this
+    // wave's 32 rows, p >= 4 -> B piece.  live = false stages zeros (used for the tail, into a dead slot, so that the
+    // K-step body is branch-free and the vmcnt bookkeeping uniform).
+    struct KStep {
+        int tap, koff, kb;
+    };
+    auto kstep_of = [&](int kt) {
+        // K-step order for the convolution: channel slice OUTER, tap INNER (kt = slice*9 + tap): the nine taps of one
+        // 64-channel slice re-read the same (patch + halo) pixels in nine consecutive K-steps -> L2 hits.
+        KStep k;
+        if (AMODE == GEMM_A_CONV3) {
+            const int slice = kt / 9;
+            k.tap = kt - 9 * slice;
+            const int kh = k.tap / 3, kw = k.tap - 3 * kh;
+            k.koff = ((kh - 1) * g.W + (kw - 1)) * g.Cin + slice * 64;
+            k.kb = k.tap * g.Cin + slice * 64;
+        } else {
+            k.tap = 0;
+            k.koff = kt * 64;
+            k.kb = k.koff;
+        }
+        return k;
+    };
+    auto stage_piece = [&](int buf, const KStep &k, int p, bool live) {
         unsigned char *As = smem + buf * BUF;
         unsigned char *Bs = As + A_BYTES;
-        int tap = 0, koff;
-        if (AMODE == GEMM_A_CONV3) {
-            tap = kt / kpt;
-            const int kh = tap / 3, kw = tap - 3 * kh;
-            koff = ((kh - 1) * g.W + (kw - 1)) * g.Cin + (kt - tap * kpt) * 64;
+        if (p < 4) {
+            const bool ok = live && ((a_mask[p] >> k.tap) & 1u);
+            const bf16_t *src = ok ? Ab + (a_off[p] + k.koff) : Zp;
+            __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(As + (wave * 32 + p * 8) * 128), 16, 0, 0);
         } else {
-            koff = kt * 64;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const bool ok = (a_mask[q] >> tap) & 1u;
-            const bf16_t *src = ok ? Ab + (a_off[q] + koff) : Zp;
-            __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(As + (wave * 32 + q * 8) * 128), 16, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < BQ; ++i) {
-            const bf16_t *src = b_ok[i] ? Bb + (b_off[i] + kt * 64) : Zp;
+            const int i = p - 4;
+            const bf16_t *src = (live && b_ok[i]) ? Bb + (b_off[i] + k.kb) : Zp;
             __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(Bs + (wave + NW * i) * 8 * 128), 16, 0, 0);
         }
     };
@@ -139,16 +154,24 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_glds_kernel(const GemmArgs g
     // NBUF-deep ring: the DMA of K-steps kt+1 .. kt+NBUF-1 is in flight while K-step kt is multiplied.  A K-step's
     // data is ordered for every wave's ds_read by: each wave's counted vmcnt for its own pieces, then the barrier.
     // (raw s_barrier: __syncthreads() would drain vmcnt to 0 -- cdna guide "Pipelining across barriers")
+    // All DMA pieces of the next tile are issued in one burst right after the barrier, then the compiler schedules the
+    // ds_reads against the MFMAs.  (Tried: cutting the K-step into sched_barrier-pinned chunks of [1 DMA piece, 2 A-fragment
+    // reads, 2*TN MFMAs] -- 14 % SLOWER, 693 vs 803 TF over the VGG stack; the burst form is kept.)
 #pragma unroll
-    for (int t = 0; t < NBUF - 1; ++t)
-        if (t < KT) stage(t, kbeg + t);
+    for (int t = 0; t < NBUF - 1; ++t) {
+        const KStep k = kstep_of(kbeg + (t < KT ? t : 0));
+#pragma unroll
+        for (int p = 0; p < IPT; ++p) stage_piece(t, k, p, t < KT);
+    }
     for (int kt = 0; kt < KT; ++kt) {
-        if (kt + NBUF - 2 < KT)
-            wait_vmcnt<(NBUF - 2) * IPT>();
-        else
-            wait_vmcnt<0>();
+        wait_vmcnt<(NBUF - 2) * IPT>();
         __builtin_amdgcn_s_barrier();
-        if (kt + NBUF - 1 < KT) stage((kt + NBUF - 1) % NBUF, kbeg + kt + NBUF - 1);
+        const int nxt = kt + NBUF - 1;
+        const bool live = nxt < KT && !(g.dbg & 1);
+        const KStep kn = kstep_of(kbeg + (nxt < KT ? nxt : 0));
+#pragma unroll
+        for (int p = 0; p < IPT; ++p) stage_piece(nxt % NBUF, kn, p, live);
+        if (g.dbg & 2) continue;
         const int cur = kt % NBUF;
         const unsigned char *As = smem + cur * BUF + (wm * TM * 32) * 128;
         const unsigned char *Bs = smem + cur * BUF + A_BYTES + (wn * TN * 32) * 128;
@@ -170,9 +193,73 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_glds_kernel(const GemmArgs g
                                                                         __builtin_bit_cast(bf16x8, bfr[n][j]), acc[i][n], 0, 0, 0);
         }
     }
+    wait_vmcnt<0>();  // the tail's dummy pieces
 
-    // ---- epilogue (C layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) ----
+    // ---- epilogue A (bf16 output, no accumulate): bias/ReLU/pool in registers -> bf16 C tile staged in LDS (the ring is
+    // free now) -> whole rows written with 16 B per lane (one 2*BN-byte row segment per BN/8 lanes).  The direct
+    // per-lane 2-byte stores of epilogue B cost the un-pooled convolution layers 15-45 % (profiles/r01 conv_bench).
     const int hh = lane >> 5;
+    const bool staged = !g.c_f32 && !g.beta && gridDim.y == 1 && (g.ldc % 8) == 0 && ((uintptr_t)g.C & 15) == 0 &&
+                        (n0 + BN <= N || (N % 8) == 0);
+    if (staged) {
+        constexpr int CSTR = BN * 2;  // bytes per staged row
+        __builtin_amdgcn_s_barrier();  // every wave is done reading the last K-step (and no DMA is in flight)
+        const bool pool = g.out_mode == GEMM_OUT_POOL;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int n = 0; n < TN; ++n) {
+                const int lcol = (wn * TN + n) * 32 + (lane & 31);
+                const int col = n0 + lcol;
+                const float bias = (g.bias && col < N) ? g.bias[col] : 0.0f;
+                const int lrow0 = (wm * TM + i) * 32 + 4 * hh;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (pool) {
+                        float v = fmaxf(fmaxf(acc[i][n][4 * q], acc[i][n][4 * q + 1]),
+                                        fmaxf(acc[i][n][4 * q + 2], acc[i][n][4 * q + 3])) + bias;
+                        if (g.relu) v = fmaxf(v, 0.0f);
+                        *reinterpret_cast<bf16_t *>(smem + ((lrow0 + 8 * q) >> 2) * CSTR + lcol * 2) = (bf16_t)v;
+                    } else {
+#pragma unroll
+                        for (int s2 = 0; s2 < 4; ++s2) {
+                            float v = acc[i][n][4 * q + s2] + bias;
+                            if (g.relu) v = fmaxf(v, 0.0f);
+                            *reinterpret_cast<bf16_t *>(smem + (lrow0 + 8 * q + s2) * CSTR + lcol * 2) = (bf16_t)v;
+                        }
+                    }
+                }
+            }
+        __syncthreads();
+        const int rows_out = pool ? BM / 4 : BM;
+        constexpr int CPR = BN / 8;  // 16-byte chunks per staged row
+        bf16_t *Cb = reinterpret_cast<bf16_t *>(g.C);
+        for (int idx = tid; idx < rows_out * CPR; idx += NW * 64) {
+            const int lrow = idx / CPR, ch = idx - lrow * CPR;
+            const int col = n0 + ch * 8;
+            if (col >= N) continue;
+            int64_t off;
+            if (pool) {
+                const int prow = (m0 >> 2) + lrow;
+                if (prow >= (M >> 2)) continue;
+                off = (int64_t)prow * g.ldc + col;
+            } else {
+                const int row = m0 + lrow;
+                if (row >= M) continue;
+                if (g.out_mode == GEMM_OUT_CONV) {
+                    const PixDecode p = decode_pixel(row, g.H, g.W);
+                    off = (((int64_t)p.n * g.H + p.y) * g.W + p.x) * g.ldc + col;
+                } else {
+                    off = (int64_t)row * g.ldc + col;
+                }
+            }
+            *reinterpret_cast<uint4 *>(Cb + off) = *reinterpret_cast<const uint4 *>(smem + lrow * CSTR + ch * 16);
+        }
+        return;
+    }
+
+    // ---- epilogue B (f32 / accumulating / split-K outputs): direct stores from the 32x32 MFMA C layout
+    //      (col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) ----
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -321,8 +408,11 @@ bool gemm_glds_eligible(const GemmArgs &g) {
     return true;
 }
 
-hipError_t launch_gemm_glds(hipStream_t stream, const GemmArgs &g) {
-    if (!gemm_glds_eligible(g)) return hipErrorInvalidValue;
+hipError_t launch_gemm_glds(hipStream_t stream, const GemmArgs &g0) {
+    if (!gemm_glds_eligible(g0)) return hipErrorInvalidValue;
+    GemmArgs g = g0;
+    const char *dbg = getenv("LRCN_DBG");
+    g.dbg = dbg ? atoi(dbg) : 0;
     return g.a_mode == GEMM_A_CONV3 ? dispatch<GEMM_A_CONV3>(stream, g) : dispatch<GEMM_A_PLAIN>(stream, g);
 }
 

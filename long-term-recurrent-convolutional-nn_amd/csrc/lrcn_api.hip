@@ -918,6 +918,47 @@ int lrcn_profile_get(lrcn_ctx *c, double *conv_ms, int64_t *conv_launches) {
     return LRCN_OK;
 }
 
+// Diagnostic: time one bf16 implicit-GEMM convolution layer (random data) in isolation: avg ms over `iters` launches.
+int lrcn_bench_conv(lrcn_ctx *c, int N, int S, int Cin, int Cout, int pool, int iters, double *ms_out) {
+    if (!c || !ms_out || N < 1 || S < 2 || (S & 1) || Cin % 64 || Cout < 1 || iters < 1) return LRCN_EINVAL;
+    const size_t in_e = (size_t)N * S * S * Cin, w_e = (size_t)Cout * 9 * Cin, out_e = (size_t)N * S * S * Cout;
+    void *in = nullptr, *w = nullptr, *out = nullptr;
+    float *tmp = nullptr, *bias = nullptr;
+    hipEvent_t e0, e1;
+    auto cleanup = [&]() {
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipFree(in); (void)hipFree(w); (void)hipFree(out); (void)hipFree(tmp); (void)hipFree(bias);
+    };
+    const size_t big = in_e > w_e ? in_e : w_e;
+    if (hipMalloc(&in, 2 * in_e) != hipSuccess || hipMalloc(&w, 2 * w_e) != hipSuccess || hipMalloc(&out, 2 * out_e) != hipSuccess ||
+        hipMalloc((void **)&tmp, 4 * big) != hipSuccess || hipMalloc((void **)&bias, 4 * Cout) != hipSuccess) {
+        cleanup();
+        FAIL(c, LRCN_ENOMEM, "bench_conv scratch");
+    }
+    k_init_uniform(c->stream, tmp, (int64_t)in_e, 1.0f, 11, 0);
+    // cast in row chunks of Cin (k_cast_rows works row-wise)
+    k_cast_rows(c->stream, GEMM_T_BF16, tmp, Cin, (int)(in_e / Cin), Cin, in, Cin);
+    k_init_uniform(c->stream, tmp, (int64_t)w_e, (float)std::sqrt(2.0 / (9.0 * Cin)), 12, 1);
+    k_cast_rows(c->stream, GEMM_T_BF16, tmp, 9 * Cin, Cout, 9 * Cin, w, 9 * Cin);
+    k_fill(c->stream, bias, Cout, 0.01f);
+    VggLayer L;
+    L.w = w; L.b = bias; L.Cin = Cin; L.Cout = Cout; L.S = S; L.pool = pool;
+    int r = conv_layer(c, GEMM_T_BF16, in, L, N, out);  // warm-up
+    if (r) { cleanup(); return r; }
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, c->stream);
+    for (int i = 0; i < iters && !r; ++i) r = conv_layer(c, GEMM_T_BF16, in, L, N, out);
+    (void)hipEventRecord(e1, c->stream);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    cleanup();
+    if (r) return r;
+    *ms_out = ms / iters;
+    return LRCN_OK;
+}
+
 int lrcn_vgg_forward(lrcn_ctx *c, const float *x, int N, float *feats) {
     if (!c || !x || !feats) return LRCN_EINVAL;
     int r = vgg_check(c, N);
