@@ -36,3 +36,8 @@ hipError_t launch_gemm(hipStream_t stream, const GemmArgs &g);
 bool gemm_glds_eligible(const GemmArgs &g);
 hipError_t launch_gemm_glds(hipStream_t stream, const GemmArgs &g);
 int64_t gemm_glds_blocks(const GemmArgs &g);  // workgroups the direct-to-LDS path would launch (0 = no config fits)
+
+// Phase-interleaved variant (gemm_8p.hip): 256 x 256 / 256 x 128 tiles, v_mfma_f32_16x16x32_bf16, two wave groups one
+// barrier apart.  gemm_8p_config returns the tile config (>= 0) and the grid size, or -1 when the problem does not fit it.
+int gemm_8p_config(const GemmArgs &g, int64_t *blocks);
+hipError_t launch_gemm_8p(hipStream_t stream, const GemmArgs &g);

@@ -274,6 +274,11 @@ hipError_t launch_gemm(hipStream_t stream, const GemmArgs &g) {
     // LRCN_GLDS=0 disables the direct-to-LDS path, LRCN_GLDS=force uses it whenever eligible (tests); default: when
     // the grid fills the chip.
     const char *knob = getenv("LRCN_GLDS");
+    const char *knob8 = getenv("LRCN_8P");  // LRCN_8P=0 disables the phase-interleaved path, =force lowers its grid threshold
+    if (!(knob && knob[0] == '0') && !(knob8 && knob8[0] == '0')) {
+        int64_t blocks = 0;
+        if (gemm_8p_config(g, &blocks) >= 0 && ((knob8 && knob8[0] == 'f') || blocks >= 128)) return launch_gemm_8p(stream, g);
+    }
     if (!(knob && knob[0] == '0') && gemm_glds_eligible(g)) {
         const int64_t blocks = gemm_glds_blocks(g);
         if (blocks > 0 && ((knob && knob[0] == 'f') || blocks >= 96)) return launch_gemm_glds(stream, g);

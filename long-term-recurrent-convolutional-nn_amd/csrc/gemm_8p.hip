@@ -1,0 +1,467 @@
+// gemm_8p.hip -- phase-interleaved bf16 NT contraction / implicit-GEMM 3x3 convolution for gfx950 (the fast path).
+//
+// Same contract as gemm_glds.hip (GemmArgs, NT operands, im2col formed by the LDS-DMA source addresses, window-major conv
+// rows, XOR-swizzled 128-byte LDS rows), re-scheduled the way a CDNA4 CU wants to be fed (cdna guide 5, "8-phase"):
+//   * 256-row tiles, 8 waves (two per SIMD), v_mfma_f32_16x16x32_bf16 (holds a higher clock than 32x32x16 on random data);
+//   * a K-tile (64 deep) is processed in 4 phases, one quadrant of the wave's output tile each.  A phase is
+//       [ds_read this quadrant's new fragments | issue one half-tile of LDS-DMA prefetch]  s_barrier
+//       [16 (or 8) MFMAs under s_setprio 1]                                                s_barrier
+//   * waves 4..7 run ONE barrier behind waves 0..3, so on every SIMD one wave is in its MFMA cluster while its partner
+//     reads LDS / issues DMA: the matrix pipe is never idle waiting for fragment reads;
+//   * LDS = 2 K-tile buffers x {A half 0, A half 1, B half 0, B half 1}.  A half-tile slot is refilled two phases after its
+//     last read, so 2-3 half-tiles are always in flight; one counted s_waitcnt vmcnt per K-tile, never 0 in the loop;
+//   * D = B_frag x A_frag ("swapped": lane = pixel, 4 registers = 4 consecutive channels) for plain/conv outputs, so
+//     the epilogue moves 8/16 bytes per lane; D = A_frag x B_frag for the fused 2x2 max-pool (4 registers = the 4 pixels
+//     of one pool window, SURVEY conv rows / DESIGN.md).
+// Hazards (two wave groups one barrier apart): a half-tile is read one phase AFTER the phase whose first barrier
+// follows the wait that retires it; a slot is re-staged >= 2 phases after its last ds_read.
+#include <cstdlib>
+#include <type_traits>
+
+#include "common.h"
+#include "gemm.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+struct KStep {
+    int tap, koff, kb;
+};
+
+// compile-time loop: the ds_read offsets below must be literal immediates of an inline-asm statement
+template <int I, int N, class F> __device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+// Fragment reads are inline asm on purpose: hipcc orders every ordinary LDS load behind ALL outstanding LDS-DMA with
+// s_waitcnt vmcnt(0) (it cannot tell which ring slot a global_load_lds writes), which would drain the prefetch ring at
+// every phase.  The ordering that matters is established by hand: counted vmcnt + s_barrier (see the hazard note above).
+template <int OFF> __device__ __forceinline__ uint4 lds_read16(unsigned addr) {
+    uint4 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
+    return r;
+}
+
+template <int WM, int WN, int MT, int NT, int AMODE, bool SWAP>
+__global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs g) {
+    static_assert(WM * WN == 8, "8 waves");
+    constexpr int QM = MT * 16, QN = NT * 16;   // quadrant = QM x QN of a wave's (2 QM) x (2 QN) output tile
+    constexpr int WTM = 2 * QM, WTN = 2 * QN;
+    constexpr int BM = WM * WTM, BN = WN * WTN;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF = A_BYTES + B_BYTES;
+    constexpr int APW = BM / 128, BPW = BN / 128;  // DMA instructions per wave per half-tile
+    static_assert(APW >= 1 && BPW >= 1 && APW * 128 == BM && BPW * 128 == BN, "tile must be a multiple of 128");
+    constexpr int CPR = BN / 8;                     // 16-byte chunks per staged C row
+    static_assert(CPR >= 16, "epilogue swizzle needs >= 16 chunks per row");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WN, wc = wave % WN;
+    const int grp = wave >> 2;  // waves 4..7 run one barrier behind waves 0..3
+    const int M = g.M, N = g.N;
+    const int tiles_n = (N + BN - 1) / BN;
+    int bid = blockIdx.x;
+    {   // bijective XCD renumbering: the N-tiles of one im2col panel (consecutive logical ids) share an XCD's L2
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int nt = bid % tiles_n, mt = bid / tiles_n;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    const bf16_t *Ab = reinterpret_cast<const bf16_t *>(g.A);
+    const bf16_t *Bb = reinterpret_cast<const bf16_t *>(g.B);
+    const bf16_t *Zp = reinterpret_cast<const bf16_t *>(g.zero_page) + (lane & 7) * 8;
+
+    const int kpt = (AMODE == GEMM_A_CONV3) ? g.Cin / 64 : g.K / 64;
+    const int KT_all = (AMODE == GEMM_A_CONV3) ? 9 * kpt : kpt;
+    const int kbeg = (int)((int64_t)KT_all * blockIdx.y / gridDim.y);
+    const int KT = (int)((int64_t)KT_all * (blockIdx.y + 1) / gridDim.y) - kbeg;
+
+    // ---- staging geometry: half-tile `hf` of A = rows {wr' * WTM + hf * QM + i}; piece = 8 rows x 128 B ----
+    auto a_piece_row = [&](int hf, int j) {
+        const int hr = (wave * APW + j) * 8;
+        return (hr / QM) * WTM + hf * QM + (hr % QM);
+    };
+    auto b_piece_row = [&](int hf, int j) {
+        const int hr = (wave * BPW + j) * 8;
+        return (hr / QN) * WTN + hf * QN + (hr % QN);
+    };
+    int a_off[2][APW];
+    unsigned a_mask[2][APW];
+    int b_off[2][BPW];
+    bool b_ok[2][BPW];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+        for (int j = 0; j < APW; ++j) {
+            const int row = a_piece_row(hf, j) + (lane >> 3);
+            const int m = m0 + row;
+            const int src_chunk = (lane & 7) ^ ((row >> 1) & 7);
+            a_off[hf][j] = 0;
+            a_mask[hf][j] = 0;
+            if (m < M) {
+                if (AMODE == GEMM_A_CONV3) {
+                    const PixDecode p = decode_pixel(m, g.H, g.W);
+                    a_off[hf][j] = ((p.n * g.H + p.y) * g.W + p.x) * g.Cin + src_chunk * 8;
+                    unsigned mk = 0;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        const int y = p.y + t / 3 - 1, x = p.x + t % 3 - 1;
+                        if ((unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W) mk |= 1u << t;
+                    }
+                    a_mask[hf][j] = mk;
+                } else {
+                    a_off[hf][j] = m * (int)g.lda + src_chunk * 8;
+                    a_mask[hf][j] = 1;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < BPW; ++j) {
+            const int row = b_piece_row(hf, j) + (lane >> 3);
+            const int n = n0 + row;
+            const int src_chunk = (lane & 7) ^ ((row >> 1) & 7);
+            b_ok[hf][j] = n < N;
+            b_off[hf][j] = b_ok[hf][j] ? n * (int)g.ldb + src_chunk * 8 : 0;
+        }
+    }
+
+    auto kstep_of = [&](int kt) {  // conv: channel slice OUTER, tap INNER (nine consecutive K-tiles re-read one patch: L2 hits)
+        KStep k;
+        if (AMODE == GEMM_A_CONV3) {
+            const int slice = kt / 9;
+            k.tap = kt - 9 * slice;
+            const int kh = k.tap / 3, kw = k.tap - 3 * kh;
+            k.koff = ((kh - 1) * g.W + (kw - 1)) * g.Cin + slice * 64;
+            k.kb = k.tap * g.Cin + slice * 64;
+        } else {
+            k.tap = 0;
+            k.koff = kt * 64;
+            k.kb = k.koff;
+        }
+        return k;
+    };
+    auto stage_a = [&](int buf, int hf, const KStep &k, bool live) {
+        const unsigned tapbit = live ? (1u << k.tap) : 0u;  // wave-uniform
+#pragma unroll
+        for (int j = 0; j < APW; ++j) {
+            const bool ok = (a_mask[hf][j] & tapbit) != 0;
+            const bf16_t *src = ok ? Ab + (a_off[hf][j] + k.koff) : Zp;
+            __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(smem + buf * BUF + a_piece_row(hf, j) * 128), 16, 0, 0);
+        }
+    };
+    auto stage_b = [&](int buf, int hf, const KStep &k, bool live) {
+#pragma unroll
+        for (int j = 0; j < BPW; ++j) {
+            const bf16_t *src = (b_ok[hf][j] & live) ? Bb + (b_off[hf][j] + k.kb) : Zp;
+            __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(smem + buf * BUF + A_BYTES + b_piece_row(hf, j) * 128), 16, 0,
+                                             0);
+        }
+    };
+
+    // fragment read offsets (16x16x32 operand: lane -> row lane&15, 16-byte K chunk 4s + (lane>>4), swizzled)
+    unsigned fa[2], fb[2];  // per-lane LDS byte addresses (buffer 0) of the wave's first A / B fragment, K half s
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const unsigned fo = (lane & 15) * 128 + (((s * 4 + (lane >> 4)) ^ (((lane & 15) >> 1) & 7)) << 4);
+        const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
+        fa[s] = base + (wr * WTM) * 128 + fo;
+        fb[s] = base + A_BYTES + (wc * WTN) * 128 + fo;
+    }
+
+    f32x4v acc[2][MT][2][NT];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[a][i][b][n] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+    uint4 af[MT][2], bf0[NT][2], bf1[NT][2];
+    auto read_a = [&](int buf, auto mhc) {
+        constexpr int mh = decltype(mhc)::value;
+        const unsigned a0 = fa[0] + buf * BUF, a1 = fa[1] + buf * BUF;
+        static_for<0, MT>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            af[i][0] = lds_read16<(mh * QM + i * 16) * 128>(a0);
+            af[i][1] = lds_read16<(mh * QM + i * 16) * 128>(a1);
+        });
+    };
+    auto read_b = [&](int buf, auto nhc, uint4 (&bf)[NT][2]) {
+        constexpr int nh = decltype(nhc)::value;
+        const unsigned b0 = fb[0] + buf * BUF, b1 = fb[1] + buf * BUF;
+        static_for<0, NT>([&](auto ic) {
+            constexpr int n = decltype(ic)::value;
+            bf[n][0] = lds_read16<(nh * QN + n * 16) * 128>(b0);
+            bf[n][1] = lds_read16<(nh * QN + n * 16) * 128>(b1);
+        });
+    };
+    constexpr std::integral_constant<int, 0> I0{};
+    constexpr std::integral_constant<int, 1> I1{};
+#define MFMA_QUADRANT(mh, nh, BF)                                                                                          \
+    do {                                                                                                                   \
+        __builtin_amdgcn_s_barrier();                                                                                      \
+        wait_lgkm0();                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+        __builtin_amdgcn_s_setprio(1);                                                                                     \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s) _Pragma("unroll") for (int i = 0; i < MT; ++i) _Pragma("unroll") for (int n = 0; \
+                                                                                                                   n < NT; ++n) { \
+            const bf16x8 av = __builtin_bit_cast(bf16x8, af[i][s]);                                                        \
+            const bf16x8 bv = __builtin_bit_cast(bf16x8, BF[n][s]);                                                        \
+            acc[mh][i][nh][n] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(bv, av, acc[mh][i][nh][n], 0, 0, 0)         \
+                                     : __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[mh][i][nh][n], 0, 0, 0);        \
+        }                                                                                                                  \
+        __builtin_amdgcn_s_setprio(0);                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+        __builtin_amdgcn_s_barrier();                                                                                      \
+    } while (0)
+
+    // ---- prologue: all of tile 0, then A0 and B0 of tile 1 (the two half-tiles phases 2 and 3 of the previous tile issue) ----
+    {
+        const KStep k0 = kstep_of(kbeg);
+        const KStep k1 = kstep_of(kbeg + (KT > 1 ? 1 : 0));
+        stage_a(0, 0, k0, true);
+        stage_b(0, 0, k0, true);
+        stage_b(0, 1, k0, true);
+        stage_a(0, 1, k0, true);
+        stage_a(1, 0, k1, KT > 1);
+        stage_b(1, 0, k1, KT > 1);
+        wait_vmcnt<APW + BPW>();
+        __builtin_amdgcn_s_barrier();
+        if (grp == 1) __builtin_amdgcn_s_barrier();  // stagger
+    }
+    KStep kn = kstep_of(kbeg + (KT > 1 ? 1 : 0));  // tile t+1
+    for (int t = 0; t < KT; ++t) {
+        const int cur = t & 1, nxt = cur ^ 1;
+        const bool live1 = t + 1 < KT, live2 = t + 2 < KT;
+        const KStep k2 = kstep_of(kbeg + (live2 ? t + 2 : 0));
+        // phase 0: quadrant (0,0)
+        read_a(cur, I0);
+        read_b(cur, I0, bf0);
+        stage_b(nxt, 1, kn, live1);
+        MFMA_QUADRANT(0, 0, bf0);
+        // phase 1: quadrant (0,1)
+        read_b(cur, I1, bf1);
+        stage_a(nxt, 1, kn, live1);
+        MFMA_QUADRANT(0, 1, bf1);
+        // phase 2: quadrant (1,1)
+        read_a(cur, I1);
+        stage_a(cur, 0, k2, live2);
+        MFMA_QUADRANT(1, 1, bf1);
+        // phase 3: quadrant (1,0); retire everything of tile t+1 (leaves A0, B0 of tile t+2 in flight)
+        stage_b(cur, 0, k2, live2);
+        wait_vmcnt<APW + BPW>();
+        MFMA_QUADRANT(1, 0, bf0);
+        kn = k2;
+    }
+#undef MFMA_QUADRANT
+    if (grp == 0) __builtin_amdgcn_s_barrier();  // un-stagger
+    wait_vmcnt<0>();                             // the tail's dummy pieces
+    __builtin_amdgcn_s_barrier();                // nobody reads or DMA-writes the ring any more
+
+    // ---------------------------------------------------------------- epilogue A: bf16 tile staged through LDS
+    const int l15 = lane & 15, lq = lane >> 4;
+    const bool staged = !g.c_f32 && !g.beta && gridDim.y == 1 && (g.ldc % 8) == 0 && ((uintptr_t)g.C & 15) == 0 &&
+                        (N % 8) == 0 && (!SWAP || (N % 4) == 0);
+    if (staged) {
+        constexpr int CSTR = BN * 2;  // bytes per staged row; 16-byte chunk c of row r lives at chunk c ^ (r & 15)
+        if (!SWAP) {  // fused 2x2 max-pool: registers 0..3 = the four pixels of one window, lane&15 = channel
+#pragma unroll
+            for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) {
+                            const int lcol = wc * WTN + nh * QN + n * 16 + l15;
+                            const int col = n0 + lcol;
+                            const float bias = (g.bias && col < N) ? g.bias[col] : 0.0f;
+                            const f32x4v a = acc[mh][i][nh][n];
+                            float v = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])) + bias;
+                            if (g.relu) v = fmaxf(v, 0.0f);
+                            const int prow = (wr * WTM + mh * QM + i * 16) / 4 + lq;
+                            const int pos = ((lcol >> 3) ^ (prow & 15)) * 16 + (lcol & 7) * 2;
+                            *reinterpret_cast<bf16_t *>(smem + prow * CSTR + pos) = (bf16_t)v;
+                        }
+        } else {  // lane&15 = row (pixel), registers 0..3 = four consecutive channels
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const int lcol = wc * WTN + nh * QN + n * 16 + lq * 4;
+                    const int col = n0 + lcol;
+                    f32x4v bias = f32x4v{0.f, 0.f, 0.f, 0.f};
+                    if (g.bias && col < N) bias = *reinterpret_cast<const f32x4v *>(g.bias + col);
+#pragma unroll
+                    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                        for (int i = 0; i < MT; ++i) {
+                            f32x4v a = acc[mh][i][nh][n] + bias;
+                            if (g.relu) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) a[r] = fmaxf(a[r], 0.0f);
+                            }
+                            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                            bf16x4 o;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) o[r] = (bf16_t)a[r];
+                            const int lrow = wr * WTM + mh * QM + i * 16 + l15;
+                            const int pos = ((lcol >> 3) ^ (lrow & 15)) * 16 + (lcol & 7) * 2;
+                            *reinterpret_cast<bf16x4 *>(smem + lrow * CSTR + pos) = o;
+                        }
+                }
+        }
+        __syncthreads();
+        const int rows_out = SWAP ? BM : BM / 4;
+        bf16_t *Cb = reinterpret_cast<bf16_t *>(g.C);
+        for (int idx = tid; idx < rows_out * CPR; idx += 512) {
+            const int lrow = idx / CPR, ch = idx - lrow * CPR;
+            const int col = n0 + ch * 8;
+            if (col >= N) continue;
+            int64_t off;
+            if (!SWAP) {
+                const int prow = (m0 >> 2) + lrow;
+                if (prow >= (M >> 2)) continue;
+                off = (int64_t)prow * g.ldc + col;
+            } else {
+                const int row = m0 + lrow;
+                if (row >= M) continue;
+                if (g.out_mode == GEMM_OUT_CONV) {
+                    const PixDecode p = decode_pixel(row, g.H, g.W);
+                    off = (((int64_t)p.n * g.H + p.y) * g.W + p.x) * g.ldc + col;
+                } else {
+                    off = (int64_t)row * g.ldc + col;
+                }
+            }
+            *reinterpret_cast<uint4 *>(Cb + off) = *reinterpret_cast<const uint4 *>(smem + lrow * CSTR + ((ch ^ (lrow & 15)) << 4));
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------- epilogue B: direct stores (f32 / accumulate / split-K / odd N)
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const f32x4v a = acc[mh][i][nh][n];
+                    const int rb = m0 + wr * WTM + mh * QM + i * 16, cb = n0 + wc * WTN + nh * QN + n * 16;
+                    if (!SWAP) {  // pool: rows rb + 4 lq .. +3 are one window, col cb + l15
+                        const int col = cb + l15, row = rb + 4 * lq;
+                        if (col >= N || row >= M) continue;
+                        float v = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])) + (g.bias ? g.bias[col] : 0.0f);
+                        if (g.relu) v = fmaxf(v, 0.0f);
+                        const int64_t off = (int64_t)(row >> 2) * g.ldc + col;
+                        if (g.c_f32)
+                            reinterpret_cast<float *>(g.C)[off] = v;
+                        else
+                            reinterpret_cast<bf16_t *>(g.C)[off] = (bf16_t)v;
+                        continue;
+                    }
+                    const int row = rb + l15, col0 = cb + 4 * lq;
+                    if (row >= M || col0 >= N) continue;
+                    int64_t off0;
+                    if (g.out_mode == GEMM_OUT_CONV) {
+                        const PixDecode p = decode_pixel(row, g.H, g.W);
+                        off0 = (((int64_t)p.n * g.H + p.y) * g.W + p.x) * g.ldc + col0;
+                    } else {
+                        off0 = (int64_t)row * g.ldc + col0;
+                    }
+                    const bool vec = g.c_f32 && col0 + 3 < N && ((off0 & 3) == 0) && (((uintptr_t)g.C & 15) == 0) && gridDim.y == 1;
+                    if (vec) {
+                        f32x4v v = a;
+                        if (g.bias) v += *reinterpret_cast<const f32x4v *>(g.bias + col0);  // bias + col0: 16-byte aligned when col0 % 4 == 0
+                        float *c = reinterpret_cast<float *>(g.C) + off0;
+                        if (g.beta) v += *reinterpret_cast<const f32x4v *>(c);
+                        if (g.relu) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
+                        }
+                        *reinterpret_cast<f32x4v *>(c) = v;
+                        continue;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (col0 + r >= N) continue;
+                        float v = a[r] + ((g.bias && blockIdx.y == 0) ? g.bias[col0 + r] : 0.0f);
+                        if (gridDim.y > 1) {  // split-K (launcher guarantees c_f32, PLAIN, no relu, C zeroed unless beta)
+                            atomicAdd(reinterpret_cast<float *>(g.C) + off0 + r, v);
+                        } else if (g.c_f32) {
+                            float *c = reinterpret_cast<float *>(g.C) + off0 + r;
+                            if (g.beta) v += *c;
+                            if (g.relu) v = fmaxf(v, 0.0f);
+                            *c = v;
+                        } else {
+                            bf16_t *c = reinterpret_cast<bf16_t *>(g.C) + off0 + r;
+                            if (g.beta) v += (float)*c;
+                            if (g.relu) v = fmaxf(v, 0.0f);
+                            *c = (bf16_t)v;
+                        }
+                    }
+                }
+}
+
+template <int WM, int WN, int MT, int NT, int AMODE, bool SWAP> hipError_t launch_one(hipStream_t s, const GemmArgs &g, int splitk) {
+    constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
+    constexpr int ring = 2 * (BM + BN) * 128, ctile = BM * BN * 2;
+    constexpr int lds = ring > ctile ? ring : ctile;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    static bool attr_done = false;
+    auto kern = gemm8p_kernel<WM, WN, MT, NT, AMODE, SWAP>;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    const int64_t blocks = (int64_t)cdiv(g.M, BM) * cdiv(g.N, BN);
+    if (blocks <= 0 || blocks > 0x7FFFFFFF) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)splitk), dim3(512), lds, s, g);
+    return hipGetLastError();
+}
+
+template <int AMODE, bool SWAP> hipError_t dispatch(hipStream_t s, const GemmArgs &g, int cfg) {
+    switch (cfg) {
+        case 0: return launch_one<2, 4, 4, 2, AMODE, SWAP>(s, g, 1);  // 256 x 256
+        case 1: return launch_one<4, 2, 2, 2, AMODE, SWAP>(s, g, 1);  // 256 x 128
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace
+
+// Tile menu of the phase-interleaved path: 256 x 256 when that gives the chip >= 200 workgroups or N > 128, else 256 x 128.
+int gemm_8p_config(const GemmArgs &g, int64_t *blocks) {
+    if (!gemm_glds_eligible(g) || g.M < 256 || g.N < 128) return -1;
+    const int kt = (g.a_mode == GEMM_A_CONV3) ? 9 * (g.Cin / 64) : g.K / 64;
+    if (kt < 2) return -1;
+    const int64_t b0 = (int64_t)cdiv(g.M, 256) * cdiv(g.N, 256), b1 = (int64_t)cdiv(g.M, 256) * cdiv(g.N, 128);
+    int cfg = (g.N > 128 && (b0 >= 200 || g.N % 256 == 0 || g.N > 384)) ? 0 : 1;
+    if (cfg == 0 && b0 < 200 && b1 >= 200) cfg = 1;
+    *blocks = cfg == 0 ? b0 : b1;
+    return cfg;
+}
+
+hipError_t launch_gemm_8p(hipStream_t stream, const GemmArgs &g) {
+    int64_t blocks = 0;
+    const int cfg = gemm_8p_config(g, &blocks);
+    if (cfg < 0) return hipErrorInvalidValue;
+    const bool swap = g.out_mode != GEMM_OUT_POOL;
+    if (g.a_mode == GEMM_A_CONV3)
+        return swap ? dispatch<GEMM_A_CONV3, true>(stream, g, cfg) : dispatch<GEMM_A_CONV3, false>(stream, g, cfg);
+    return swap ? dispatch<GEMM_A_PLAIN, true>(stream, g, cfg) : dispatch<GEMM_A_PLAIN, false>(stream, g, cfg);
+}

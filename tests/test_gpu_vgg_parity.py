@@ -57,6 +57,34 @@ def test_conv_layers_vs_oracle(dtype, tol, shape, glds, monkeypatch):
     assert (got_lin < 0).any() and rel_max_err(got_lin, ref_lin) <= tol
 
 
+@pytest.mark.parametrize("shape", [(16, 64, 256, 2), (28, 64, 128, 3), (12, 128, 136, 3), (10, 64, 384, 5), (8, 192, 512, 9),
+                                   (6, 64, 200, 8)])
+def test_conv_phase_interleaved_kernel_vs_oracle(shape, monkeypatch):
+    # gemm_8p.hip (256x256 / 256x128 tiles, 16x16x32 MFMA, two staggered wave groups) forced on even for small grids:
+    # full / partial M tiles, N tails, both epilogues (swapped plain, fused pool); and the same layer with the kernel off.
+    S, Cin, Cout, N = shape
+    rng = np.random.default_rng(S * 77 + Cout)
+    x = rng.standard_normal((S, S, Cin, N)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, Cin, Cout)) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    ref = orc.conv3x3(x, w, b, relu=True)
+    refp = orc.pool2(ref)
+    ref_lin = orc.conv3x3(x, w, b, relu=False)
+    outs = {}
+    for knob in ("force", "0"):
+        monkeypatch.setenv("LRCN_8P", knob)
+        ctx = small_ctx(lrcn_amd.LRCN_BF16)
+        got = L.from_jl(L.conv3x3(ctx, L.to_jl(x), L.to_jl(w), torch.as_tensor(b).cuda(), relu=True, pool=False))
+        gotp = L.from_jl(L.conv3x3(ctx, L.to_jl(x), L.to_jl(w), torch.as_tensor(b).cuda(), relu=True, pool=True))
+        got_lin = L.from_jl(L.conv3x3(ctx, L.to_jl(x), L.to_jl(w), torch.as_tensor(b).cuda(), relu=False, pool=False))
+        assert rel_max_err(got, ref) <= 2e-2 and rel_max_err(gotp, refp) <= 2e-2 and rel_max_err(got_lin, ref_lin) <= 2e-2
+        outs[knob] = (got, gotp, got_lin)
+        ctx.close()
+    # same bf16 operands, f32 accumulation in a different order: the two kernels agree to bf16 output rounding
+    for a, c in zip(outs["force"], outs["0"]):
+        assert rel_max_err(a, c) <= 1e-2
+
+
 def test_preprocess_u8_bit_exact():
     rng = np.random.default_rng(4)
     img = rng.integers(0, 256, size=(3, 224, 224, 3), dtype=np.uint8)
