@@ -438,6 +438,7 @@ template <int AMODE, bool SWAP> hipError_t dispatch(hipStream_t s, const GemmArg
     switch (cfg) {
         case 0: return launch_one<2, 4, 4, 2, AMODE, SWAP>(s, g, 1);  // 256 x 256
         case 1: return launch_one<4, 2, 2, 2, AMODE, SWAP>(s, g, 1);  // 256 x 128
+        case 2: return launch_one<4, 2, 4, 2, AMODE, SWAP>(s, g, 1);  // 512 x 128 (all 160 KiB of LDS)
         default: return hipErrorInvalidValue;
     }
 }
@@ -453,6 +454,11 @@ int gemm_8p_config(const GemmArgs &g, int64_t *blocks) {
     int cfg = (g.N > 128 && (b0 >= 200 || g.N % 256 == 0 || g.N > 384)) ? 0 : 1;
     if (cfg == 0 && b0 < 200 && b1 >= 200) cfg = 1;
     *blocks = cfg == 0 ? b0 : b1;
+    const char *t = getenv("LRCN_8P_TALL");  // kernel-development knob: 0 disables the 512 x 128 tile
+    if (cfg == 1 && g.N <= 128 && cdiv(g.M, 512) >= 400 && !(t && t[0] == '0')) {
+        cfg = 2;
+        *blocks = cdiv(g.M, 512);
+    }
     return cfg;
 }
 

@@ -23,6 +23,11 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ uint4 lds_read16(unsigned addr) {
+    uint4 r;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr) : "memory");
+    return r;
+}
 
 template <int WM, int WN, int TM, int TN, int AMODE, int NBUF>
 __global__ __launch_bounds__(WM *WN * 64) void gemm_glds_kernel(const GemmArgs g) {
@@ -139,6 +144,7 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_glds_kernel(const GemmArgs g
     };
 
     // fragment read offsets: lane (r = lane&31, hh = lane>>5) reads logical chunks 4hh..4hh+3 of its row
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
     int fo[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) fo[j] = (lane & 31) * 128 + ((((lane >> 5) * 4 + j) ^ (((lane & 31) >> 1) & 7)) << 4);
@@ -173,24 +179,35 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_glds_kernel(const GemmArgs g
         for (int p = 0; p < IPT; ++p) stage_piece(nxt % NBUF, kn, p, live);
         if (g.dbg & 2) continue;
         const int cur = kt % NBUF;
-        const unsigned char *As = smem + cur * BUF + (wm * TM * 32) * 128;
-        const unsigned char *Bs = smem + cur * BUF + A_BYTES + (wn * TN * 32) * 128;
-        uint4 bfr[TN][4];
+        // Fragment reads are inline asm: hipcc orders every ordinary LDS load behind ALL outstanding LDS-DMA with
+        // s_waitcnt vmcnt(0) (it cannot tell which ring slot a global_load_lds writes), which drained the ring at every
+        // K-step.  Ordering is by hand: the counted vmcnt + barrier above, counted lgkmcnt below.
+        const unsigned As = lds0 + cur * BUF + (wm * TM * 32) * 128;
+        const unsigned Bs = lds0 + cur * BUF + A_BYTES + (wn * TN * 32) * 128;
+        uint4 bfr[TN][4], af[2][4];
 #pragma unroll
         for (int n = 0; n < TN; ++n)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bfr[n][j] = *reinterpret_cast<const uint4 *>(Bs + n * 32 * 128 + fo[j]);
+            for (int j = 0; j < 4; ++j) bfr[n][j] = lds_read16(Bs + n * 32 * 128 + fo[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) af[0][j] = lds_read16(As + fo[j]);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            uint4 af[4];
+            if (i + 1 < TM) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) af[j] = *reinterpret_cast<const uint4 *>(As + i * 32 * 128 + fo[j]);
+                for (int j = 0; j < 4; ++j) af[(i + 1) & 1][j] = lds_read16(As + (i + 1) * 32 * 128 + fo[j]);
+                asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int n = 0; n < TN; ++n)
-                    acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[j]),
+                    acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i & 1][j]),
                                                                         __builtin_bit_cast(bf16x8, bfr[n][j]), acc[i][n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     wait_vmcnt<0>();  // the tail's dummy pieces
