@@ -1,0 +1,324 @@
+// conv64.hip -- 3x3 / pad 1 convolution + bias + ReLU (+ fused 2x2 max-pool) for the Cin = 64 layers of VGG-16
+// (conv1_2: 64 -> 64 with pool, conv2_1: 64 -> 128), bf16, gfx950.                     (lrcn.jl:724-726 convx/relux/poolx)
+//
+// Why a second convolution kernel: in the implicit-GEMM formulation (gemm_8p.hip) every input pixel is pulled L2 -> LDS
+// nine times (once per tap) and, with only 64..128 output channels to amortise it over, those layers are bound by the
+// LDS-DMA fill rate (~50 FLOP per staged byte), not by MFMA.  Here the reuse is made explicit:
+//   * a workgroup owns a 16 x 16 output-pixel tile x 64 output channels; the 18 x 18 x 64ch input PATCH (tile + halo,
+//     40.5 KiB) is DMA'd to LDS once (global_load_lds_dwordx4, zero page outside the image) and serves all nine taps:
+//     the A fragment of tap (kh,kw) is the same patch read at a shifted pixel -- 7x less staging traffic;
+//   * the weights never touch LDS: each wave keeps the B fragments of ALL nine taps for its 32 output channels in
+//     registers (144 VGPRs) for the whole persistent kernel, so LDS bandwidth is spent on A fragments only
+//     (8 ds_read_b128 per 16 MFMAs per wave = 50 % of the LDS read rate at full MFMA rate);
+//   * persistent workgroups walk the tiles; three patch buffers, the DMA of patch j+2 is issued while patch j is
+//     multiplied (counted s_waitcnt vmcnt, raw s_barrier, two barriers per patch);
+//   * no barrier inside the 9-tap loop (patch and weights are resident); waves 4..7 run one barrier (= half a patch)
+//     behind waves 0..3, so one wave of every SIMD is in MFMAs while its partner does the epilogue;
+//   * rows of a tile are in window-major order (DESIGN.md "conv rows"): with D = A x B the four accumulator registers of
+//     a lane are the four pixels of one 2x2 pool window (pool = 3 v_max); without pool D = B x A gives a lane 8 consecutive
+//     output channels of one pixel (one 16-byte store).  The channel <-> fragment-row permutation that makes those
+//     stores contiguous is free: it only changes which weight row a lane loads.
+// LDS patch image: pixel q = py*18 + px at q*128 bytes, 16-byte chunk c at position c ^ g(py,px),
+//   g = (((px >> 1) & 3) << 1) | (py & 1): conflict-free for the 16-lane groups of ds_read_b128 at every tap shift.
+#include <cstdlib>
+#include <type_traits>
+
+#include "common.h"
+#include "gemm.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int PATCH_BYTES = 48 * 1024;  // 48 DMA pieces of 1 KiB (41 carry pixels, the rest keep the per-wave count uniform)
+constexpr int NPIECE = 6;               // pieces per wave per patch
+constexpr int BIAS_OFF = 3 * PATCH_BYTES;
+constexpr int LDS_BYTES = BIAS_OFF + 64 * 4;
+
+struct Conv64Args {
+    const bf16_t *in;   // NHWC [N][H][W][64]
+    const bf16_t *w;    // [Cout][9][64]   (tap = kh*3 + kw)
+    const float *bias;  // [Cout]
+    bf16_t *out;        // NHWC [N][H][W][Cout] or pooled [N][H/2][W/2][Cout]
+    const void *zero_page;
+    int N, H, W, Cout, relu;
+    int tiles_y, tiles_x, ntiles;
+};
+
+template <int I, int N, class F> __device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+template <int OFF> __device__ __forceinline__ uint4 lds_read16(unsigned addr) {
+    uint4 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
+    return r;
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+
+// fragment row j (0..15) of n-tile n (0..1) of a wave's 32 output channels -> channel offset within those 32
+template <bool POOL> __device__ __forceinline__ int chan_of(int n, int j) {
+    return POOL ? 2 * j + n                           // lane = channel pair (2 l15, 2 l15 + 1): one 4-byte store
+                : (j >> 2) * 8 + n * 4 + (j & 3);     // lane (lq) = 8 consecutive channels: one 16-byte store
+}
+
+template <bool POOL> __global__ __launch_bounds__(512) void conv64_kernel(const Conv64Args a) {
+    constexpr int NST = POOL ? 4 : 4;  // global stores per wave per epilogue (the counted vmcnt below depends on it)
+    extern __shared__ __attribute__((aligned(128))) unsigned char smem[];  // K-half select is address ^ 64
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = wave & 3;   // pixel group: m-tiles 4 wp .. 4 wp + 3 of the 16 (window rows 2 wp, 2 wp + 1)
+    const int wq = wave >> 2;  // channel group (32 channels) AND stagger group
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int cc = blockIdx.y;  // 64-channel chunk of Cout
+    const int H = a.H, W = a.W;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
+
+    // ---- weights: B fragments of all 9 taps x 2 K-halves x 2 n-tiles, resident in registers ----
+    uint4 breg[9][2][2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const bf16_t *wr = a.w + (size_t)(cc * 64 + wq * 32 + chan_of<POOL>(n, l15)) * 576 + lq * 8;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) breg[t][s][n] = *reinterpret_cast<const uint4 *>(wr + t * 64 + s * 32);
+    }
+    if (tid < 64) reinterpret_cast<float *>(smem + BIAS_OFF)[tid] = a.bias ? a.bias[cc * 64 + tid] : 0.0f;
+
+    // ---- A-fragment read addresses: lane l15 = (window w, dy, dx) of an m-tile, lq = 16-byte K chunk ----
+    const int w_ = l15 >> 2, dy = (l15 >> 1) & 1, dx = l15 & 1, xl = 2 * w_ + dx;
+    unsigned areg[2][3];  // [kh parity][kw], K half 0; K half 1 = address ^ 64
+#pragma unroll
+    for (int yp = 0; yp < 2; ++yp)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int gsw = ((((xl + kw) >> 1) & 3) << 1) | ((dy + yp) & 1);
+            areg[yp][kw] = lds0 + ((4 * wp + dy) * 18 + xl) * 128 + ((lq ^ gsw) << 4);
+        }
+
+    // ---- DMA geometry: piece k = wave + 8 j covers patch pixels q = 8k .. 8k+7 (q = py*18 + px); lane -> (pixel, chunk) ----
+    int doff[NPIECE];
+    unsigned dflags = 0;  // 5 bits per piece: top, bottom, left, right halo row/column, not-a-pixel
+    const bf16_t *Zp = reinterpret_cast<const bf16_t *>(a.zero_page) + (lane & 7) * 8;
+#pragma unroll
+    for (int j = 0; j < NPIECE; ++j) {
+        const int q = (wave + 8 * j) * 8 + (lane >> 3);
+        const int py = q / 18, px = q - 18 * py;
+        const int gsw = (((px >> 1) & 3) << 1) | (py & 1);
+        doff[j] = ((py - 1) * W + (px - 1)) * 64 + (((lane & 7) ^ gsw) << 3);
+        const unsigned f = (py == 0 ? 1u : 0u) | (py == 17 ? 2u : 0u) | (px == 0 ? 4u : 0u) | (px == 17 ? 8u : 0u) | (q >= 324 ? 16u : 0u);
+        dflags |= f << (5 * j);
+    }
+    auto issue_patch = [&](int tile, int buf) {
+        // tile < 0: nothing left for this workgroup -- stage zeros so that every wave's vmcnt arithmetic stays uniform
+        const bool live = tile >= 0;
+        const int t = live ? tile : 0;
+        const int per_img = a.tiles_y * a.tiles_x;
+        const int n = t / per_img, r = t - n * per_img;
+        const int ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
+        const int origin = ((n * H + ty * 16) * W + tx * 16) * 64;
+        const unsigned edge = (ty == 0 ? 1u : 0u) | (ty == a.tiles_y - 1 ? 2u : 0u) | (tx == 0 ? 4u : 0u) | (tx == a.tiles_x - 1 ? 8u : 0u) |
+                              16u | (live ? 0u : 15u);
+#pragma unroll
+        for (int j = 0; j < NPIECE; ++j) {
+            const bool bad = ((dflags >> (5 * j)) & edge) != 0;
+            const bf16_t *src = bad ? Zp : a.in + (origin + doff[j]);
+            __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(smem + buf * PATCH_BYTES + (wave + 8 * j) * 1024), 16, 0, 0);
+        }
+    };
+
+    const int G = gridDim.x, b0 = blockIdx.x;
+    const int my_tiles = (a.ntiles - b0 + G - 1) / G;  // tiles b0, b0 + G, ...  (>= 1: the launcher keeps G <= ntiles)
+    auto tile_at = [&](int j) { return j < my_tiles ? b0 + j * G : -1; };
+
+    f32x4v acc[4][2];
+    uint4 af[2][4];
+
+    // ---- prologue: patches 0 and 1 ----
+    issue_patch(tile_at(0), 0);
+    issue_patch(tile_at(1), 1);
+    wait_vmcnt<0>();
+    __syncthreads();                              // patches 0, 1 and the bias are visible (no DMA in flight here)
+    if (wq == 1) __builtin_amdgcn_s_barrier();    // stagger
+
+    for (int j = 0; j < my_tiles; ++j) {
+        const int buf = j % 3;
+        const unsigned boff = buf * PATCH_BYTES;
+        unsigned ar[2][3][2];
+#pragma unroll
+        for (int yp = 0; yp < 2; ++yp)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                ar[yp][kw][0] = areg[yp][kw] + boff;
+                ar[yp][kw][1] = ar[yp][kw][0] ^ 64u;
+            }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) acc[i][n] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+        // half-tap h = 2*tap + s; reads of h+1 are issued before the MFMAs of h
+        auto read_half = [&](auto hc) {
+            constexpr int h = decltype(hc)::value;
+            constexpr int t = h >> 1, s = h & 1, kh = t / 3, kw = t % 3;
+            const unsigned ad = ar[kh & 1][kw][s];
+            static_for<0, 4>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                af[h & 1][i] = lds_read16<((2 * (i / 2) + kh) * 18 + 8 * (i % 2) + kw) * 128>(ad);
+            });
+        };
+        auto mfma_half = [&](auto hc) {
+            constexpr int h = decltype(hc)::value;
+            constexpr int t = h >> 1, s = h & 1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const bf16x8 av = __builtin_bit_cast(bf16x8, af[h & 1][i]);
+                    const bf16x8 bv = __builtin_bit_cast(bf16x8, breg[t][s][n]);
+                    acc[i][n] = POOL ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[i][n], 0, 0, 0)
+                                     : __builtin_amdgcn_mfma_f32_16x16x32_bf16(bv, av, acc[i][n], 0, 0, 0);
+                }
+        };
+        auto run_halves = [&](auto lo, auto hi) {  // half-taps [lo, hi); the reads of `lo` are already in flight
+            constexpr int LO = decltype(lo)::value, HI = decltype(hi)::value;
+            static_for<LO, HI>([&](auto hc) {
+                constexpr int h = decltype(hc)::value;
+                if constexpr (h + 1 < 18) {
+                    read_half(std::integral_constant<int, h + 1>{});
+                    wait_lgkm<4>();
+                } else {
+                    wait_lgkm<0>();
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+                mfma_half(hc);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+
+        // ---------------- first half of the patch ----------------
+        if (wq == 1) issue_patch(tile_at(j + 2), (j + 2) % 3);
+        read_half(std::integral_constant<int, 0>{});
+        run_halves(std::integral_constant<int, 0>{}, std::integral_constant<int, 9>{});
+        if (wq == 1) wait_vmcnt<NPIECE + NST>();  // retires this wave's pieces of patch j+1
+        __builtin_amdgcn_s_barrier();
+        // ---------------- second half ----------------
+        if (wq == 0) issue_patch(tile_at(j + 2), (j + 2) % 3);
+        run_halves(std::integral_constant<int, 9>{}, std::integral_constant<int, 18>{});
+        if (wq == 0) wait_vmcnt<NPIECE + NST>();
+
+        // ---------------- epilogue: bias, ReLU, (pool), store ----------------
+        {
+            const int tile = b0 + j * G;
+            const int per_img = a.tiles_y * a.tiles_x;
+            const int n_img = tile / per_img, r = tile - n_img * per_img;
+            const int ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
+            if (POOL) {
+                // lane: channels (2 l15, 2 l15 + 1) of the wave's 32; registers = the 4 pixels of window lq of m-tile 4 wp + i
+                float b0v, b1v;
+                {
+                    const unsigned ba = lds0 + BIAS_OFF + (wq * 32 + 2 * l15) * 4;
+                    uint2 bb;
+                    asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(bb) : "v"(ba) : "memory");
+                    b0v = __builtin_bit_cast(float, bb.x);
+                    b1v = __builtin_bit_cast(float, bb.y);
+                }
+                const int Ho = H >> 1, Wo = W >> 1;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int widx = (4 * wp + i) * 4 + lq;  // window index in the tile (8 x 8 windows)
+                    const int oy = ty * 8 + (widx >> 3), ox = tx * 8 + (widx & 7);
+                    float v0 = fmaxf(fmaxf(acc[i][0][0], acc[i][0][1]), fmaxf(acc[i][0][2], acc[i][0][3])) + b0v;
+                    float v1 = fmaxf(fmaxf(acc[i][1][0], acc[i][1][1]), fmaxf(acc[i][1][2], acc[i][1][3])) + b1v;
+                    if (a.relu) {
+                        v0 = fmaxf(v0, 0.0f);
+                        v1 = fmaxf(v1, 0.0f);
+                    }
+                    bf16x2 o;
+                    o[0] = (bf16_t)v0;
+                    o[1] = (bf16_t)v1;
+                    bf16_t *dst = a.out + ((size_t)(n_img * Ho + oy) * Wo + ox) * a.Cout + cc * 64 + wq * 32 + 2 * l15;
+                    *reinterpret_cast<bf16x2 *>(dst) = o;
+                }
+            } else {
+                // lane: pixel l15 of m-tile 4 wp + i; registers of n-tile n = channels lq*8 + n*4 + (0..3)
+                f32x4v bv0, bv1;
+                {
+                    const unsigned ba = lds0 + BIAS_OFF + (wq * 32 + lq * 8) * 4;
+                    uint4 x0, x1;
+                    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(x0), "=&v"(x1)
+                                 : "v"(ba)
+                                 : "memory");
+                    bv0 = __builtin_bit_cast(f32x4v, x0);
+                    bv1 = __builtin_bit_cast(f32x4v, x1);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int mt = 4 * wp + i;
+                    const int y = ty * 16 + 2 * (mt >> 1) + dy, x = tx * 16 + 8 * (mt & 1) + xl;
+                    f32x4v u0 = acc[i][0] + bv0, u1 = acc[i][1] + bv1;
+                    typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+                    bf16x8v o;
+#pragma unroll
+                    for (int r2 = 0; r2 < 4; ++r2) {
+                        float p0 = u0[r2], p1 = u1[r2];
+                        if (a.relu) {
+                            p0 = fmaxf(p0, 0.0f);
+                            p1 = fmaxf(p1, 0.0f);
+                        }
+                        o[r2] = (bf16_t)p0;
+                        o[4 + r2] = (bf16_t)p1;
+                    }
+                    bf16_t *dst = a.out + ((size_t)(n_img * H + y) * W + x) * a.Cout + cc * 64 + wq * 32 + lq * 8;
+                    *reinterpret_cast<bf16x8v *>(dst) = o;
+                }
+            }
+        }
+        __builtin_amdgcn_s_barrier();
+    }
+    if (wq == 0) __builtin_amdgcn_s_barrier();  // un-stagger
+    wait_vmcnt<0>();
+}
+
+}  // namespace
+
+bool conv64_eligible(int dtype, int Cin, int Cout, int H, int W) {
+    return dtype == GEMM_T_BF16 && Cin == 64 && Cout % 64 == 0 && Cout >= 64 && H % 16 == 0 && W % 16 == 0 && H >= 16 && W >= 16;
+}
+
+hipError_t launch_conv64(hipStream_t stream, const void *in, const void *w, const float *bias, void *out, int N, int H, int W, int Cout,
+                         int relu, int pool, const void *zero_page) {
+    if (!conv64_eligible(GEMM_T_BF16, 64, Cout, H, W) || !in || !w || !out || !zero_page || N < 1) return hipErrorInvalidValue;
+    if ((int64_t)N * H * W * 64 >= (1ll << 31)) return hipErrorInvalidValue;  // 32-bit element offsets into the input
+    Conv64Args a{};
+    a.in = reinterpret_cast<const bf16_t *>(in);
+    a.w = reinterpret_cast<const bf16_t *>(w);
+    a.bias = bias;
+    a.out = reinterpret_cast<bf16_t *>(out);
+    a.zero_page = zero_page;
+    a.N = N; a.H = H; a.W = W; a.Cout = Cout; a.relu = relu;
+    a.tiles_y = H / 16; a.tiles_x = W / 16; a.ntiles = N * a.tiles_y * a.tiles_x;
+    const int chunks = Cout / 64;
+    int gx = 256 / chunks;  // one workgroup per CU (all of LDS)
+    if (gx > a.ntiles) gx = a.ntiles;
+    static bool attr_done[2] = {false, false};
+    auto kern = pool ? conv64_kernel<true> : conv64_kernel<false>;
+    if (!attr_done[pool ? 1 : 0]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_done[pool ? 1 : 0] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)chunks), dim3(512), LDS_BYTES, stream, a);
+    return hipGetLastError();
+}

@@ -41,3 +41,9 @@ int64_t gemm_glds_blocks(const GemmArgs &g);  // workgroups the direct-to-LDS pa
 // barrier apart.  gemm_8p_config returns the tile config (>= 0) and the grid size, or -1 when the problem does not fit it.
 int gemm_8p_config(const GemmArgs &g, int64_t *blocks);
 hipError_t launch_gemm_8p(hipStream_t stream, const GemmArgs &g);
+
+// Halo-patch convolution for the Cin = 64 layers (conv64.hip): NHWC bf16 in/out, weights [Cout][9][64], H and W multiples
+// of 16, Cout a multiple of 64; bias + optional ReLU + optional fused 2x2 max-pool.
+bool conv64_eligible(int dtype, int Cin, int Cout, int H, int W);
+hipError_t launch_conv64(hipStream_t stream, const void *in, const void *w, const float *bias, void *out, int N, int H, int W, int Cout,
+                         int relu, int pool, const void *zero_page);

@@ -783,7 +783,16 @@ int lrcn_vgg_load(lrcn_ctx *c, const float *const cw[13], const float *const cb[
 }
 
 namespace {
+bool conv64_enabled() {
+    const char *k = getenv("LRCN_CONV64");  // LRCN_CONV64=0 routes the Cin = 64 layers back to the implicit-GEMM kernels
+    return !(k && k[0] == '0');
+}
 int conv_layer(lrcn_ctx *c, int dtype, const void *in, const VggLayer &L, int N, void *out) {
+    if (conv64_enabled() && conv64_eligible(dtype, L.Cin, L.Cout, L.S, L.S)) {
+        hipError_t e = launch_conv64(c->stream, in, L.w, L.b, out, N, L.S, L.S, L.Cout, 1, L.pool, c->zero_page);
+        if (e != hipSuccess) FAIL(c, LRCN_EHIP, "conv64 layer S=%d Cout=%d: %s", L.S, L.Cout, hipGetErrorString(e));
+        return LRCN_OK;
+    }
     GemmArgs g{};
     g.dtype = dtype;
     g.A = in;
@@ -1014,6 +1023,16 @@ int lrcn_conv3x3(lrcn_ctx *c, const float *x, int W, int H, int Cin, int N, cons
     (void)hipMemcpyAsync(bd, b, sizeof(float) * Cout, hipMemcpyDeviceToDevice, c->stream);
     k_ref_to_nhwc(c->stream, vdt, x, W, H, Cin, N, xin, Cp);
     k_repack_conv_w(c->stream, vdt, w, Cin, Cout, Cp, wp);
+    if (conv64_enabled() && conv64_eligible(vdt, Cp, Cout, H, W)) {
+        hipError_t e = launch_conv64(c->stream, xin, wp, bd, out, N, H, W, Cout, relu, pool, c->zero_page);
+        if (e == hipSuccess) {
+            k_nhwc_to_ref(c->stream, vdt, out, Wo, Ho, Cout, N, Cout, y);
+            e = hipGetLastError();
+        }
+        cleanup();
+        if (e != hipSuccess) FAIL(c, LRCN_EHIP, "conv3x3 (conv64): %s", hipGetErrorString(e));
+        return LRCN_OK;
+    }
     GemmArgs g{};
     g.dtype = vdt;
     g.A = xin;

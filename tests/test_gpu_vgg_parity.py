@@ -85,6 +85,33 @@ def test_conv_phase_interleaved_kernel_vs_oracle(shape, monkeypatch):
         assert rel_max_err(a, c) <= 1e-2
 
 
+@pytest.mark.parametrize("shape", [(16, 16, 64, 3), (32, 32, 128, 2), (48, 16, 64, 5), (16, 64, 192, 1), (32, 32, 64, 11)])
+def test_conv64_halo_patch_kernel_vs_oracle(shape, monkeypatch):
+    # conv64.hip (Cin = 64: 18x18 halo patch in LDS, weights register-resident, persistent tiles, 3 patch buffers):
+    # image borders, tile borders inside an image, several 64-channel chunks, more tiles than one pass of the ring
+    # (N = 11 -> 44 tiles), W != H; against the oracle and against the implicit-GEMM kernels on the same operands.
+    W, H, Cout, N = shape
+    rng = np.random.default_rng(W * 31 + H + Cout)
+    x = rng.standard_normal((W, H, 64, N)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 64, Cout)) * np.sqrt(2.0 / (9 * 64))).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    ref = orc.conv3x3(x, w, b, relu=True)
+    refp = orc.pool2(ref)
+    ref_lin = orc.conv3x3(x, w, b, relu=False)
+    outs = {}
+    for knob in ("1", "0"):
+        monkeypatch.setenv("LRCN_CONV64", knob)
+        ctx = small_ctx(lrcn_amd.LRCN_BF16)
+        got = L.from_jl(L.conv3x3(ctx, L.to_jl(x), L.to_jl(w), torch.as_tensor(b).cuda(), relu=True, pool=False))
+        gotp = L.from_jl(L.conv3x3(ctx, L.to_jl(x), L.to_jl(w), torch.as_tensor(b).cuda(), relu=True, pool=True))
+        got_lin = L.from_jl(L.conv3x3(ctx, L.to_jl(x), L.to_jl(w), torch.as_tensor(b).cuda(), relu=False, pool=False))
+        assert rel_max_err(got, ref) <= 2e-2 and rel_max_err(gotp, refp) <= 2e-2 and rel_max_err(got_lin, ref_lin) <= 2e-2
+        outs[knob] = (got, gotp, got_lin)
+        ctx.close()
+    for a, c in zip(outs["1"], outs["0"]):
+        assert rel_max_err(a, c) <= 1e-2
+
+
 def test_preprocess_u8_bit_exact():
     rng = np.random.default_rng(4)
     img = rng.integers(0, 256, size=(3, 224, 224, 3), dtype=np.uint8)
