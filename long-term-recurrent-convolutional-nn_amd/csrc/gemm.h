@@ -25,6 +25,8 @@ struct GemmArgs {
     int H, W, Cin;  // conv geometry (square-agnostic; H, W even)
     int dbg;                // kernel-development ablation flags (LRCN_DBG env): 1 = skip steady-state DMA, 2 = skip LDS reads + MFMA
     const void *zero_page;  // >= 256 zero bytes, 16-byte aligned (source of padding rows for the direct-to-LDS path) or NULL
+    void *ws;               // split-K workspace (f32 slabs [slices][M][N]) or NULL: enables gemm_8p's split-K form
+    size_t ws_bytes;
 };
 
 // Requirements (checked): A/B base 16-byte aligned, lda/ldb multiples of the 16-byte chunk (4 f32 / 8 bf16),
@@ -40,7 +42,8 @@ int64_t gemm_glds_blocks(const GemmArgs &g);  // workgroups the direct-to-LDS pa
 // Phase-interleaved variant (gemm_8p.hip): 256 x 256 / 256 x 128 tiles, v_mfma_f32_16x16x32_bf16, two wave groups one
 // barrier apart.  gemm_8p_config returns the tile config (>= 0) and the grid size, or -1 when the problem does not fit it.
 int gemm_8p_config(const GemmArgs &g, int64_t *blocks);
-hipError_t launch_gemm_8p(hipStream_t stream, const GemmArgs &g);
+int gemm_8p_splitk(const GemmArgs &g, int64_t *blocks);  // split-K slices for skinny problems (0 = not applicable)
+hipError_t launch_gemm_8p(hipStream_t stream, const GemmArgs &g, int splitk = 1);
 
 // Halo-patch convolution for the Cin = 64 layers (conv64.hip): NHWC bf16 in/out, weights [Cout][9][64], H and W multiples
 // of 16, Cout a multiple of 64; bias + optional ReLU + optional fused 2x2 max-pool.

@@ -350,7 +350,26 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs g) {
         return;
     }
 
-    // ---------------------------------------------------------------- epilogue B: direct stores (f32 / accumulate / split-K / odd N)
+    // ---------------------------------------------------------------- split-K: this slice's partial tile -> its f32 slab
+    if (gridDim.y > 1) {
+        if constexpr (SWAP) {
+            float *slab = reinterpret_cast<float *>(g.ws) + (size_t)blockIdx.y * M * N;
+#pragma unroll
+            for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) {
+                            const int row = m0 + wr * WTM + mh * QM + i * 16 + l15, col0 = n0 + wc * WTN + nh * QN + n * 16 + 4 * lq;
+                            if (row < M && col0 < N) *reinterpret_cast<f32x4v *>(slab + (size_t)row * N + col0) = acc[mh][i][nh][n];
+                        }
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------- epilogue B: direct stores (f32 / accumulate / odd N)
 #pragma unroll
     for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
@@ -382,7 +401,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs g) {
                     } else {
                         off0 = (int64_t)row * g.ldc + col0;
                     }
-                    const bool vec = g.c_f32 && col0 + 3 < N && ((off0 & 3) == 0) && (((uintptr_t)g.C & 15) == 0) && gridDim.y == 1;
+                    const bool vec = g.c_f32 && col0 + 3 < N && ((off0 & 3) == 0) && (((uintptr_t)g.C & 15) == 0);
                     if (vec) {
                         f32x4v v = a;
                         if (g.bias) v += *reinterpret_cast<const f32x4v *>(g.bias + col0);  // bias + col0: 16-byte aligned when col0 % 4 == 0
@@ -398,10 +417,8 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs g) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         if (col0 + r >= N) continue;
-                        float v = a[r] + ((g.bias && blockIdx.y == 0) ? g.bias[col0 + r] : 0.0f);
-                        if (gridDim.y > 1) {  // split-K (launcher guarantees c_f32, PLAIN, no relu, C zeroed unless beta)
-                            atomicAdd(reinterpret_cast<float *>(g.C) + off0 + r, v);
-                        } else if (g.c_f32) {
+                        float v = a[r] + (g.bias ? g.bias[col0 + r] : 0.0f);
+                        if (g.c_f32) {
                             float *c = reinterpret_cast<float *>(g.C) + off0 + r;
                             if (g.beta) v += *c;
                             if (g.relu) v = fmaxf(v, 0.0f);
@@ -434,11 +451,11 @@ template <int WM, int WN, int MT, int NT, int AMODE, bool SWAP> hipError_t launc
     return hipGetLastError();
 }
 
-template <int AMODE, bool SWAP> hipError_t dispatch(hipStream_t s, const GemmArgs &g, int cfg) {
+template <int AMODE, bool SWAP> hipError_t dispatch(hipStream_t s, const GemmArgs &g, int cfg, int splitk) {
     switch (cfg) {
-        case 0: return launch_one<2, 4, 4, 2, AMODE, SWAP>(s, g, 1);  // 256 x 256
-        case 1: return launch_one<4, 2, 2, 2, AMODE, SWAP>(s, g, 1);  // 256 x 128
-        case 2: return launch_one<4, 2, 4, 2, AMODE, SWAP>(s, g, 1);  // 512 x 128 (all 160 KiB of LDS)
+        case 0: return launch_one<2, 4, 4, 2, AMODE, SWAP>(s, g, splitk);  // 256 x 256
+        case 1: return launch_one<4, 2, 2, 2, AMODE, SWAP>(s, g, splitk);  // 256 x 128
+        case 2: return launch_one<4, 2, 4, 2, AMODE, SWAP>(s, g, splitk);  // 512 x 128 (all 160 KiB of LDS)
         default: return hipErrorInvalidValue;
     }
 }
@@ -462,12 +479,71 @@ int gemm_8p_config(const GemmArgs &g, int64_t *blocks) {
     return cfg;
 }
 
-hipError_t launch_gemm_8p(hipStream_t stream, const GemmArgs &g) {
+// Split-K plan for skinny problems (few 256-row tiles, long K: fc6/fc7, the image-embedding and dH GEMMs): 256 x 128
+// tiles, K cut into `splits` slices of >= 8 K-tiles so that tiles * splits ~ one workgroup per CU.  Each slice writes its
+// partial tile to an f32 slab with 16-byte stores; splitk_reduce_kernel then sums the slabs and applies bias / accumulate
+// / ReLU / output type.  (f32 atomics instead of slabs were 8x slower here: 16 scattered rows per wave instruction.)
+// Returns the number of slices (0 = not applicable).
+int gemm_8p_splitk(const GemmArgs &g, int64_t *blocks) {
+    if (!gemm_glds_eligible(g) || g.M < 256 || g.N < 128 || (g.N % 4) || g.a_mode != GEMM_A_PLAIN || g.out_mode != GEMM_OUT_PLAIN) return 0;
+    if (!g.ws || (g.ldc % 4) || ((uintptr_t)g.C & 15)) return 0;
+    const int kt = g.K / 64;
+    const int64_t b1 = (int64_t)cdiv(g.M, 256) * cdiv(g.N, 128);
+    int s = (int)(256 / b1);
+    if (s > kt / 8) s = kt / 8;
+    if (s > 16) s = 16;
+    while (s >= 2 && (size_t)s * g.M * g.N * sizeof(float) > g.ws_bytes) --s;
+    if (s < 2) return 0;
+    *blocks = b1 * s;
+    return s;
+}
+
+namespace {
+template <typename T> __global__ void splitk_reduce_kernel(const float *ws, int S, int M, int N, const float *bias, int beta, int relu,
+                                                            void *C, int64_t ldc, int c_f32) {
+    const int n4 = N >> 2;
+    const int64_t total = (int64_t)M * n4;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(idx / n4), c4 = (int)(idx - (int64_t)m * n4) * 4;
+        f32x4v v = *reinterpret_cast<const f32x4v *>(ws + (size_t)m * N + c4);
+        for (int s = 1; s < S; ++s) v += *reinterpret_cast<const f32x4v *>(ws + ((size_t)s * M + m) * N + c4);
+        if (bias) v += *reinterpret_cast<const f32x4v *>(bias + c4);
+        if (c_f32) {
+            float *c = reinterpret_cast<float *>(C) + (int64_t)m * ldc + c4;
+            if (beta) v += *reinterpret_cast<const f32x4v *>(c);
+            if (relu)
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
+            *reinterpret_cast<f32x4v *>(c) = v;
+        } else {
+            T *c = reinterpret_cast<T *>(C) + (int64_t)m * ldc + c4;
+            for (int r = 0; r < 4; ++r) {
+                float x = v[r] + (beta ? to_f32(c[r]) : 0.0f);
+                if (relu) x = fmaxf(x, 0.0f);
+                c[r] = from_f32<T>(x);
+            }
+        }
+    }
+}
+}  // namespace
+
+hipError_t launch_gemm_8p(hipStream_t stream, const GemmArgs &g, int splitk) {
     int64_t blocks = 0;
-    const int cfg = gemm_8p_config(g, &blocks);
+    int cfg = gemm_8p_config(g, &blocks);
     if (cfg < 0) return hipErrorInvalidValue;
+    if (splitk > 1) {
+        if (gemm_8p_splitk(g, &blocks) != splitk) return hipErrorInvalidValue;
+        hipError_t e = dispatch<GEMM_A_PLAIN, true>(stream, g, 1, splitk);
+        if (e != hipSuccess) return e;
+        const int64_t total = (int64_t)g.M * (g.N >> 2);
+        const int grid = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+        hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, reinterpret_cast<const float *>(g.ws), splitk,
+                           g.M, g.N, g.bias, g.beta, g.relu, g.C, g.ldc, g.c_f32);
+        return hipGetLastError();
+    } else {
+        splitk = 1;
+    }
     const bool swap = g.out_mode != GEMM_OUT_POOL;
     if (g.a_mode == GEMM_A_CONV3)
-        return swap ? dispatch<GEMM_A_CONV3, true>(stream, g, cfg) : dispatch<GEMM_A_CONV3, false>(stream, g, cfg);
-    return swap ? dispatch<GEMM_A_PLAIN, true>(stream, g, cfg) : dispatch<GEMM_A_PLAIN, false>(stream, g, cfg);
+        return swap ? dispatch<GEMM_A_CONV3, true>(stream, g, cfg, splitk) : dispatch<GEMM_A_CONV3, false>(stream, g, cfg, splitk);
+    return swap ? dispatch<GEMM_A_PLAIN, true>(stream, g, cfg, splitk) : dispatch<GEMM_A_PLAIN, false>(stream, g, cfg, splitk);
 }

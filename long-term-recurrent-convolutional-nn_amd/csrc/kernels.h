@@ -53,6 +53,9 @@ void k_transpose(hipStream_t st, int dtype, int in_f32, const void *in, int64_t 
 void k_transpose_f32(hipStream_t st, const float *in, int64_t ld_in, int R, int C, float *out, int64_t ld_out);
 // out[r][c] = (T) in[r*ld_in + c]  (f32 -> T copy of a sub-matrix; pads [C, ld_out) with zeros)
 void k_cast_rows(hipStream_t st, int dtype, const float *in, int64_t ld_in, int R, int C, void *out, int64_t ld_out);
+// out[r][c] = (T) act(in[r][c] + bias[c])  (epilogue of a split-K GEMM whose partial sums were combined in f32)
+void k_bias_act_cast(hipStream_t st, int dtype, const float *in, int64_t ld_in, const float *bias, int relu, int R, int C, void *out,
+                     int64_t ld_out);
 // out_f32[r][c] = in[r][c] (T -> f32)
 void k_uncast_rows(hipStream_t st, int dtype, const void *in, int64_t ld_in, int R, int C, float *out, int64_t ld_out);
 

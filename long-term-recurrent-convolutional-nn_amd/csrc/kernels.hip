@@ -249,6 +249,18 @@ __global__ void cast_rows_kernel(const float *in, int64_t ld_in, int R, int C, T
         out[(int64_t)r * ld_out + c] = from_f32<T>(c < C ? in[(int64_t)r * ld_in + c] : 0.0f);
 }
 template <typename T>
+__global__ void bias_act_cast_kernel(const float *in, int64_t ld_in, const float *bias, int relu, int R, int C, T *out, int64_t ld_out) {
+    const int r = blockIdx.y;
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < ld_out; c += gridDim.x * blockDim.x) {
+        float v = 0.0f;
+        if (c < C) {
+            v = in[(int64_t)r * ld_in + c] + (bias ? bias[c] : 0.0f);
+            if (relu) v = fmaxf(v, 0.0f);
+        }
+        out[(int64_t)r * ld_out + c] = from_f32<T>(v);
+    }
+}
+template <typename T>
 __global__ void uncast_rows_kernel(const T *in, int64_t ld_in, int R, int C, float *out, int64_t ld_out) {
     const int r = blockIdx.y;
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x)
@@ -518,6 +530,11 @@ void k_transpose_f32(hipStream_t st, const float *in, int64_t ld_in, int R, int 
 void k_cast_rows(hipStream_t st, int dtype, const float *in, int64_t ld_in, int R, int C, void *out, int64_t ld_out) {
     const dim3 grid(cdiv(ld_out, 256) > 64 ? 64 : cdiv(ld_out, 256), R);
     DISPATCH_T(dtype, hipLaunchKernelGGL(cast_rows_kernel<T>, grid, dim3(256), 0, st, in, ld_in, R, C, (T *)out, ld_out));
+}
+void k_bias_act_cast(hipStream_t st, int dtype, const float *in, int64_t ld_in, const float *bias, int relu, int R, int C, void *out,
+                     int64_t ld_out) {
+    const dim3 grid(cdiv(ld_out, 256) > 64 ? 64 : cdiv(ld_out, 256), R);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(bias_act_cast_kernel<T>, grid, dim3(256), 0, st, in, ld_in, bias, relu, R, C, (T *)out, ld_out));
 }
 void k_uncast_rows(hipStream_t st, int dtype, const void *in, int64_t ld_in, int R, int C, float *out, int64_t ld_out) {
     const dim3 grid(cdiv(C, 256) > 64 ? 64 : cdiv(C, 256), R);

@@ -59,6 +59,8 @@ struct lrcn_ctx {
     void *dxcT = nullptr;
     double *logp = nullptr;
     void *zero_page = nullptr;
+    void *gemm_ws = nullptr;  // split-K slabs of gemm_8p
+    size_t gemm_ws_bytes = 0;
     int last_norm = 1, last_S = 1;
     // single-step scratch (lrcn_lstm / lrcn_step / beam search), row-major
     float *st_f32[4] = {nullptr, nullptr, nullptr, nullptr};   // h1,c1,h2,c2 [B][H]
@@ -153,6 +155,8 @@ int gemm(lrcn_ctx *c, int dtype, const void *A, int64_t lda, const void *B, int6
     g.a_mode = GEMM_A_PLAIN;
     g.out_mode = GEMM_OUT_PLAIN;
     g.zero_page = c->zero_page;
+    g.ws = c->gemm_ws;
+    g.ws_bytes = c->gemm_ws_bytes;
     hipError_t e = launch_gemm(c->stream, g);
     if (e != hipSuccess) FAIL(c, LRCN_EHIP, "gemm M=%d N=%d K=%d: %s", M, N, K, hipGetErrorString(e));
     return LRCN_OK;
@@ -478,6 +482,8 @@ int lrcn_create(const lrcn_config *cfg, lrcn_ctx **out) {
         DALLOC(c, c->logp, sizeof(double) * 2);
         DALLOC(c, c->zero_page, 256);
         if (hipMemset(c->zero_page, 0, 256) != hipSuccess) return LRCN_EHIP;
+        c->gemm_ws_bytes = 48u << 20;
+        DALLOC(c, c->gemm_ws, c->gemm_ws_bytes);
         for (int i = 0; i < 4; ++i) {
             DALLOC(c, c->st_f32[i], sizeof(float) * B * Hm);
             DALLOC(c, c->st2_f32[i], sizeof(float) * B * Hm);
@@ -810,6 +816,8 @@ int conv_layer(lrcn_ctx *c, int dtype, const void *in, const VggLayer &L, int N,
     g.H = g.W = L.S;
     g.Cin = L.Cin;
     g.zero_page = c->zero_page;
+    g.ws = c->gemm_ws;
+    g.ws_bytes = c->gemm_ws_bytes;
     hipError_t e = launch_gemm(c->stream, g);
     if (e != hipSuccess) FAIL(c, LRCN_EHIP, "conv layer S=%d Cin=%d Cout=%d: %s", L.S, L.Cin, L.Cout, hipGetErrorString(e));
     return LRCN_OK;
@@ -845,6 +853,8 @@ int vgg_body(lrcn_ctx *c, int N, const void *src, bool src_u8, const float *mean
         g.out_mode = GEMM_OUT_CONV;
         g.H = g.W = 224;
         g.zero_page = c->zero_page;
+    g.ws = c->gemm_ws;
+    g.ws_bytes = c->gemm_ws_bytes;
         hipError_t e = launch_gemm(c->stream, g);
         if (e != hipSuccess) FAIL(c, LRCN_EHIP, "conv1_1: %s", hipGetErrorString(e));
     }
@@ -873,15 +883,17 @@ int vgg_body(lrcn_ctx *c, int N, const void *src, bool src_u8, const float *mean
     g.lda = 25088;
     g.B = c->fc6w;
     g.ldb = 25088;
-    g.C = c->f6;
-    g.ldc = 4096;
     g.M = N;
     g.N = 4096;
     g.K = 25088;
+    g.zero_page = c->zero_page;
+    g.ws = c->gemm_ws;
+    g.ws_bytes = c->gemm_ws_bytes;
+    g.C = c->f6;
+    g.ldc = 4096;
     g.bias = c->fc6b;
     g.relu = 1;
-    g.zero_page = c->zero_page;
-    hipError_t e = launch_gemm(c->stream, g);
+    hipError_t e = launch_gemm(c->stream, g);  // N = 256 images: 205 MB of weights through 32 tiles -> gemm_8p's split-K form
     if (e != hipSuccess) FAIL(c, LRCN_EHIP, "fc6: %s", hipGetErrorString(e));
     g.A = c->f6;
     g.lda = 4096;
@@ -1051,6 +1063,8 @@ int lrcn_conv3x3(lrcn_ctx *c, const float *x, int W, int H, int Cin, int N, cons
     g.W = W;
     g.Cin = Cp;
     g.zero_page = c->zero_page;
+    g.ws = c->gemm_ws;
+    g.ws_bytes = c->gemm_ws_bytes;
     hipError_t e = launch_gemm(c->stream, g);
     if (e == hipSuccess) {
         k_nhwc_to_ref(c->stream, vdt, out, Wo, Ho, Cout, N, Cout, y);
