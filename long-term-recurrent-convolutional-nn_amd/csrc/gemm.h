@@ -44,6 +44,11 @@ int64_t gemm_glds_blocks(const GemmArgs &g);  // workgroups the direct-to-LDS pa
 int gemm_8p_config(const GemmArgs &g, int64_t *blocks);
 int gemm_8p_splitk(const GemmArgs &g, int64_t *blocks);  // split-K slices for skinny problems (0 = not applicable)
 hipError_t launch_gemm_8p(hipStream_t stream, const GemmArgs &g, int splitk = 1);
+hipError_t launch_splitk_reduce(hipStream_t stream, const GemmArgs &g, int splits);
+
+// Skinny-M weight-streaming variant (gemm_skinny.hip): M <= 256 rows, B fragments straight from HBM/L2 to registers.
+bool gemm_skinny_eligible(const GemmArgs &g);
+hipError_t launch_gemm_skinny(hipStream_t stream, const GemmArgs &g);
 
 // Halo-patch convolution for the Cin = 64 layers (conv64.hip): NHWC bf16 in/out, weights [Cout][9][64], H and W multiples
 // of 16, Cout a multiple of 64; bias + optional ReLU + optional fused 2x2 max-pool.

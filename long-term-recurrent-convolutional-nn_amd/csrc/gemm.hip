@@ -275,9 +275,12 @@ hipError_t launch_gemm(hipStream_t stream, const GemmArgs &g) {
     // the grid fills the chip.
     const char *knob = getenv("LRCN_GLDS");
     const char *knob8 = getenv("LRCN_8P");  // LRCN_8P=0 disables the phase-interleaved path, =force lowers its grid threshold
+    const char *knobs = getenv("LRCN_SKINNY");  // LRCN_SKINNY=0 disables the skinny-M weight-streaming kernel
+    const bool skinny_ok = !(knob && knob[0] == '0') && !(knobs && knobs[0] == '0') && gemm_skinny_eligible(g);
     if (!(knob && knob[0] == '0') && !(knob8 && knob8[0] == '0')) {
         int64_t blocks = 0;
         if (gemm_8p_config(g, &blocks) >= 0 && ((knob8 && knob8[0] == 'f') || blocks >= 128)) return launch_gemm_8p(stream, g);
+        if (skinny_ok && g.M <= 128) return launch_gemm_skinny(stream, g);
         const char *ksk = getenv("LRCN_8P_SPLITK");  // kernel-development knob: 0 disables the split-K form
         const int sk = (ksk && ksk[0] == '0') ? 0 : gemm_8p_splitk(g, &blocks);
         if (sk > 1 && blocks >= 96) return launch_gemm_8p(stream, g, sk);
@@ -286,6 +289,7 @@ hipError_t launch_gemm(hipStream_t stream, const GemmArgs &g) {
         const int64_t blocks = gemm_glds_blocks(g);
         if (blocks > 0 && ((knob && knob[0] == 'f') || blocks >= 96)) return launch_gemm_glds(stream, g);
     }
+    if (skinny_ok) return launch_gemm_skinny(stream, g);  // 128 < M <= 256 with too few tiles for the paths above
     const int ce = g.dtype == GEMM_T_BF16 ? 8 : 4;
     if (((uintptr_t)g.A & 15) || ((uintptr_t)g.B & 15) || (g.ldb % ce)) return hipErrorInvalidValue;
     if (g.a_mode == GEMM_A_CONV3) {

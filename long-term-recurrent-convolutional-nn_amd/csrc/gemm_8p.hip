@@ -526,6 +526,15 @@ template <typename T> __global__ void splitk_reduce_kernel(const float *ws, int 
 }
 }  // namespace
 
+// C = act((beta ? C : 0) + sum of the `splits` f32 slabs [M][N] in g.ws + bias), written in C's type (N, ldc multiples of 4)
+hipError_t launch_splitk_reduce(hipStream_t stream, const GemmArgs &g, int splits) {
+    const int64_t total = (int64_t)g.M * (g.N >> 2);
+    const int grid = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+    hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, reinterpret_cast<const float *>(g.ws), splits, g.M,
+                       g.N, g.bias, g.beta, g.relu, g.C, g.ldc, g.c_f32);
+    return hipGetLastError();
+}
+
 hipError_t launch_gemm_8p(hipStream_t stream, const GemmArgs &g, int splitk) {
     int64_t blocks = 0;
     int cfg = gemm_8p_config(g, &blocks);
@@ -534,11 +543,7 @@ hipError_t launch_gemm_8p(hipStream_t stream, const GemmArgs &g, int splitk) {
         if (gemm_8p_splitk(g, &blocks) != splitk) return hipErrorInvalidValue;
         hipError_t e = dispatch<GEMM_A_PLAIN, true>(stream, g, 1, splitk);
         if (e != hipSuccess) return e;
-        const int64_t total = (int64_t)g.M * (g.N >> 2);
-        const int grid = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
-        hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, reinterpret_cast<const float *>(g.ws), splitk,
-                           g.M, g.N, g.bias, g.beta, g.relu, g.C, g.ldc, g.c_f32);
-        return hipGetLastError();
+        return launch_splitk_reduce(stream, g, splitk);
     } else {
         splitk = 1;
     }

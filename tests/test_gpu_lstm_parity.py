@@ -140,6 +140,35 @@ def test_config1_shape_vs_oracle_fp32_and_bf16():
         assert cos > 0.99, (n, cos)
 
 
+@pytest.mark.parametrize("B,T", [(24, 5), (64, 3), (128, 2), (160, 2)])
+def test_bf16_recurrent_gemms_on_skinny_kernel(B, T, monkeypatch):
+    # gemm_skinny.hip (M = B rows: m-tile counts 2 / 4 / 8 / 16, M tails, N = 4H = 1280 and the N = h = 160 tail tile,
+    # accumulate-into-G epilogue, split-K slabs for the K = 4096 image embedding) against the oracle and against the same
+    # step with the kernel disabled.
+    rng = np.random.default_rng(B)
+    E = H1 = H2 = 320
+    V = 777
+    m = orc.init_weights(E, H1, H2, V, seed=3)
+    feats = (rng.standard_normal((B, 4096)) * 0.01).astype(np.float32)
+    tokens = rng.integers(3, V, size=(T, B)).astype(np.int32)
+    ref_loss, ref_g = orc.loss(m, feats, tokens, want_grad=True)
+    param = L.model_from_arrays(m.p)
+    res = {}
+    for knob in ("1", "0"):
+        monkeypatch.setenv("LRCN_SKINNY", knob)
+        ctx = L.Context(E, H1, H2, V, max_B=B, max_T=T, lstm_dtype=lrcn_amd.LRCN_BF16)
+        grads, val = L.lossgradient(ctx, param, L.to_jl(feats), tokens)
+        res[knob] = (val, [L.from_jl(g).astype(np.float64) for g in grads])
+        ctx.close()
+        assert abs(val - ref_loss) <= 2e-2 * abs(ref_loss)
+        for n, g in zip(orc.PARAM_NAMES, res[knob][1]):
+            a, b = g.ravel(), ref_g.p[n].ravel().astype(np.float64)
+            assert a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30) > 0.99, n
+    assert abs(res["1"][0] - res["0"][0]) <= 2e-3 * abs(ref_loss)
+    for a, b in zip(res["1"][1], res["0"][1]):
+        assert np.linalg.norm(a - b) <= 3e-2 * np.linalg.norm(b) + 1e-12
+
+
 def test_bf16_time_batched_gemms_on_phase_interleaved_kernel(monkeypatch):
     # M = (T+1)*B = 512 rows: with LRCN_8P=force every time-batched GEMM (gate inputs, logits, weight gradients) runs on
     # gemm_8p.hip's PLAIN mode (f32 direct epilogue, bf16 staged epilogue); loss within 2e-2 of the f32 oracle, gradients
