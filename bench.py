@@ -31,7 +31,7 @@ def pmc_traffic(dtype, per_gpu_batch):
     """HBM-side bytes per launch of the dominant kernel family, from the committed rocprofv3 PMC passes of this same
     command (tools/pmc_traffic.py -> profiles/*.json; FETCH_SIZE/WRITE_SIZE cannot be read from inside the process).
     Only valid for the configuration it was measured on; otherwise null."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic_bench_bf16_b256.json")
+    path = os.path.join(ROOT, "profiles", "r01g_pmc_traffic_bench_bf16_b256.json")
     if dtype != "bf16" or per_gpu_batch != 256 or not os.path.exists(path):
         return None
     try:
@@ -153,7 +153,7 @@ def main():
     if rank == 0:
         ms_step = 1e3 * dt_s / a.steps
         value = Bg * a.steps / dt_s
-        # dominant kernel: gemm_nt_kernel<T,128,128,CONV3> = the 12 implicit-GEMM convolutions conv1_2..conv5_3
+        # dominant kernel family: the 12 convolution launches conv1_2..conv5_3 (2 x conv64_kernel + 10 x gemm8p_kernel<CONV3>)
         flops_per_launch = (VGG_CONV_GFLOP_PER_IMAGE - CONV11_GFLOP_PER_IMAGE) * 1e9 * B / 12.0
         avg_launch_s = conv_ms.value * 1e-3 / max(conv_n.value, 1)
         achieved = flops_per_launch / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
@@ -170,7 +170,7 @@ def main():
                        "last_loss": loss},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": pmc_traffic(a.dtype, B),
-                         "kernel": "gemm_glds_kernel<*,CONV3,*> (implicit-GEMM conv1_2..conv5_3, 12 launches/step)"
+                         "kernel": "conv64_kernel (conv1_2, conv2_1) + gemm8p_kernel<*,CONV3,*> (conv2_2..conv5_3): 12 launches/step"
                                    if a.dtype == "bf16" else "gemm_nt_kernel<float,*,CONV3> (conv1_2..conv5_3)",
                          "avg_launch_ms": 1e3 * avg_launch_s, "flops_per_launch": flops_per_launch},
         }

@@ -23,12 +23,19 @@ def main():
     fetch, write, out = sys.argv[1:4]
     nparam = int(sys.argv[4]) if len(sys.argv) > 4 else 39846640
     fe, wr = load(fetch), load(write)
-    conv = [k for k in fe if "gemm_glds_kernel" in k and k.rstrip(")").split(",")[4].strip() == "1"]  # AMODE == CONV3
+    def is_conv(k):  # the 12 launches conv1_2 .. conv5_3: conv64_kernel (Cin = 64) and the CONV3 instantiations of the GEMMs
+        if "conv64_kernel" in k:
+            return True
+        if "gemm8p_kernel<" in k or "gemm_glds_kernel<" in k:
+            args = k[k.index("<") + 1:k.index(">")].split(",")
+            return args[4].strip() == "1"  # AMODE == GEMM_A_CONV3
+        return False
+    conv = [k for k in fe if is_conv(k)]
     n = sum(len(fe[k]) for k in conv)
     f_kib = sum(sum(fe[k]) for k in conv)
     w_kib = sum(sum(wr[k]) for k in conv)
     res = {
-        "kernel_family": "gemm_glds_kernel<*,CONV3,*> (conv1_2..conv5_3)",
+        "kernel_family": "conv64_kernel + gemm8p_kernel<*,CONV3,*> (conv1_2..conv5_3)",
         "launches_counted": n,
         "fetch_size_kib_per_launch": f_kib / n,
         "write_size_kib_per_launch": w_kib / n,

@@ -14,9 +14,10 @@ def short(n):
 def main():
     rows = list(csv.DictReader(open(sys.argv[1])))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    idx = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
+    key = "conv11_kernel" if any("conv11_kernel" in r["Kernel_Name"] for r in rows) else "adam_kernel"
+    idx = [i for i, r in enumerate(rows) if key in r["Kernel_Name"]]
     a, b = idx[-2], idx[-1]
-    step = rows[a + 1:b + 1]
+    step = rows[a:b]  # one full step: from one conv1_1 launch (VGG of step k) to the next
     if "--stats" in sys.argv:
         tot = collections.defaultdict(lambda: [0, 0.0])
         for r in step:
