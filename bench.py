@@ -154,7 +154,9 @@ def main():
         ms_step = 1e3 * dt_s / a.steps
         value = Bg * a.steps / dt_s
         # dominant kernel family: the 12 convolution launches conv1_2..conv5_3 (2 x conv64_kernel + 10 x gemm8p_kernel<CONV3>)
-        flops_per_launch = (VGG_CONV_GFLOP_PER_IMAGE - CONV11_GFLOP_PER_IMAGE) * 1e9 * B / 12.0
+        # bf16: conv1_1 runs inside conv1_2's launch (conv64.hip FUSE), so its FLOPs belong to the 12 timed launches
+        fused11 = a.dtype == "bf16" and os.environ.get("LRCN_FUSE11", "1")[:1] != "0" and os.environ.get("LRCN_CONV64", "1")[:1] != "0"
+        flops_per_launch = (VGG_CONV_GFLOP_PER_IMAGE - (0.0 if fused11 else CONV11_GFLOP_PER_IMAGE)) * 1e9 * B / 12.0
         avg_launch_s = conv_ms.value * 1e-3 / max(conv_n.value, 1)
         achieved = flops_per_launch / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
         peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
@@ -170,7 +172,7 @@ def main():
                        "last_loss": loss},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": pmc_traffic(a.dtype, B),
-                         "kernel": "conv64_kernel (conv1_2, conv2_1) + gemm8p_kernel<*,CONV3,*> (conv2_2..conv5_3): 12 launches/step"
+                         "kernel": "conv64_kernel (conv1_1+conv1_2 fused, conv2_1) + gemm8p_kernel<*,CONV3,*> (conv2_2..conv5_3): 12 launches/step"
                                    if a.dtype == "bf16" else "gemm_nt_kernel<float,*,CONV3> (conv1_2..conv5_3)",
                          "avg_launch_ms": 1e3 * avg_launch_s, "flops_per_launch": flops_per_launch},
         }

@@ -18,6 +18,13 @@
 //     a lane are the four pixels of one 2x2 pool window (pool = 3 v_max); without pool D = B x A gives a lane 8 consecutive
 //     output channels of one pixel (one 16-byte store).  The channel <-> fragment-row permutation that makes those
 //     stores contiguous is free: it only changes which weight row a lane loads.
+// FUSE variant (conv1_2 fed by the mean-subtracted bf16 crops): the patch is not loaded but COMPUTED -- conv1_1 (3 -> 64
+// channels, K = 27) runs inside the kernel: the 20 x 20 x 3 window of a tile is DMA'd to LDS (2.4 KB, zero page outside the
+// image = conv1_1's zero padding), a lane's im2col fragment is ONE 16-byte LDS read (the 9 values (kh, c) of image row kw
+// are contiguous in the crop: run kw = lane group lq < 3 takes the first 8, lane group 3 the three 9th values), 4 MFMAs per
+// 16-pixel m-tile with the bias as accumulator input, ReLU, bf16, 8-byte writes into the swizzled patch.  The 1.64 GB
+// conv1_1 activation tensor never exists in HBM.  (A first version converted uint8 bytes in the producer: 3x the VALU
+// work, slower than two launches; the u8 -> bf16 - mean pass is now a 25 us elementwise pre-kernel.)
 // LDS patch image: pixel q = py*18 + px at q*128 bytes, 16-byte chunk c at position c ^ g(py,px),
 //   g = (((px >> 1) & 3) << 1) | (py & 1): conflict-free for the 16-lane groups of ds_read_b128 at every tap shift.
 #include <cstdlib>
@@ -38,6 +45,14 @@ constexpr int PATCH_BYTES = 48 * 1024;  // 48 DMA pieces of 1 KiB (41 carry pixe
 constexpr int NPIECE = 6;               // pieces per wave per patch
 constexpr int BIAS_OFF = 3 * PATCH_BYTES;
 constexpr int LDS_BYTES = BIAS_OFF + 64 * 4;
+// FUSE layout: 21 m-tiles (336 pixel rows) per patch, 4 raw-window buffers, conv1_1 weights and both bias vectors
+constexpr int F_PATCH = 21 * 2048;
+constexpr int F_RAW_OFF = 3 * F_PATCH;
+constexpr int F_RAW = 4096;  // 16 DMA slots of 256 B: slot i = window rows 2i, 2i+1 (128 B each, 120 used); slots 10..15 dummy
+constexpr int F_W11_OFF = F_RAW_OFF + 4 * F_RAW;
+constexpr int F_B11_OFF = F_W11_OFF + 64 * 64;
+constexpr int F_BIAS_OFF = F_B11_OFF + 256;
+constexpr int F_LDS_BYTES = F_BIAS_OFF + 256;
 
 struct Conv64Args {
     const bf16_t *in;   // NHWC [N][H][W][64]
@@ -47,6 +62,10 @@ struct Conv64Args {
     const void *zero_page;
     int N, H, W, Cout, relu;
     int tiles_y, tiles_x, ntiles;
+    // FUSE only: mean-subtracted crops img16[n][row = x][col = y][3] bf16 (H = W = S), conv1_1 weights [64][32] in k' order, bias
+    const bf16_t *img16;
+    const bf16_t *w11;
+    const float *b11;
 };
 
 template <int I, int N, class F> __device__ __forceinline__ void static_for(F &&f) {
@@ -60,6 +79,12 @@ template <int OFF> __device__ __forceinline__ uint4 lds_read16(unsigned addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
     return r;
 }
+template <int OFF> __device__ __forceinline__ unsigned lds_read_u16(unsigned addr) {
+    unsigned r;
+    asm volatile("ds_read_u16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
+    return r;
+}
+__device__ __forceinline__ void lds_write8(unsigned addr, uint2 v) { asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -69,8 +94,16 @@ template <bool POOL> __device__ __forceinline__ int chan_of(int n, int j) {
                 : (j >> 2) * 8 + n * 4 + (j & 3);     // lane (lq) = 8 consecutive channels: one 16-byte store
 }
 
-template <bool POOL> __global__ __launch_bounds__(512) void conv64_kernel(const Conv64Args a) {
-    constexpr int NST = POOL ? 4 : 4;  // global stores per wave per epilogue (the counted vmcnt below depends on it)
+template <bool POOL, bool FUSE> __global__ __launch_bounds__(512) void conv64_kernel(const Conv64Args a) {
+    constexpr int PB = FUSE ? F_PATCH : PATCH_BYTES;  // bytes per patch buffer
+    constexpr int BOFF = FUSE ? F_BIAS_OFF : BIAS_OFF;
+    constexpr int NST = POOL ? 4 : 4;
+    // half-taps before the mid-patch barrier.  FUSE: ALL of them -- the second segment is epilogue + producer, so (waves 4..7
+    // being one barrier behind) one wave of a SIMD multiplies while its partner produces the patch after next
+#ifndef CONV64_FUSE_SPLIT
+#define CONV64_FUSE_SPLIT 18
+#endif
+    constexpr int SPLIT = FUSE ? CONV64_FUSE_SPLIT : 9;  // global stores per wave per epilogue (the counted vmcnt below depends on it)
     extern __shared__ __attribute__((aligned(128))) unsigned char smem[];  // K-half select is address ^ 64
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -91,7 +124,7 @@ template <bool POOL> __global__ __launch_bounds__(512) void conv64_kernel(const 
 #pragma unroll
             for (int s = 0; s < 2; ++s) breg[t][s][n] = *reinterpret_cast<const uint4 *>(wr + t * 64 + s * 32);
     }
-    if (tid < 64) reinterpret_cast<float *>(smem + BIAS_OFF)[tid] = a.bias ? a.bias[cc * 64 + tid] : 0.0f;
+    if (tid < 64) reinterpret_cast<float *>(smem + BOFF)[tid] = a.bias ? a.bias[cc * 64 + tid] : 0.0f;
 
     // ---- A-fragment read addresses: lane l15 = (window w, dy, dx) of an m-tile, lq = 16-byte K chunk ----
     const int w_ = l15 >> 2, dy = (l15 >> 1) & 1, dx = l15 & 1, xl = 2 * w_ + dx;
@@ -131,8 +164,112 @@ template <bool POOL> __global__ __launch_bounds__(512) void conv64_kernel(const 
         for (int j = 0; j < NPIECE; ++j) {
             const bool bad = ((dflags >> (5 * j)) & edge) != 0;
             const bf16_t *src = bad ? Zp : a.in + (origin + doff[j]);
-            __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(smem + buf * PATCH_BYTES + (wave + 8 * j) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(smem + buf * PB + (wave + 8 * j) * 1024), 16, 0, 0);
         }
+    };
+
+
+    // ================= FUSE: raw-window DMA and the conv1_1 patch producer =================
+    auto issue_raw = [&](int tile, int rbuf) {
+        // two 256-byte DMAs per wave: slot ii = 2 wave + k = window rows 2 ii, 2 ii + 1; lane -> (row half, dword i < 30); the
+        // window starts at element (16 ty - 2) * 3 of image row 16 tx - 2 + wrow: dword-aligned, and so is every pixel edge
+        const bool live = tile >= 0;
+        const int t = live ? tile : 0;
+        const int per_img = a.tiles_y * a.tiles_x;
+        const int n = t / per_img, r = t - n * per_img;
+        const int ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
+        const int S = H;
+        const int half = lane >> 5, i = lane & 31;
+        const int e0 = (16 * ty - 2) * 3 + 2 * i;  // first of the lane's two elements inside the image row
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int ii = 2 * wave + k;
+            const int wrow = 2 * ii + half;
+            const int xr = 16 * tx - 2 + wrow;
+            const bool ok = live && i < 30 && wrow < 20 && (unsigned)xr < (unsigned)S && e0 >= 0 && e0 + 2 <= 3 * S;
+            const bf16_t *src = ok ? a.img16 + ((size_t)(n * S + xr) * S * 3 + e0) : reinterpret_cast<const bf16_t *>(a.zero_page);
+            __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(smem + F_RAW_OFF + rbuf * F_RAW + ii * 256), 4, 0, 0);
+        }
+    };
+    auto produce = [&](int tile, int pbuf, int rbuf) {
+        if (tile < 0) return;
+        const int per_img = a.tiles_y * a.tiles_x;
+        const int n = tile / per_img, r = tile - n * per_img;
+        const int ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
+        (void)n;
+        const int S = H;
+        const unsigned raw = lds0 + F_RAW_OFF + rbuf * F_RAW;
+        const unsigned pat = lds0 + pbuf * F_PATCH;
+        // everything below depends only on the lane and the tile: keep hipcc from hoisting it out of the patch loop (it would
+        // pin ~30 registers across the MFMA body and spill)
+        int l15v = l15, lqv = lq;
+        asm volatile("" : "+v"(l15v), "+v"(lqv));
+        const int lsel = lqv < 2 ? lqv : 2;
+        const bool last = lqv == 3;
+        // conv1_1 weight fragments: rows = channels nn*16 + l15 (64-byte rows: nn KiB apart), chunk lq swizzled by (row >> 2) & 3
+        const unsigned wfa = lds0 + F_W11_OFF + l15v * 64 + ((lqv ^ ((l15v >> 2) & 3)) << 4);
+        const unsigned bba = lds0 + F_B11_OFF + lqv * 16;  // bias of channels nn*16 + 4 lq .. + 3
+        // All LDS reads of the call and their wait are ONE asm statement: for hipcc the outputs exist only after the wait.
+        // (With separate statements it folded `phi(n9, 0) << 16` into the block that issues the read and consumed the
+        // register before the data had landed.)  Waves 5..7 own two m-tiles; their third read set hits in-bounds garbage.
+        const bool three = wave + 16 < 21;  // wave-uniform
+        uint4 run[3], wf[4], bq[4];
+        unsigned n9[3][3];
+        int qv[3];
+        unsigned rbs[3], rbl[3];
+#pragma unroll
+        for (int sl = 0; sl < 3; ++sl) {
+            const int q = (wave + 8 * sl) * 16 + l15v;
+            const int py = q / 18, px = q - 18 * py;
+            qv[sl] = q;
+            // run kw of pixel (py, px): window row px + kw, 9 bf16 from byte 6 py  (2-byte aligned 16-byte read: replayed, correct)
+            rbl[sl] = raw + px * 128 + 6 * py;
+            rbs[sl] = rbl[sl] + lsel * 128;
+        }
+        asm volatile(
+            "ds_read_b128 %0, %20\n\tds_read_u16 %3, %23 offset:16\n\tds_read_u16 %4, %23 offset:144\n\tds_read_u16 %5, %23 offset:272\n\t"
+            "ds_read_b128 %1, %21\n\tds_read_u16 %6, %24 offset:16\n\tds_read_u16 %7, %24 offset:144\n\tds_read_u16 %8, %24 offset:272\n\t"
+            "ds_read_b128 %2, %22\n\tds_read_u16 %9, %25 offset:16\n\tds_read_u16 %10, %25 offset:144\n\tds_read_u16 %11, %25 offset:272\n\t"
+            "ds_read_b128 %12, %26\n\tds_read_b128 %13, %26 offset:1024\n\tds_read_b128 %14, %26 offset:2048\n\tds_read_b128 %15, %26 offset:3072\n\t"
+            "ds_read_b128 %16, %27\n\tds_read_b128 %17, %27 offset:64\n\tds_read_b128 %18, %27 offset:128\n\tds_read_b128 %19, %27 offset:192\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(run[0]), "=&v"(run[1]), "=&v"(run[2]), "=&v"(n9[0][0]), "=&v"(n9[0][1]), "=&v"(n9[0][2]), "=&v"(n9[1][0]),
+              "=&v"(n9[1][1]), "=&v"(n9[1][2]), "=&v"(n9[2][0]), "=&v"(n9[2][1]), "=&v"(n9[2][2]), "=&v"(wf[0]), "=&v"(wf[1]),
+              "=&v"(wf[2]), "=&v"(wf[3]), "=&v"(bq[0]), "=&v"(bq[1]), "=&v"(bq[2]), "=&v"(bq[3])
+            : "v"(rbs[0]), "v"(rbs[1]), "v"(rbs[2]), "v"(rbl[0]), "v"(rbl[1]), "v"(rbl[2]), "v"(wfa), "v"(bba)
+            : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, 3>([&](auto sc) {
+            constexpr int sl = decltype(sc)::value;
+            if (sl < 2 || three) {
+                const int q = qv[sl];
+                const int py = q / 18, px = q - 18 * py;
+                const bool pv = (q < 324) & ((unsigned)(16 * ty - 1 + py) < (unsigned)S) & ((unsigned)(16 * tx - 1 + px) < (unsigned)S);
+                uint4 afr;
+                afr.x = last ? (n9[sl][0] | (n9[sl][1] << 16)) : run[sl].x;
+                afr.y = last ? n9[sl][2] : run[sl].y;
+                afr.z = last ? 0u : run[sl].z;
+                afr.w = last ? 0u : run[sl].w;
+                const bf16x8 av = __builtin_bit_cast(bf16x8, afr);
+                const int gsw = (((px >> 1) & 3) << 1) | (py & 1);
+                const unsigned pmask = pv ? 0xFFFFFFFFu : 0u;
+                const unsigned wdst = pat + q * 128 + (lqv & 1) * 8;
+                static_for<0, 4>([&](auto nc) {
+                    constexpr int nn = decltype(nc)::value;
+                    f32x4v d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[nn]), av,
+                                                                       __builtin_bit_cast(f32x4v, bq[nn]), 0, 0, 0);
+                    bf16x4 o;
+#pragma unroll
+                    for (int r2 = 0; r2 < 4; ++r2) o[r2] = (bf16_t)fmaxf(d[r2], 0.0f);
+                    uint2 ov = __builtin_bit_cast(uint2, o);
+                    ov.x &= pmask;
+                    ov.y &= pmask;
+                    // channels nn*16 + 4 lq .. + 3 of pixel q: chunk nn*2 + (lq >> 1), 8-byte half lq & 1
+                    lds_write8(wdst + (((nn * 2 + (lqv >> 1)) ^ gsw) << 4), ov);
+                });
+            }
+        });
+        wait_lgkm<0>();
     };
 
     const int G = gridDim.x, b0 = blockIdx.x;
@@ -143,15 +280,36 @@ template <bool POOL> __global__ __launch_bounds__(512) void conv64_kernel(const 
     uint4 af[2][4];
 
     // ---- prologue: patches 0 and 1 ----
-    issue_patch(tile_at(0), 0);
-    issue_patch(tile_at(1), 1);
-    wait_vmcnt<0>();
-    __syncthreads();                              // patches 0, 1 and the bias are visible (no DMA in flight here)
+    if constexpr (FUSE) {
+        {   // conv1_1 weights [64][32] bf16 -> LDS rows of 64 B (chunk c at c ^ ((row >> 2) & 3)); conv1_1 bias
+            if (tid < 256) {
+                const int r = tid >> 2, c = tid & 3;
+                *reinterpret_cast<uint4 *>(smem + F_W11_OFF + r * 64 + ((c ^ ((r >> 2) & 3)) << 4)) =
+                    *reinterpret_cast<const uint4 *>(a.w11 + r * 32 + c * 8);
+            } else if (tid < 320) {
+                reinterpret_cast<float *>(smem + F_B11_OFF)[tid - 256] = a.b11[tid - 256];
+            }
+        }
+        issue_raw(tile_at(0), 0);
+        issue_raw(tile_at(1), 1);
+        issue_raw(tile_at(2), 2);
+        issue_raw(tile_at(3), 3);
+        wait_vmcnt<0>();
+        __syncthreads();
+        produce(tile_at(0), 0, 0);
+        produce(tile_at(1), 1, 1);
+        __syncthreads();
+    } else {
+        issue_patch(tile_at(0), 0);
+        issue_patch(tile_at(1), 1);
+        wait_vmcnt<0>();
+        __syncthreads();                          // patches 0, 1 and the bias are visible (no DMA in flight here)
+    }
     if (wq == 1) __builtin_amdgcn_s_barrier();    // stagger
 
     for (int j = 0; j < my_tiles; ++j) {
         const int buf = j % 3;
-        const unsigned boff = buf * PATCH_BYTES;
+        const unsigned boff = buf * PB;
         unsigned ar[2][3][2];
 #pragma unroll
         for (int yp = 0; yp < 2; ++yp)
@@ -207,15 +365,15 @@ template <bool POOL> __global__ __launch_bounds__(512) void conv64_kernel(const 
         };
 
         // ---------------- first half of the patch ----------------
-        if (wq == 1) issue_patch(tile_at(j + 2), (j + 2) % 3);
+        if (!FUSE && wq == 1) issue_patch(tile_at(j + 2), (j + 2) % 3);
         read_half(std::integral_constant<int, 0>{});
-        run_halves(std::integral_constant<int, 0>{}, std::integral_constant<int, 9>{});
-        if (wq == 1) wait_vmcnt<NPIECE + NST>();  // retires this wave's pieces of patch j+1
+        run_halves(std::integral_constant<int, 0>{}, std::integral_constant<int, SPLIT>{});
+        if (!FUSE && wq == 1) wait_vmcnt<NPIECE + NST>();  // retires this wave's pieces of patch j+1
         __builtin_amdgcn_s_barrier();
         // ---------------- second half ----------------
-        if (wq == 0) issue_patch(tile_at(j + 2), (j + 2) % 3);
-        run_halves(std::integral_constant<int, 9>{}, std::integral_constant<int, 18>{});
-        if (wq == 0) wait_vmcnt<NPIECE + NST>();
+        if (!FUSE && wq == 0) issue_patch(tile_at(j + 2), (j + 2) % 3);
+        run_halves(std::integral_constant<int, SPLIT>{}, std::integral_constant<int, 18>{});
+        if (!FUSE && wq == 0) wait_vmcnt<NPIECE + NST>();
 
         // ---------------- epilogue: bias, ReLU, (pool), store ----------------
         {
@@ -227,7 +385,7 @@ template <bool POOL> __global__ __launch_bounds__(512) void conv64_kernel(const 
                 // lane: channels (2 l15, 2 l15 + 1) of the wave's 32; registers = the 4 pixels of window lq of m-tile 4 wp + i
                 float b0v, b1v;
                 {
-                    const unsigned ba = lds0 + BIAS_OFF + (wq * 32 + 2 * l15) * 4;
+                    const unsigned ba = lds0 + BOFF + (wq * 32 + 2 * l15) * 4;
                     uint2 bb;
                     asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(bb) : "v"(ba) : "memory");
                     b0v = __builtin_bit_cast(float, bb.x);
@@ -254,7 +412,7 @@ template <bool POOL> __global__ __launch_bounds__(512) void conv64_kernel(const 
                 // lane: pixel l15 of m-tile 4 wp + i; registers of n-tile n = channels lq*8 + n*4 + (0..3)
                 f32x4v bv0, bv1;
                 {
-                    const unsigned ba = lds0 + BIAS_OFF + (wq * 32 + lq * 8) * 4;
+                    const unsigned ba = lds0 + BOFF + (wq * 32 + lq * 8) * 4;
                     uint4 x0, x1;
                     asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
                                  : "=&v"(x0), "=&v"(x1)
@@ -285,6 +443,13 @@ template <bool POOL> __global__ __launch_bounds__(512) void conv64_kernel(const 
                 }
             }
         }
+        if constexpr (FUSE) {
+            // vm-op order of a wave: ... raw(j+3), stores(j), [here], raw(j+4) ...: vmcnt(NST) retires raw window j+3 (used by
+            // the NEXT iteration's producer, after this iteration's barrier made every wave's piece visible)
+            wait_vmcnt<NST>();
+            produce(tile_at(j + 2), (j + 2) % 3, (j + 2) & 3);
+            issue_raw(tile_at(j + 4), (j + 4) & 3);
+        }
         __builtin_amdgcn_s_barrier();
     }
     if (wq == 0) __builtin_amdgcn_s_barrier();  // un-stagger
@@ -313,12 +478,42 @@ hipError_t launch_conv64(hipStream_t stream, const void *in, const void *w, cons
     int gx = 256 / chunks;  // one workgroup per CU (all of LDS)
     if (gx > a.ntiles) gx = a.ntiles;
     static bool attr_done[2] = {false, false};
-    auto kern = pool ? conv64_kernel<true> : conv64_kernel<false>;
+    auto kern = pool ? conv64_kernel<true, false> : conv64_kernel<false, false>;
     if (!attr_done[pool ? 1 : 0]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_done[pool ? 1 : 0] = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)chunks), dim3(512), LDS_BYTES, stream, a);
+    return hipGetLastError();
+}
+
+// conv1_1 + conv1_2 (+ pool) in one launch from the mean-subtracted bf16 crops img16[n][x][y][3] (k_img_u8_to_bf16): see the
+// FUSE note at the top.  w11 = conv1_1 weights [64][32] in
+// the k' order (k_repack_conv11_w_fused), S = crop size (multiple of 16), out = pooled NHWC [N][S/2][S/2][64].
+hipError_t launch_conv64_fused11(hipStream_t stream, const void *img16, const void *w11, const float *b11, const void *w,
+                                 const float *bias, void *out, int N, int S, const void *zero_page) {
+    if (!img16 || !w11 || !b11 || !w || !out || !zero_page || N < 1 || S < 16 || (S % 16)) return hipErrorInvalidValue;
+    if ((int64_t)N * S * S * 3 >= (1ll << 31)) return hipErrorInvalidValue;
+    Conv64Args a{};
+    a.w = reinterpret_cast<const bf16_t *>(w);
+    a.bias = bias;
+    a.out = reinterpret_cast<bf16_t *>(out);
+    a.zero_page = zero_page;
+    a.N = N; a.H = S; a.W = S; a.Cout = 64; a.relu = 1;
+    a.tiles_y = S / 16; a.tiles_x = S / 16; a.ntiles = N * a.tiles_y * a.tiles_x;
+    a.img16 = reinterpret_cast<const bf16_t *>(img16);
+    a.w11 = reinterpret_cast<const bf16_t *>(w11);
+    a.b11 = b11;
+    int gx = 256;
+    if (gx > a.ntiles) gx = a.ntiles;
+    static bool attr_done = false;
+    auto kern = conv64_kernel<true, true>;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, 1), dim3(512), F_LDS_BYTES, stream, a);
     return hipGetLastError();
 }

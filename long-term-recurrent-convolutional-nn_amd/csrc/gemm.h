@@ -55,3 +55,6 @@ hipError_t launch_gemm_skinny(hipStream_t stream, const GemmArgs &g);
 bool conv64_eligible(int dtype, int Cin, int Cout, int H, int W);
 hipError_t launch_conv64(hipStream_t stream, const void *in, const void *w, const float *bias, void *out, int N, int H, int W, int Cout,
                          int relu, int pool, const void *zero_page);
+// conv1_1 + conv1_2 (+ pool) fused, from mean-subtracted bf16 crops (conv64.hip FUSE): w11 from k_repack_conv11_w_fused
+hipError_t launch_conv64_fused11(hipStream_t stream, const void *img16, const void *w11, const float *b11, const void *w,
+                                 const float *bias, void *out, int N, int S, const void *zero_page);

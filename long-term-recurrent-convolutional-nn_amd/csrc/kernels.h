@@ -80,6 +80,10 @@ void k_fill(hipStream_t st, float *w, int64_t n, float v);
 void k_repack_conv_w(hipStream_t st, int dtype, const float *w, int Cin, int Cout, int Cin_pad, void *out);
 // conv1_1 weight -> [64][ld] T with k = tap*3 + c (27 real, rest zero)
 void k_repack_conv11_w(hipStream_t st, int dtype, const float *w, int Cout, void *out, int64_t ld);
+// out[i] = (bf16)(img[i] - mean[i % 3]) over n = N*S*S*3 bytes: the crop, mean-subtracted, in its own layout (input of conv64 FUSE)
+void k_img_u8_to_bf16(hipStream_t st, const uint8_t *img, int64_t n, float m0, float m1, float m2, void *out);
+// conv1_1 weight -> [64][32] bf16 in the K order of the fused conv1_1+conv1_2 kernel (conv64.hip, FUSE)
+void k_repack_conv11_w_fused(hipStream_t st, const float *w, void *out);
 // fc6 weight (4096 x 25088 column-major, k_ref = x + 7y + 49c) -> [4096][25088] T with k = (y*7+x)*512 + c
 void k_repack_fc6_w(hipStream_t st, int dtype, const float *w, void *out);
 // conv1_1 im2col from uint8 crops img[n][row][col][3]: A[m][k = tap*3+c] (T, ld), m window-major over (y=col, x=row);

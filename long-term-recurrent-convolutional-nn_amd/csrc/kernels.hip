@@ -330,6 +330,45 @@ template <typename T> __global__ void repack_conv11_w_kernel(const float *w, int
     }
     out[i] = from_f32<T>(v);
 }
+// out[i] = (bf16)(img[i] - mean[i % 3])  : read_image_data's arithmetic (lrcn.jl:770) in the crop's own layout [n][row][col][3]
+__global__ void img_u8_to_bf16_kernel(const uint8_t *img, int64_t n, float m0, float m1, float m2, bf16_t *out) {
+    // 12 bytes (4 pixels) per thread: channel phase is the same for every thread
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i0 = t * 12;
+    if (i0 >= n) return;
+    if (i0 + 12 <= n) {
+        const uint32_t *p = reinterpret_cast<const uint32_t *>(img + i0);
+        const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
+        const float mean[3] = {m0, m1, m2};
+        bf16_t o[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            const uint32_t w = k < 4 ? w0 : (k < 8 ? w1 : w2);
+            o[k] = (bf16_t)((float)((w >> (8 * (k & 3))) & 0xFFu) - mean[k % 3]);
+        }
+        uint2 *q = reinterpret_cast<uint2 *>(out + i0);
+        const uint2 *ov = reinterpret_cast<const uint2 *>(o);
+        q[0] = ov[0]; q[1] = ov[1]; q[2] = ov[2];
+    } else {
+        for (int64_t i = i0; i < n; ++i) out[i] = (bf16_t)((float)img[i] - (i % 3 == 0 ? m0 : (i % 3 == 1 ? m1 : m2)));
+    }
+}
+// conv1_1 weights for the fused conv1_1+conv1_2 kernel (conv64.hip FUSE): out[co][k'], k' = 8 lq + j:
+//   lq < 3: kw = lq, kh = j / 3, c = j % 3 (the first 8 bytes of the 9-byte run of image row kw);  lq = 3: j < 3 -> kw = j, kh = 2, c = 2
+__global__ void repack_conv11_w_fused_kernel(const float *w, bf16_t *out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 64 * 32) return;
+    const int k = i & 31, co = i >> 5, lq = k >> 3, j = k & 7;
+    float v = 0.0f;
+    int kw = -1, kh = 0, c = 0;
+    if (lq < 3) {
+        kw = lq; kh = j / 3; c = j % 3;
+    } else if (j < 3) {
+        kw = j; kh = 2; c = 2;
+    }
+    if (kw >= 0) v = w[kw + 3 * (kh + 3 * (c + 3 * co))];  // reference layout (3,3,3,64) column-major: a = kw (dim 1), b = kh (dim 2)
+    out[i] = (bf16_t)v;
+}
 template <typename T> __global__ void repack_fc6_w_kernel(const float *w, T *out) {
     // out[o][(y*7+x)*512 + c] = w(o, x + 7y + 49c) = w[o + 4096*(x + 7y + 49c)]; tiled through LDS for coalescing both ways
     __shared__ float tile[32][33];
@@ -563,6 +602,13 @@ void k_repack_conv_w(hipStream_t st, int dtype, const float *w, int Cin, int Cou
 void k_repack_conv11_w(hipStream_t st, int dtype, const float *w, int Cout, void *out, int64_t ld) {
     DISPATCH_T(dtype, hipLaunchKernelGGL(repack_conv11_w_kernel<T>, dim3(cdiv(Cout * ld, 256)), dim3(256), 0, st, w, Cout,
                                          (T *)out, ld));
+}
+void k_img_u8_to_bf16(hipStream_t st, const uint8_t *img, int64_t n, float m0, float m1, float m2, void *out) {
+    const int64_t threads = (n + 11) / 12;
+    hipLaunchKernelGGL(img_u8_to_bf16_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, img, n, m0, m1, m2, (bf16_t *)out);
+}
+void k_repack_conv11_w_fused(hipStream_t st, const float *w, void *out) {
+    hipLaunchKernelGGL(repack_conv11_w_fused_kernel, dim3(8), dim3(256), 0, st, w, (bf16_t *)out);
 }
 void k_repack_fc6_w(hipStream_t st, int dtype, const float *w, void *out) {
     DISPATCH_T(dtype, hipLaunchKernelGGL(repack_fc6_w_kernel<T>, dim3(25088 / 32, 4096 / 32), dim3(256), 0, st, w, (T *)out));

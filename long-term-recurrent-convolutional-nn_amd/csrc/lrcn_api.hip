@@ -30,6 +30,7 @@ static thread_local std::string g_create_err;
 
 struct VggLayer {
     void *w = nullptr;    // [Cout][9*Cin] T (conv) ; conv1_1: [64][32]
+    void *w_fused = nullptr;  // conv1_1 only (bf16): [64][32] in the K order of the fused conv1_1+conv1_2 kernel
     float *b = nullptr;   // [Cout] f32
     int Cin = 0, Cout = 0, S = 0, pool = 0;
 };
@@ -73,7 +74,7 @@ struct lrcn_ctx {
     VggLayer conv[13];
     void *fc6w = nullptr, *fc7w = nullptr;
     float *fc6b = nullptr, *fc7b = nullptr;
-    void *actA = nullptr, *actB = nullptr, *im2col = nullptr, *f6 = nullptr;
+    void *actA = nullptr, *actB = nullptr, *im2col = nullptr, *f6 = nullptr, *img16 = nullptr;
     float *featsRM = nullptr;  // [N][4096] f32 row-major
     // live timing of the dominant kernel (the 12 implicit-GEMM conv launches conv1_2..conv5_3), see lrcn_profile*
     bool prof = false;
@@ -502,6 +503,7 @@ int lrcn_create(const lrcn_config *cfg, lrcn_ctx **out) {
             const size_t ve = c->vesz;
             if (c->vdt != GEMM_T_BF16) DALLOC(c, c->im2col, ve * N * 224 * 224 * 32);  // bf16 fuses conv1_1's im2col
             DALLOC(c, c->actA, ve * N * 224 * 224 * 64);
+            if (c->vdt == GEMM_T_BF16) DALLOC(c, c->img16, 2 * N * 224 * 224 * 3);  // mean-subtracted crops for the fused conv1_1+conv1_2
             DALLOC(c, c->actB, ve * N * 112 * 112 * 128);  // largest tensor ever written to the second buffer (pool1 out = N*112*112*64; conv2_1 out = N*112*112*128)
             DALLOC(c, c->f6, ve * N * 4096);
             DALLOC(c, c->featsRM, sizeof(float) * N * 4096);
@@ -767,6 +769,10 @@ int lrcn_vgg_load(lrcn_ctx *c, const float *const cw[13], const float *const cb[
         if (l == 0) {
             DALLOC(c, L.w, ve * 64 * 32);
             k_repack_conv11_w(st, vdt, cw[0], 64, L.w, 32);
+            if (vdt == GEMM_T_BF16) {
+                DALLOC(c, L.w_fused, 2 * 64 * 32);
+                k_repack_conv11_w_fused(st, cw[0], L.w_fused);
+            }
         } else {
             DALLOC(c, L.w, ve * (size_t)L.Cout * 9 * Cin);
             k_repack_conv_w(st, vdt, cw[l], Cin, L.Cout, Cin, L.w);
@@ -827,7 +833,12 @@ int conv_layer(lrcn_ctx *c, int dtype, const void *in, const VggLayer &L, int N,
 int vgg_body(lrcn_ctx *c, int N, const void *src, bool src_u8, const float *mean) {
     const int vdt = c->vdt;
     const float m0 = mean ? mean[0] : 0.f, m1 = mean ? mean[1] : 0.f, m2 = mean ? mean[2] : 0.f;
-    if (vdt == GEMM_T_BF16) {
+    const char *kf = getenv("LRCN_FUSE11");  // LRCN_FUSE11=0: conv1_1 and conv1_2 as two launches
+    const bool fuse11 = vdt == GEMM_T_BF16 && src_u8 && c->conv[0].w_fused && conv64_enabled() && !(kf && kf[0] == '0');
+    if (fuse11) {
+        // read_image_data's arithmetic as an elementwise pass (38 MB -> 77 MB at N = 256); conv1_1 itself runs inside conv1_2's launch
+        k_img_u8_to_bf16(c->stream, reinterpret_cast<const uint8_t *>(src), (int64_t)N * 224 * 224 * 3, m0, m1, m2, c->img16);
+    } else if (vdt == GEMM_T_BF16) {
         // conv1_1 fused with the preprocessing arithmetic (conv11.hip): HBM-bound, no im2col in memory
         k_conv11_fused(c->stream, src_u8 ? 1 : 0, src, N, 224, m0, m1, m2, c->conv[0].w, c->conv[0].b, c->actA);
     } else {
@@ -853,8 +864,6 @@ int vgg_body(lrcn_ctx *c, int N, const void *src, bool src_u8, const float *mean
         g.out_mode = GEMM_OUT_CONV;
         g.H = g.W = 224;
         g.zero_page = c->zero_page;
-    g.ws = c->gemm_ws;
-    g.ws_bytes = c->gemm_ws_bytes;
         hipError_t e = launch_gemm(c->stream, g);
         if (e != hipSuccess) FAIL(c, LRCN_EHIP, "conv1_1: %s", hipGetErrorString(e));
     }
@@ -870,7 +879,15 @@ int vgg_body(lrcn_ctx *c, int N, const void *src, bool src_u8, const float *mean
         ev = &c->prof_ev[c->prof_used++];
         HIPCHK(c, hipEventRecord(ev->first, c->stream));
     }
-    for (int l = 1; l < 13; ++l) {
+    int l0 = 1;
+    if (fuse11) {  // conv1_1 + conv1_2 + pool1 in one launch, straight from the uint8 crops: actA is never written
+        hipError_t e = launch_conv64_fused11(c->stream, c->img16, c->conv[0].w_fused, c->conv[0].b, c->conv[1].w, c->conv[1].b, nxt, N, 224,
+                                             c->zero_page);
+        if (e != hipSuccess) FAIL(c, LRCN_EHIP, "fused conv1_1+conv1_2: %s", hipGetErrorString(e));
+        std::swap(cur, nxt);
+        l0 = 2;
+    }
+    for (int l = l0; l < 13; ++l) {
         int r = conv_layer(c, vdt, cur, c->conv[l], N, nxt);
         if (r) return r;
         std::swap(cur, nxt);

@@ -155,3 +155,25 @@ def test_full_vgg_bf16_vs_oracle(vgg_setup):
     assert rel_max_err(got, ref) <= 3e-2
     cos = float((got * ref).sum() / (np.linalg.norm(got) * np.linalg.norm(ref)))
     assert cos > 0.999
+
+
+def test_fused_conv1_1_conv1_2_matches_two_launch_path(vgg_setup, monkeypatch):
+    # conv64.hip FUSE (conv1_1 computed inside the conv1_2 kernel from the raw uint8 window) against the two-launch path
+    # (conv11.hip + conv64.hip) on the same crops: same bf16 operands, conv1_1 summed in a different K order.
+    w, img, x, ref = vgg_setup
+    rng = np.random.default_rng(99)
+    img3 = np.concatenate([img, rng.integers(0, 256, size=(1, 224, 224, 3), dtype=np.uint8)])
+    img3[2, :40] = 255  # saturated / dark bands: exercises ReLU cut-off and the image borders
+    img3[2, -30:] = 0
+    host = ([L.from_jl(t) for t in w[0]], [t.cpu().numpy() for t in w[1]], (L.from_jl(w[2][0]), w[2][1].cpu().numpy()),
+            (L.from_jl(w[3][0]), w[3][1].cpu().numpy()))
+    ref3 = orc.vgg_forward(host[0], host[1], host[2], host[3], orc.preprocess_u8(img3[2:3], np.array(L.VGG_MEAN, np.float32)))
+    outs = {}
+    for knob in ("1", "0"):
+        monkeypatch.setenv("LRCN_FUSE11", knob)
+        ctx = small_ctx(lrcn_amd.LRCN_BF16, max_images=3)
+        L.vgg_load(ctx, *w)
+        outs[knob] = L.from_jl(L.convnet_u8(ctx, torch.as_tensor(img3).cuda()))
+        ctx.close()
+        assert rel_max_err(outs[knob][:2], ref) <= 3e-2 and rel_max_err(outs[knob][2:], ref3) <= 3e-2
+    assert rel_max_err(outs["1"], outs["0"]) <= 1.5e-2
