@@ -283,7 +283,8 @@ hipError_t launch_gemm(hipStream_t stream, const GemmArgs &g) {
         if (skinny_ok && g.M <= 128) return launch_gemm_skinny(stream, g);
         const char *ksk = getenv("LRCN_8P_SPLITK");  // kernel-development knob: 0 disables the split-K form
         const int sk = (ksk && ksk[0] == '0') ? 0 : gemm_8p_splitk(g, &blocks);
-        if (sk > 1 && blocks >= 96) return launch_gemm_8p(stream, g, sk);
+        const char *kth = getenv("LRCN_8P_SPLITK_MIN");
+        if (sk > 1 && blocks >= (kth ? atoi(kth) : 96)) return launch_gemm_8p(stream, g, sk);
     }
     if (!(knob && knob[0] == '0') && gemm_glds_eligible(g)) {
         const int64_t blocks = gemm_glds_blocks(g);

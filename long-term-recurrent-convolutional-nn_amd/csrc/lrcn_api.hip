@@ -60,7 +60,8 @@ struct lrcn_ctx {
     void *dxcT = nullptr;
     double *logp = nullptr;
     void *zero_page = nullptr;
-    void *gemm_ws = nullptr;  // split-K slabs of gemm_8p
+    void *gemm_ws = nullptr;  // split-K slabs of gemm_8p / gemm_skinny (LSTM side)
+    void *vgg_ws = nullptr;   // same for fc6/fc7: the VGG forward may run on another stream, concurrently with the LSTM step
     size_t gemm_ws_bytes = 0;
     int last_norm = 1, last_S = 1;
     // single-step scratch (lrcn_lstm / lrcn_step / beam search), row-major
@@ -485,6 +486,7 @@ int lrcn_create(const lrcn_config *cfg, lrcn_ctx **out) {
         if (hipMemset(c->zero_page, 0, 256) != hipSuccess) return LRCN_EHIP;
         c->gemm_ws_bytes = 48u << 20;
         DALLOC(c, c->gemm_ws, c->gemm_ws_bytes);
+        if (cfg->max_images > 0) DALLOC(c, c->vgg_ws, c->gemm_ws_bytes);
         for (int i = 0; i < 4; ++i) {
             DALLOC(c, c->st_f32[i], sizeof(float) * B * Hm);
             DALLOC(c, c->st2_f32[i], sizeof(float) * B * Hm);
@@ -904,7 +906,7 @@ int vgg_body(lrcn_ctx *c, int N, const void *src, bool src_u8, const float *mean
     g.N = 4096;
     g.K = 25088;
     g.zero_page = c->zero_page;
-    g.ws = c->gemm_ws;
+    g.ws = c->vgg_ws;
     g.ws_bytes = c->gemm_ws_bytes;
     g.C = c->f6;
     g.ldc = 4096;

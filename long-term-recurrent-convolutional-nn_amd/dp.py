@@ -6,6 +6,8 @@ forward/backward on its B_global/N rows, normalising by the GLOBAL batch (lrcn.j
 4 B/param) and an identical Adam step everywhere.  VGG is frozen (its output does not depend on the LSTM
 parameters), so the all-reduce of step k is overlapped with the VGG forward of step k+1 while keeping exactly
 synchronous-SGD semantics: RCCL runs on its own stream, the compute stream waits for it only before Adam.
+On the GPU the VGG forward of step k+1 also runs on a SIDE HIP stream, concurrently with the LSTM step k (hundreds of small,
+latency-bound launches that leave most CUs idle): the frozen extractor shares nothing with the LSTM but read-only weights.
 """
 import numpy as np
 import torch
@@ -40,8 +42,15 @@ class HipOps:
     def __init__(self, ctx):
         self.ctx = ctx
 
-    def vgg(self, img_u8):
-        return L.convnet_u8(self.ctx, img_u8)
+    def vgg(self, img_u8, feats=None):
+        return L.convnet_u8(self.ctx, img_u8, feats=feats)
+
+    def side_stream(self):
+        """A second HIP stream for the VGG forward (None = run everything in order on the caller's stream)."""
+        import os
+        if os.environ.get("LRCN_OVERLAP_VGG", "1")[:1] == "0":
+            return None
+        return torch.cuda.Stream(device=self.ctx.device)
 
     def lossgradient(self, param, feats, tokens, norm_B, pdrop, seed, grads):
         L.lossgradient(self.ctx, param, feats, tokens, norm_B=norm_B, pdrop=pdrop, seed=seed, grads=grads,
@@ -67,6 +76,9 @@ class DataParallelTrainer:
         self.flat_grads, self.grads = flat_model_like([tuple(t.shape) for t in param], device=param[0].device)
         self.step_no = 0
         self._feats_next = None
+        self._side = self.ops.side_stream() if hasattr(self.ops, "side_stream") else None
+        self._vgg_done = None    # event: the side stream finished the VGG forward whose output is _feats_next
+        self._feats_buf = [None, None]  # ping-pong outputs of the side-stream VGG
 
     def _allreduce_async(self):
         if self.world == 1:
@@ -76,19 +88,44 @@ class DataParallelTrainer:
     def vgg(self, img_u8):
         return self.ops.vgg(img_u8)
 
+    def _vgg_on_side_stream(self, img_u8):
+        """Issue VGG(img) on the side stream into a ping-pong buffer; the main stream waits on the event only when it
+        consumes the features (next step)."""
+        main = torch.cuda.current_stream(self.ctx.device)
+        k = self.step_no & 1
+        if self._feats_buf[k] is None or self._feats_buf[k].shape[0] != img_u8.shape[0]:
+            self._feats_buf[k] = L.jl_empty(img_u8.shape[0], L.CNNOUT)
+        self._side.wait_stream(main)  # the crops (and the previous consumer of this buffer) are ordered before it
+        self.ctx.use_stream(self._side)
+        try:
+            feats = self.ops.vgg(img_u8, feats=self._feats_buf[k])
+        finally:
+            self.ctx.use_stream(main)
+        self._vgg_done = torch.cuda.Event()
+        self._vgg_done.record(self._side)
+        return feats
+
     def step(self, img_u8, tokens, next_img_u8=None, feats=None):
         """One synchronous-SGD step on this rank's shard.  img_u8: this rank's uint8 crops (or feats given);
-        next_img_u8: the NEXT step's crops, whose VGG forward is issued under this step's all-reduce."""
+        next_img_u8: the NEXT step's crops, whose VGG forward runs beside this step's LSTM work and all-reduce."""
         if feats is None:
-            feats = self._feats_next if self._feats_next is not None else self.vgg(img_u8)
+            if self._feats_next is not None:
+                feats = self._feats_next
+                if self._vgg_done is not None:
+                    torch.cuda.current_stream(self.ctx.device).wait_event(self._vgg_done)
+                    self._vgg_done = None
+            else:
+                feats = self.vgg(img_u8)
         self._feats_next = None
         self.step_no += 1
+        if next_img_u8 is not None and self._side is not None:
+            self._feats_next = self._vgg_on_side_stream(next_img_u8)  # concurrent with everything below
         # rank-dependent dropout stream: masks differ per shard like rows of one big batch would
         self.ops.lossgradient(self.param, feats, tokens, self.B_global, self.pdrop,
                               (self.seed + self.step_no) * 65536 + self.rank, self.grads)
         work = self._allreduce_async()
-        if next_img_u8 is not None:
-            self._feats_next = self.vgg(next_img_u8)  # overlaps the all-reduce (frozen VGG)
+        if next_img_u8 is not None and self._side is None:
+            self._feats_next = self.vgg(next_img_u8)  # in-order variant: overlaps the all-reduce only (frozen VGG)
         if work is not None:
             work.wait()  # compute stream waits for RCCL
         self.ops.update(self.param, self.grads, self.optim)
