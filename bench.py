@@ -9,6 +9,8 @@ Workload = BASELINE.json configs[3] / SURVEY.md 8(d) "C4": MS-COCO-shaped synthe
 E=H1=H2=1000 bf16 (fp32 accumulate / master weights / Adam), V=10640, T=11, GLOBAL batch 256 split by rows over the
 N ranks ("strong" scaling), dropout 0.4, one RCCL all-reduce(SUM) of the 39.8 M fp32 gradients per step.
 A step = [VGG fwd on B/N images] + lossgradient + all-reduce + update!; inputs (uint8 crops, tokens) resident in HBM.
+The VGG forward of step k+1 runs on a side HIP stream beside the LSTM work of step k (dp.py); every step's VGG forward,
+including the first one's, is inside the timed region or the warm-up that precedes it (K steps = K VGG forwards).
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
 """
 import argparse
