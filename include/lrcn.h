@@ -157,6 +157,8 @@ int lrcn_profile_get(lrcn_ctx *ctx, double *conv_ms, int64_t *conv_launches);
 /* Diagnostic: average milliseconds of one bf16 3x3 convolution layer (N images of S x S x Cin -> Cout, optional fused
  * pool) on random data, `iters` back-to-back launches timed with HIP events.  Kernel-development aid, not the product path. */
 int lrcn_bench_conv(lrcn_ctx *ctx, int N, int S, int Cin, int Cout, int pool, int iters, double *ms_out);
+/* Same for one bf16 NT contraction C[M][N] = A[M][K] B[N][K]^T (K a multiple of 64, N of 8) through the library's dispatch. */
+int lrcn_bench_gemm(lrcn_ctx *ctx, int M, int N, int K, int iters, double *ms_out);
 
 #ifdef __cplusplus
 }

@@ -999,6 +999,43 @@ int lrcn_bench_conv(lrcn_ctx *c, int N, int S, int Cin, int Cout, int pool, int 
     return LRCN_OK;
 }
 
+// Diagnostic: time one bf16 NT GEMM C[M][N] = A[M][K] B[N][K]^T (random data, bf16 output) through launch_gemm.
+int lrcn_bench_gemm(lrcn_ctx *c, int M, int N, int K, int iters, double *ms_out) {
+    if (!c || !ms_out || M < 1 || N < 8 || K < 64 || (K % 64) || (N % 8) || iters < 1) return LRCN_EINVAL;
+    void *A = nullptr, *B = nullptr, *C = nullptr;
+    float *tmp = nullptr;
+    const size_t ae = (size_t)M * K, be = (size_t)N * K, ce = (size_t)M * N;
+    const size_t big = ae > be ? ae : be;
+    auto cleanup = [&]() {
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipFree(A); (void)hipFree(B); (void)hipFree(C); (void)hipFree(tmp);
+    };
+    if (hipMalloc(&A, 2 * ae) != hipSuccess || hipMalloc(&B, 2 * be) != hipSuccess || hipMalloc(&C, 2 * ce) != hipSuccess ||
+        hipMalloc((void **)&tmp, 4 * big) != hipSuccess) {
+        cleanup();
+        FAIL(c, LRCN_ENOMEM, "bench_gemm scratch");
+    }
+    k_init_uniform(c->stream, tmp, (int64_t)ae, 1.0f, 21, 0);
+    k_cast_rows(c->stream, GEMM_T_BF16, tmp, K, M, K, A, K);
+    k_init_uniform(c->stream, tmp, (int64_t)be, 1.0f, 22, 1);
+    k_cast_rows(c->stream, GEMM_T_BF16, tmp, K, N, K, B, K);
+    int r = gemm(c, GEMM_T_BF16, A, K, B, K, C, N, M, N, K, nullptr, false);
+    if (r) { cleanup(); return r; }
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, c->stream);
+    for (int i = 0; i < iters && !r; ++i) r = gemm(c, GEMM_T_BF16, A, K, B, K, C, N, M, N, K, nullptr, false);
+    (void)hipEventRecord(e1, c->stream);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    cleanup();
+    if (r) return r;
+    *ms_out = ms / iters;
+    return LRCN_OK;
+}
+
 int lrcn_vgg_forward(lrcn_ctx *c, const float *x, int N, float *feats) {
     if (!c || !x || !feats) return LRCN_EINVAL;
     int r = vgg_check(c, N);

@@ -1,0 +1,132 @@
+"""On-disk formats around the hot path -- host-only code.
+
+  * model checkpoints: the reference saves `model` + `vocab` as JLD/HDF5 after every epoch (`lrcn.jl:228-231, 183-186`)
+    and **never saves the optimizer** (Adam restarts cold on `--loadfile`, `:88-95`).  No HDF5 reader exists in this image,
+    so the checkpoint here is a NumPy `.npz` with the same payload in the reference's array shapes (column-major
+    semantics preserved by storing the `(rows, cols)` arrays as-is) plus what the reference forgot: Adam moments, step.
+  * MatConvNet VGG-16 (`imagenet-vgg-verydeep-16.mat`, `lrcn.jl:110-113`): `load_vgg_mat` walks `layers` like
+    `get_params_cnn` (`:697-721`) up to and including `fc7` and returns the arrays `lrcn_vgg_load` takes.
+  * Karpathy features (`feature_extractor.jl:13-50`): `dataset.json` + `vgg_feats.mat` (`feats` 4096 x N, column
+    `imgid + 1`) -> {integer filename stem: float32[4096]}; the feature dictionary itself is stored as `.npz`.
+  * crops: `center_crop_224` restates `read_image_data`'s geometry (`lrcn.jl:755-765`): resize so that the shorter side is
+    224 (integer `div`), centre crop, grey -> 3 channels; returns the uint8 `[row][col][3]` crop that
+    `lrcn_vgg_forward_u8` consumes (the float arithmetic `255 x - averageImage` and the H/W swap happen on the GPU).
+"""
+import json
+import os
+
+import numpy as np
+
+PARAM_NAMES = ["W1", "b1", "W2", "b2", "Wproj", "Wcnn", "Wembed", "Wout", "bout"]  # initweights order (lrcn.jl:489-510)
+
+
+def save_checkpoint(path, model, vocab, adam=None, meta=None):
+    """model: 9 arrays in reference shapes (host, float32); vocab: word -> 1-based id; adam: optional
+    dict(m=[9 arrays], v=[9 arrays], step=int)."""
+    d = {"param_%d_%s" % (i, n): np.asarray(a, dtype=np.float32) for i, (n, a) in enumerate(zip(PARAM_NAMES, model))}
+    d["vocab_words"] = np.array(sorted(vocab, key=vocab.get), dtype=object)
+    d["vocab_ids"] = np.array([vocab[w] for w in sorted(vocab, key=vocab.get)], dtype=np.int64)
+    if adam is not None:
+        for i, (m, v) in enumerate(zip(adam["m"], adam["v"])):
+            d["adam_m_%d" % i] = np.asarray(m, dtype=np.float32)
+            d["adam_v_%d" % i] = np.asarray(v, dtype=np.float32)
+        d["adam_step"] = np.int64(adam["step"])
+    d["meta"] = np.array(json.dumps(meta or {}))
+    tmp = path + ".tmp.npz"
+    np.savez(tmp, **d)
+    os.replace(tmp, path)
+
+
+def load_checkpoint(path):
+    """-> (model list of 9 float32 arrays, vocab dict, adam dict or None, meta dict)."""
+    z = np.load(path, allow_pickle=True)
+    model = [z["param_%d_%s" % (i, n)] for i, n in enumerate(PARAM_NAMES)]
+    vocab = {str(w): int(i) for w, i in zip(z["vocab_words"], z["vocab_ids"])}
+    adam = None
+    if "adam_step" in z.files:
+        adam = {"m": [z["adam_m_%d" % i] for i in range(9)], "v": [z["adam_v_%d" % i] for i in range(9)],
+                "step": int(z["adam_step"])}
+    return model, vocab, adam, json.loads(str(z["meta"]))
+
+
+def save_features(path, feats):
+    """feats: {image id: float32[4096]} (the reference's Dict{Int,Array{Float32}} saved as feats.jld)."""
+    ids = np.array(sorted(feats), dtype=np.int64)
+    np.savez(path, ids=ids, feats=np.stack([np.asarray(feats[i], dtype=np.float32).reshape(-1) for i in ids]))
+
+
+def load_features(path, normalize=False):
+    """-> {image id: float32[4096]}.  normalize=True divides each vector by its sum, which is what the reference's
+    `featsn` files hold and what `generate` does for fresh images (`lrcn.jl:597`)."""
+    z = np.load(path)
+    out = {}
+    for i, f in zip(z["ids"], z["feats"]):
+        out[int(i)] = f / f.sum() if normalize else f
+    return out
+
+
+def karpathy_features(dataset_json_path, vgg_feats_mat_path):
+    """feature_extractor.jl:13-34: image k of dataset.json -> column imgid of `feats`, keyed by the integer filename stem."""
+    from scipy.io import loadmat
+    with open(dataset_json_path) as f:
+        images = json.load(f)["images"]
+    feats = loadmat(vgg_feats_mat_path)["feats"]  # 4096 x N
+    out = {}
+    for im in images:
+        key = int(im["filename"].split(".")[0])
+        out.setdefault(key, np.ascontiguousarray(feats[:, im["imgid"]], dtype=np.float32))
+    return out
+
+
+def load_vgg_mat(path, last_layer="fc7"):
+    """MatConvNet model -> (conv_w[13] (3,3,Cin,Cout), conv_b[13], (fc6_w (4096,25088), fc6_b), (fc7_w (4096,4096), fc7_b),
+    average RGB).  Follows get_params_cnn (lrcn.jl:697-721): conv weights as stored, fc weight = transpose(mat(w)), i.e.
+    the (7,7,512,4096) array flattened column-major over (w,h,c) then transposed; stops after `last_layer` inclusive."""
+    from scipy.io import loadmat
+    m = loadmat(path, squeeze_me=False, struct_as_record=False)
+    layers = m["layers"].ravel()
+    conv_w, conv_b, fcs = [], [], []
+    for cell in layers:
+        L = cell[0, 0] if isinstance(cell, np.ndarray) else cell
+        name = str(np.ravel(L.name)[0])
+        w = getattr(L, "weights", None)
+        if w is not None and np.size(w):
+            w0, w1 = w.ravel()[0], w.ravel()[1]
+            if name.startswith("conv"):
+                conv_w.append(np.asarray(w0, dtype=np.float32))
+                conv_b.append(np.asarray(w1, dtype=np.float32).reshape(-1))
+            elif name.startswith("fc"):
+                w0 = np.asarray(w0, dtype=np.float32)
+                flat = w0.reshape((-1, w0.shape[-1]), order="F")  # mat(w): (w*h*c) x out, column-major flatten
+                fcs.append((np.ascontiguousarray(flat.T), np.asarray(w1, dtype=np.float32).reshape(-1)))
+        if name.startswith(last_layer):
+            break
+    mean = None
+    try:
+        meta = m["meta"][0, 0]
+        mean = np.asarray(meta.normalization[0, 0].averageImage, dtype=np.float32).reshape(-1)[:3]
+    except Exception:  # older files keep it under "normalization"
+        try:
+            mean = np.asarray(m["normalization"][0, 0].averageImage, dtype=np.float32).mean(axis=(0, 1))
+        except Exception:
+            pass
+    if len(conv_w) != 13 or len(fcs) != 2:
+        raise ValueError("expected 13 conv + 2 fc weighted layers up to %s, found %d + %d" % (last_layer, len(conv_w), len(fcs)))
+    return conv_w, conv_b, fcs[0], fcs[1], mean
+
+
+def center_crop_224(img):
+    """read_image_data's geometry (lrcn.jl:755-765) on a decoded image (PIL.Image or HxW[x3] uint8 array): resize so the
+    shorter side is 224 with the other side div(side * 224, shorter), centre crop with div offsets, grey -> 3 channels.
+    -> uint8 [224][224][3] (row, col, channel).  Resampling is bilinear (Images.imresize's kernel is not pinned)."""
+    from PIL import Image
+    if not isinstance(img, Image.Image):
+        img = Image.fromarray(np.asarray(img))
+    img = img.convert("RGB")
+    w, h = img.size  # PIL: (width, height); the reference's size(a0) = (rows, cols) = (h, w)
+    s = min(h, w)
+    nh, nw = (h * 224) // s, (w * 224) // s
+    img = img.resize((nw, nh), Image.BILINEAR)
+    i1, j1 = (nh - 224) // 2, (nw - 224) // 2
+    a = np.asarray(img, dtype=np.uint8)[i1:i1 + 224, j1:j1 + 224, :3]
+    return np.ascontiguousarray(a)

@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Driver with the flag surface of `lrcn.jl`'s main (lrcn.jl:29-188): tokenise -> init/load -> one of
+{train, generate, extfeatures}, running the hot path on an MI355X through liblrcn_hip (no CPU path).
+
+    python tools/lrcn.py --coco --train --datafiles captions_train2014.json captions_val2014.json \
+        --features train_feats.npz val_feats.npz --savefile m.npz
+    python tools/lrcn.py --coco --loadfile m.npz --generate 30 --beam_width 5 --datafiles ... --features ...
+    python tools/lrcn.py --cnn --model imagenet-vgg-verydeep-16.mat --loadfile m.npz --generate 30 photo.jpg
+    python tools/lrcn.py --cnn --model vgg.mat --extfeatures --imagedir train2014 --prefix COCO_train2014_ --datafiles ...
+
+Differences from the reference, all documented in SURVEY.md 5.6 / A.8: `--lr` (default 0.001 = what the reference's
+Adam() actually uses) and `--gclip` (default 0 = off) are honoured instead of being parsed and ignored; `--bestfile` is
+accepted; data locations are flags (`--features`, `--imagedir`, `--out`) instead of hard-coded paths; files are `.npz`
+(formats.py) because JLD/HDF5 cannot be read here; `--dropout` exists (default 0.4 = the hard-coded pdrop of train!).
+"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description="LRCN (MI355X): Long-term Recurrent Convolutional Networks for Visual "
+                                            "Recognition and Description -- lrcn.jl's CLI on liblrcn_hip")
+    p.add_argument("image", nargs="?", default=None, help="Image file (with --cnn --generate).")
+    p.add_argument("--model", default="imagenet-vgg-verydeep-16.mat", help="Location of the MatConvNet VGG-16 file")
+    p.add_argument("--datafiles", nargs="+", default=[], help="first file: training captions, second: dev, others: test")
+    p.add_argument("--loadfile", help="Initialize model from file")
+    p.add_argument("--savefile", help="Save final model to file")
+    p.add_argument("--bestfile", help="accepted for compatibility (lrcn.jl:63 reads it)")
+    p.add_argument("--generate", type=int, default=0, help="If non-zero generate captions of at most this many words.")
+    p.add_argument("--hidden", nargs="+", type=int, default=[1000, 1000], help="Sizes of the two LSTM layers.")
+    p.add_argument("--embed", type=int, default=1000, help="Size of the embedding vector.")
+    p.add_argument("--epochs", type=int, default=10)
+    p.add_argument("--capnumber", type=int, default=1000, help="Number of captions to generate.")
+    p.add_argument("--batchsize", type=int, default=25, help="Number of sentences to train on in parallel.")
+    p.add_argument("--lr", type=float, default=0.001, help="Adam learning rate (the reference always ran 0.001).")
+    p.add_argument("--gclip", type=float, default=0.0, help="Gradient-norm clip (0 = off, as in the reference).")
+    p.add_argument("--seed", type=int, default=-1)
+    p.add_argument("--atype", default="bf16", choices=["bf16", "f32", "KnetArray{Float32}", "Array{Float32}"],
+                   help="arithmetic type of the LSTM/VGG kernels (the reference's array-type strings select f32)")
+    p.add_argument("--train", action="store_true")
+    p.add_argument("--cnn", action="store_true", help="load the VGG-16 weights")
+    p.add_argument("--extfeatures", action="store_true", help="extract fc7 features for the first caption file's images")
+    p.add_argument("--flickr", action="store_true")
+    p.add_argument("--coco", action="store_true")
+    p.add_argument("--beam_width", type=int, default=3)
+    p.add_argument("--dropout", type=float, default=0.4, help="pdrop of train! (lrcn.jl:227)")
+    p.add_argument("--features", nargs="+", default=[], help=".npz feature dictionaries: train [val] (formats.save_features)")
+    p.add_argument("--imagedir", default=".", help="directory of the images for --extfeatures")
+    p.add_argument("--prefix", default="", help="file-name prefix before the zero-padded id (COCO_train2014_)")
+    p.add_argument("--out", default="eval", help="directory for candidates / ids files of --generate")
+    return p
+
+
+def tokenize_all(o, cap):
+    """Tokenizer.tokenize (tokenizer.jl:6-31): vocab over all files, caption lists per split."""
+    lists, counted = [], []
+    for path in o.datafiles:
+        kind = path.split(".")[-1]
+        with open(path) as f:
+            if kind == "token":
+                lines = f.readlines()
+                counted.append(cap.tokenize_flickr(lines))  # vocab counts every caption incl. val/test (:13-15)
+                lists.extend(cap.split_flickr(lines))
+            elif kind == "json":
+                d = cap.tokenize_coco(f.read())
+                lists.append(d)
+                counted.append(d)
+            else:
+                print("invalid caption file:", path)
+    return cap.build_vocab(counted), lists
+
+
+def main(argv=None):
+    o = build_parser().parse_args(argv)
+    print("opts=", sorted(vars(o).items()))
+    import numpy as np
+    import torch
+    import lrcn_amd
+    from lrcn_amd import captions as cap
+    from lrcn_amd import formats as fmt
+    from lrcn_amd import lrcn as L
+
+    if o.seed > 0:
+        np.random.seed(o.seed)
+    rng = np.random.default_rng(o.seed if o.seed > 0 else None)
+    dt = lrcn_amd.LRCN_F32 if o.atype in ("f32", "KnetArray{Float32}", "Array{Float32}") else lrcn_amd.LRCN_BF16
+    vocab, lists = None, []
+    if o.datafiles:
+        print("Tokenization starts")
+        vocab, lists = tokenize_all(o, cap)
+        print("Tokenization finished")
+    adam_state = None
+    host_model = None
+    if o.loadfile:
+        print("Loading model from", o.loadfile)
+        host_model, vocab, adam_state, _ = fmt.load_checkpoint(o.loadfile)
+    if vocab is None:
+        raise SystemExit("need --datafiles or --loadfile (no vocabulary)")
+    V = len(vocab)
+    print("%d unique words" % V)
+    if len(o.hidden) != 2 or o.hidden[1] % 2:
+        raise SystemExit("--hidden takes two sizes, the second even (LRCN-2f, lrcn.jl:496-504)")
+    H1, H2 = o.hidden
+    ctx = L.Context(o.embed, H1, H2, V, max_B=max(o.batchsize, o.beam_width, 10), lstm_dtype=dt, vgg_dtype=dt,
+                    max_images=max(o.batchsize, 1) if o.cnn else 0)
+    param = L.initweights(ctx, seed=o.seed if o.seed > 0 else 42) if host_model is None else L.model_from_arrays(host_model)
+    print("LSTM is initialized")
+    mean = L.VGG_MEAN
+    if o.cnn:
+        print("Reading", o.model)
+        cw, cb, fc6, fc7, m = fmt.load_vgg_mat(o.model)
+        if m is not None:
+            mean = tuple(float(v) for v in m)
+        L.vgg_load(ctx, [L.to_jl(w) for w in cw], [torch.as_tensor(b).cuda() for b in cb],
+                   (L.to_jl(fc6[0]), torch.as_tensor(fc6[1]).cuda()), (L.to_jl(fc7[0]), torch.as_tensor(fc7[1]).cuda()))
+        print("Cnn is initialized")
+    feats = [fmt.load_features(p) for p in o.features]
+    idx2word = cap.index_to_word(vocab)
+
+    def feature_rows(table, ids):
+        return L.to_jl(np.stack([table[i].reshape(-1) for i in ids]).astype(np.float32))
+
+    # ---------------------------------------------------------------- generate (lrcn.jl:127-160)
+    if o.generate > 0:
+        if o.cnn:
+            from PIL import Image
+            crop = fmt.center_crop_224(Image.open(o.image))
+            f = L.from_jl(L.convnet_u8(ctx, torch.as_tensor(crop[None]).cuda(), mean=mean))[0]
+            toks, _ = L.beam_search(ctx, param, L.to_jl((f / f.sum())[None].astype(np.float32)), o.beam_width, o.generate)
+            print(cap.caption_text(toks, idx2word))
+            return 0
+        split = lists[2] if o.flickr and len(lists) > 2 else lists[min(1, len(lists) - 1)]
+        table = feats[min(1, len(feats) - 1)] if o.coco else feats[0]
+        ids = []
+        for k in rng.permutation(len(split)):
+            i = split[k][0][0]
+            if i not in ids:
+                ids.append(i)
+            if len(ids) == o.capnumber:
+                break
+        os.makedirs(o.out, exist_ok=True)
+        suffix = "_flickr" if o.flickr else ".txt"
+        with open(os.path.join(o.out, "candidates" + suffix), "w") as out, open(os.path.join(o.out, "candidate_ids" + suffix), "w") as ido:
+            for i in ids:
+                toks, _ = L.beam_search(ctx, param, feature_rows(table, [i]), o.beam_width, o.generate)
+                ido.write("%d\n" % i)
+                out.write(cap.caption_text(toks, idx2word) + "\n")
+        return 0
+
+    # ---------------------------------------------------------------- extract features (lrcn.jl:162-172, 190-221)
+    if o.extfeatures:
+        from PIL import Image
+        ids = sorted({c[0][0] for c in lists[0]})
+        table, B = {}, max(o.batchsize, 1)
+        for s in range(0, len(ids), B):
+            chunk = ids[s:s + B]
+            crops = np.stack([fmt.center_crop_224(Image.open(os.path.join(o.imagedir, "%s%012d.jpg" % (o.prefix, i) if o.prefix
+                                                                        else "%d.jpg" % i))) for i in chunk])
+            f = L.from_jl(L.convnet_u8(ctx, torch.as_tensor(crops).cuda(), mean=mean))
+            for i, row in zip(chunk, f):
+                table[i] = row.copy()
+        fmt.save_features(o.savefile or "feats.npz", table)
+        print("image features extracted")
+        return 0
+
+    # ---------------------------------------------------------------- train! (lrcn.jl:223-246)
+    if lists and o.train:
+        print("Batching starts")
+        seqs = [cap.minibatch(c, vocab, o.batchsize) for c in lists]
+        print("Batching finished")
+        optim = L.initparams(param)
+        optim.lr = o.lr
+        if adam_state is not None:
+            for dst, src in zip(optim.m, adam_state["m"]):
+                dst.copy_(L.to_jl(src))
+            for dst, src in zip(optim.v, adam_state["v"]):
+                dst.copy_(L.to_jl(src))
+            optim.t = adam_state["step"]
+        grads = L.zeros_like_model(param)
+
+        def average_loss(seq, table):
+            blocks = [(feature_rows(table, ids), toks) for ids, toks in cap.batches(seq[0], seq[1], seq[2], seq[3])]
+            return L.average_loss(ctx, param, blocks)
+
+        for epoch in range(1, o.epochs + 1):
+            seq, t0, nimg = seqs[0], time.time(), 0
+            blocks = list(cap.batches(seq[0], seq[1], seq[2], seq[3]))
+            for k in rng.permutation(len(blocks)):  # shuffle(1:batch_size:length(lengths)), lrcn.jl:351
+                ids, toks = blocks[k]
+                if o.gclip > 0:
+                    g, _ = L.lossgradient(ctx, param, feature_rows(feats[0], ids), toks, pdrop=o.dropout, seed=epoch * 1000003 + int(k),
+                                          grads=grads)
+                    gn = float(torch.sqrt(sum((t.float() ** 2).sum() for t in g)))
+                    if gn > o.gclip:
+                        for t in g:
+                            t.mul_(o.gclip / gn)
+                    L.update(ctx, param, g, optim)
+                else:
+                    L.train_step(ctx, param, optim, grads, feature_rows(feats[0], ids), toks, pdrop=o.dropout, seed=epoch * 1000003 + int(k))
+                nimg += len(ids)
+            ctx.sync()
+            dt_s = time.time() - t0
+            if o.savefile:
+                fmt.save_checkpoint(o.savefile, [L.from_jl(p) for p in param], vocab,
+                                    adam={"m": [L.from_jl(t) for t in optim.m], "v": [L.from_jl(t) for t in optim.v], "step": optim.t})
+            losses = [average_loss(seqs[0], feats[0])]
+            if len(seqs) > 1:
+                losses.append(average_loss(seqs[1], feats[min(1, len(feats) - 1)]))
+            print("(:epoch, %d, :loss, %s)  [%.0f captions/s]" % (epoch, ", ".join("%.4f" % v for v in losses), nimg / max(dt_s, 1e-9)))
+    if o.savefile and not o.train:
+        fmt.save_checkpoint(o.savefile, [L.from_jl(p) for p in param], vocab)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
