@@ -51,6 +51,22 @@ void k_transpose(hipStream_t st, int dtype, int in_f32, const void *in, int64_t 
                  int64_t ld_out, int shift);
 // out_f32[c][r] = in[r][c], f32 -> f32 (boundary layout changes)
 void k_transpose_f32(hipStream_t st, const float *in, int64_t ld_in, int R, int C, float *out, int64_t ld_out);
+// One launch for all shadow weights: parameter memory image src[R][C] (f32, C contiguous) -> direct copies split at column cs
+// (dA[r][c] | dB[r][c - cs]) and transposed copies (tA[c][r] | tB[c - cs][r]) in T; NULL destinations are skipped.  Padding
+// columns of the destinations are left as they are (zero since allocation).
+#define PREP_MAX 8
+struct PrepDesc {
+    const float *src;
+    int R, C, cs;
+    void *dA, *dB, *tA, *tB;
+    int64_t ldA, ldB, ldtA, ldtB;
+    int tile0;
+};
+struct PrepPlan {
+    PrepDesc d[PREP_MAX];
+    int n;
+};
+void k_prepare_weights(hipStream_t st, int dtype, PrepPlan &plan);
 // out[r][c] = (T) in[r*ld_in + c]  (f32 -> T copy of a sub-matrix; pads [C, ld_out) with zeros)
 void k_cast_rows(hipStream_t st, int dtype, const float *in, int64_t ld_in, int R, int C, void *out, int64_t ld_out);
 // out[r][c] = (T) act(in[r][c] + bias[c])  (epilogue of a split-K GEMM whose partial sums were combined in f32)

@@ -242,6 +242,47 @@ __global__ void transpose_kernel(const Tin *in, int64_t ld_in, int R, int C, Tou
     }
 }
 
+// All shadow weights of one model in ONE launch (was 8 cast_rows + 9 transpose launches per step): for every 32 x 32 tile of
+// a parameter's memory image [R][C] (f32) write the direct copy split at column `cs` (dA[r][c], dB[r][c - cs]) and / or the
+// transposed copy (tA[c][r], tB[c - cs][r]) in T.  Padding columns of the destinations are never touched (zero since allocation).
+template <typename T> __global__ void prepare_weights_kernel(const PrepPlan plan) {
+    __shared__ float tile[32][33];
+    int d = 0;
+#pragma unroll
+    for (int k = 1; k < PREP_MAX; ++k)
+        if (k < plan.n && (int)blockIdx.x >= plan.d[k].tile0) d = k;
+    const PrepDesc &P = plan.d[d];
+    const int t = blockIdx.x - P.tile0;
+    const int tc = (P.C + 31) / 32;
+    const int r0 = (t / tc) * 32, c0 = (t % tc) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        const bool ok = r < P.R && c < P.C;
+        const float v = ok ? P.src[(int64_t)r * P.C + c] : 0.0f;
+        tile[i][tx] = v;
+        if (ok) {
+            if (c < P.cs) {
+                if (P.dA) reinterpret_cast<T *>(P.dA)[(int64_t)r * P.ldA + c] = from_f32<T>(v);
+            } else if (P.dB) {
+                reinterpret_cast<T *>(P.dB)[(int64_t)r * P.ldB + (c - P.cs)] = from_f32<T>(v);
+            }
+        }
+    }
+    if (!P.tA && !P.tB) return;
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < P.C && r < P.R) {
+            if (c < P.cs) {
+                if (P.tA) reinterpret_cast<T *>(P.tA)[(int64_t)c * P.ldtA + r] = from_f32<T>(tile[tx][i]);
+            } else if (P.tB) {
+                reinterpret_cast<T *>(P.tB)[(int64_t)(c - P.cs) * P.ldtB + r] = from_f32<T>(tile[tx][i]);
+            }
+        }
+    }
+}
+
 template <typename T>
 __global__ void cast_rows_kernel(const float *in, int64_t ld_in, int R, int C, T *out, int64_t ld_out) {
     const int r = blockIdx.y;
@@ -565,6 +606,15 @@ void k_transpose(hipStream_t st, int dtype, int in_f32, const void *in, int64_t 
 void k_transpose_f32(hipStream_t st, const float *in, int64_t ld_in, int R, int C, float *out, int64_t ld_out) {
     hipLaunchKernelGGL((transpose_kernel<float, float>), dim3(cdiv(C, 32), cdiv(R, 32)), dim3(256), 0, st, in, ld_in, R, C,
                        out, ld_out, 0);
+}
+void k_prepare_weights(hipStream_t st, int dtype, PrepPlan &plan) {
+    int tiles = 0;
+    for (int k = 0; k < plan.n; ++k) {
+        plan.d[k].tile0 = tiles;
+        tiles += cdiv(plan.d[k].R, 32) * cdiv(plan.d[k].C, 32);
+    }
+    if (tiles == 0) return;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(prepare_weights_kernel<T>, dim3(tiles), dim3(256), 0, st, plan));
 }
 void k_cast_rows(hipStream_t st, int dtype, const float *in, int64_t ld_in, int R, int C, void *out, int64_t ld_out) {
     const dim3 grid(cdiv(ld_out, 256) > 64 ? 64 : cdiv(ld_out, 256), R);

@@ -185,23 +185,23 @@ DropSpec make_drop(const lrcn_dropout *d, int which) {
 int prepare_weights(lrcn_ctx *c, const float *const p[9], bool need_bwd) {
     const int dt = c->dt, E = c->E, H1 = c->H1, H2 = c->H2, h = c->h, V = c->V;
     hipStream_t st = c->stream;
-    // W1: memory [4H1][E+H1]
-    k_cast_rows(st, dt, p[0], E + H1, 4 * H1, E, c->W1x, c->ldE);
-    k_cast_rows(st, dt, p[0] + E, E + H1, 4 * H1, H1, c->W1h, c->ldH1);
-    k_cast_rows(st, dt, p[2], 2 * H2, 4 * H2, H2, c->W2x, c->ldH2);
-    k_cast_rows(st, dt, p[2] + H2, 2 * H2, 4 * H2, H2, c->W2h, c->ldH2);
-    k_cast_rows(st, dt, p[4], H1, h, H1, c->Wpd, c->ldH1);           // Wproj (H1 x h) memory [h][H1]
-    k_cast_rows(st, dt, p[5], LRCN_CNNOUT, h, LRCN_CNNOUT, c->Wcd, LRCN_CNNOUT);  // Wcnn memory [h][4096]
-    k_transpose(st, dt, 1, p[6], V, E, V, c->WeT, c->ldE, 0);        // Wembed (V x E) memory [E][V] -> [V][ldE]
-    k_cast_rows(st, dt, p[7], H2, V, H2, c->Wod, c->ldH2);           // Wout (H2 x V) memory [V][H2]
-    if (need_bwd) {
-        k_transpose(st, dt, 1, p[0], E + H1, 4 * H1, E, c->W1xT, c->ld4H1, 0);
-        k_transpose(st, dt, 1, p[0] + E, E + H1, 4 * H1, H1, c->W1hT, c->ld4H1, 0);
-        k_transpose(st, dt, 1, p[2], 2 * H2, 4 * H2, H2, c->W2xT, c->ld4H2, 0);
-        k_transpose(st, dt, 1, p[2] + H2, 2 * H2, 4 * H2, H2, c->W2hT, c->ld4H2, 0);
-        k_transpose(st, dt, 1, p[4], H1, h, H1, c->WpT, c->ldh, 0);   // -> [H1][ldh]
-        k_transpose(st, dt, 1, p[7], H2, V, H2, c->WoT, c->ldV, 0);   // -> [H2][ldV]
-    }
+    PrepPlan plan{};
+    auto add = [&](const float *src, int R, int C, int cs, void *dA, int64_t ldA, void *dB, int64_t ldB, void *tA, int64_t ldtA, void *tB,
+                   int64_t ldtB) {
+        PrepDesc &d = plan.d[plan.n++];
+        d.src = src; d.R = R; d.C = C; d.cs = cs;
+        d.dA = dA; d.ldA = ldA; d.dB = dB; d.ldB = ldB;
+        d.tA = tA; d.ldtA = ldtA; d.tB = tB; d.ldtB = ldtB;
+    };
+    const bool b = need_bwd;
+    // W1: memory [4H1][E + H1] -> W1x | W1h (and their transposes [E][ld4H1] | [H1][ld4H1] for the backward dX GEMMs)
+    add(p[0], 4 * H1, E + H1, E, c->W1x, c->ldE, c->W1h, c->ldH1, b ? c->W1xT : nullptr, c->ld4H1, b ? c->W1hT : nullptr, c->ld4H1);
+    add(p[2], 4 * H2, 2 * H2, H2, c->W2x, c->ldH2, c->W2h, c->ldH2, b ? c->W2xT : nullptr, c->ld4H2, b ? c->W2hT : nullptr, c->ld4H2);
+    add(p[4], h, H1, H1, c->Wpd, c->ldH1, nullptr, 0, b ? c->WpT : nullptr, c->ldh, nullptr, 0);  // Wproj (H1 x h): memory [h][H1]
+    add(p[5], h, LRCN_CNNOUT, LRCN_CNNOUT, c->Wcd, LRCN_CNNOUT, nullptr, 0, nullptr, 0, nullptr, 0);   // Wcnn: memory [h][4096]
+    add(p[6], E, V, V, nullptr, 0, nullptr, 0, c->WeT, c->ldE, nullptr, 0);                          // Wembed (V x E): memory [E][V] -> [V][ldE]
+    add(p[7], V, H2, H2, c->Wod, c->ldH2, nullptr, 0, b ? c->WoT : nullptr, c->ldV, nullptr, 0);   // Wout (H2 x V): memory [V][H2]
+    k_prepare_weights(st, dt, plan);
     KCHK(c, "prepare_weights");
     return LRCN_OK;
 }

@@ -1,0 +1,19 @@
+import sys, time, os
+sys.path.insert(0, '/root/repo')
+import numpy as np, torch
+import lrcn_amd
+from lrcn_amd import lrcn as L
+B=int(sys.argv[1]); E=H=1000; V=10640; T=11
+ctx = L.Context(E,H,H,V,max_B=B,max_T=T,lstm_dtype=lrcn_amd.LRCN_BF16)
+param = L.initweights(ctx, seed=42); optim = L.initparams(param); grads = L.zeros_like_model(param)
+feats = L.to_jl((np.random.default_rng(0).standard_normal((B,4096))*0.01).astype(np.float32))
+toks = torch.as_tensor(np.random.default_rng(1).integers(3,V,size=(T,B)).astype(np.int32)).cuda()
+for _ in range(5): L.train_step(ctx,param,optim,grads,feats,toks,pdrop=0.4,seed=1)
+torch.cuda.synchronize()
+n=30
+t0=time.perf_counter()
+for i in range(n): L.train_step(ctx,param,optim,grads,feats,toks,pdrop=0.4,seed=i)
+t1=time.perf_counter()
+torch.cuda.synchronize()
+t2=time.perf_counter()
+print("B=%d host enqueue %.3f ms/step, total %.3f ms/step"%(B,(t1-t0)/n*1e3,(t2-t0)/n*1e3))
