@@ -106,6 +106,14 @@ int lrcn_loss(lrcn_ctx *ctx, const float *const params[9], const float *feats, c
 int lrcn_loss_grad(lrcn_ctx *ctx, const float *const params[9], const float *feats, const int32_t *tokens, int T,
                    int B, int norm_B, const lrcn_dropout *drop, float *const grads[9], double *loss_host);
 
+/* Gradient-ready events (new: lets a data-parallel host start the all-reduce of a gradient group while lossgradient's
+ * backward is still running).  lrcn_loss_grad finalises the nine gradients in this order of GROUPS:
+ *   0: Wout, bout (params 7, 8)   1: W2, b2 (2, 3)   2: Wproj, Wcnn (4, 5)   3: W1, b1 (0, 1)   4: Wembed (6)
+ * and records an event on the context's stream after each.  lrcn_grad_group_wait makes `stream` (a hipStream_t) wait for
+ * the event of `group` of the most recent lrcn_loss_grad / lrcn_train_step call. */
+#define LRCN_GRAD_GROUPS 5
+int lrcn_grad_group_wait(lrcn_ctx *ctx, int group, void *stream);
+
 /* The loss of the most recent lrcn_loss/_loss_grad/_train_step call (synchronises). */
 int lrcn_last_loss(lrcn_ctx *ctx, double *loss_host);
 

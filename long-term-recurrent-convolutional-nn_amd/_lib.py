@@ -57,6 +57,7 @@ SIGNATURES = {
                             C.POINTER(C.c_double)]),
     "lrcn_loss_grad": (C.c_int, [C.c_void_p, P9, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(Dropout),
                                  P9, C.POINTER(C.c_double)]),
+    "lrcn_grad_group_wait": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "lrcn_last_loss": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "lrcn_forward_logits": (C.c_int, [C.c_void_p, P9, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "lrcn_adam_update": (C.c_int, [C.c_void_p, P9, P9, P9, P9, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]),

@@ -60,6 +60,7 @@ struct lrcn_ctx {
     void *dxcT = nullptr;
     double *logp = nullptr;
     void *zero_page = nullptr;
+    hipEvent_t grad_ev[LRCN_GRAD_GROUPS] = {};  // recorded when the gradients of a group are final (lrcn_grad_group_wait)
     void *gemm_ws = nullptr;  // split-K slabs of gemm_8p / gemm_skinny (LSTM side)
     void *vgg_ws = nullptr;   // same for fc6/fc7: the VGG forward may run on another stream, concurrently with the LSTM step
     size_t gemm_ws_bytes = 0;
@@ -302,6 +303,7 @@ int loss_impl(lrcn_ctx *c, const float *const p[9], const float *feats, const in
     k_transpose(st, dt, 0, c->H2all, c->ldH2, M, H2, c->TB, ldM, 0);     // H2all^T [H2][ldM]
     GEMM(c, dt, c->TA, ldM, c->TB, ldM, grads[7], H2, V, H2, M, nullptr, true);
     k_colsum(st, dt, c->dLog, c->ldV, M, V, grads[8]);
+    HIPCHK(c, hipEventRecord(c->grad_ev[0], st));  // group 0: Wout, bout
     GEMM(c, dt, c->dLog, c->ldV, c->WoT, c->ldV, c->dH2all, H2, M, H2, V, nullptr, true);
     // ---- LSTM 2 ----
     r = lstm_layer_bwd(c, S, B, H2, c->ld4H2, c->A2, c->C2, c->dH2all, c->W2hT, c->dZ2);
@@ -315,6 +317,7 @@ int loss_impl(lrcn_ctx *c, const float *const p[9], const float *feats, const in
         HIPCHK(c, hipMemsetAsync(c->TB, 0, es * (size_t)H2 * ldM, st));
     GEMM(c, dt, c->TA, ldM, c->TB, ldM, grads[2] + H2, 2 * H2, 4 * H2, H2, M, nullptr, true);
     k_colsum(st, dt, c->dZ2, c->ld4H2, M, 4 * H2, grads[3]);
+    HIPCHK(c, hipEventRecord(c->grad_ev[1], st));  // group 1: W2, b2
     GEMM(c, dt, c->dZ2, c->ld4H2, c->W2xT, c->ld4H2, c->dX2, c->ldH2, M, H2, 4 * H2, nullptr, false);
     k_dx2_mask_reduce(st, dt, c->dX2, c->ldH2, S, B, h, d2, c->dxcnn, c->ldh);
     // ---- projection and image embedding ----
@@ -325,6 +328,7 @@ int loss_impl(lrcn_ctx *c, const float *const p[9], const float *feats, const in
     k_transpose(st, dt, 1, c->dxcnn, c->ldh, B, h, c->dxcT, ldB, 0);     // dxcnn^T [h][ldB]
     k_cast_rows(st, dt, feats, B, LRCN_CNNOUT, B, c->FT, ldB);           // feats^T [4096][ldB] (it already is, in memory)
     GEMM(c, dt, c->dxcT, ldB, c->FT, ldB, grads[5], LRCN_CNNOUT, h, LRCN_CNNOUT, B, nullptr, true);
+    HIPCHK(c, hipEventRecord(c->grad_ev[2], st));  // group 2: Wproj, Wcnn
     // ---- LSTM 1 ----
     r = lstm_layer_bwd(c, S, B, H1, c->ld4H1, c->A1, c->C1, c->dH1all, c->W1hT, c->dZ1);
     if (r) return r;
@@ -337,9 +341,11 @@ int loss_impl(lrcn_ctx *c, const float *const p[9], const float *feats, const in
         HIPCHK(c, hipMemsetAsync(c->TB, 0, es * (size_t)H1 * ldM, st));
     GEMM(c, dt, c->TA, ldM, c->TB, ldM, grads[0] + E, E + H1, 4 * H1, H1, M, nullptr, true);
     k_colsum(st, dt, c->dZ1, c->ld4H1, M, 4 * H1, grads[1]);
+    HIPCHK(c, hipEventRecord(c->grad_ev[3], st));  // group 3: W1, b1
     GEMM(c, dt, c->dZ1, c->ld4H1, c->W1xT, c->ld4H1, c->dXemb, c->ldE, M, E, 4 * H1, nullptr, true);
     HIPCHK(c, hipMemsetAsync(grads[6], 0, sizeof(float) * (size_t)V * E, st));
     k_embed_scatter(st, c->dXemb, c->ldE, c->tok_in, S, B, E, V, d1, grads[6]);
+    HIPCHK(c, hipEventRecord(c->grad_ev[4], st));  // group 4: Wembed
     KCHK(c, "backward");
     return LRCN_OK;
 }
@@ -409,6 +415,8 @@ void lrcn_destroy(lrcn_ctx *c) {
     (void)hipSetDevice(c->cfg.device);
     (void)hipDeviceSynchronize();
     for (void *p : c->allocs) (void)hipFree(p);
+    for (auto &e : c->grad_ev)
+        if (e) (void)hipEventDestroy(e);
     for (auto &e : c->prof_ev) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
@@ -484,6 +492,8 @@ int lrcn_create(const lrcn_config *cfg, lrcn_ctx **out) {
         DALLOC(c, c->logp, sizeof(double) * 2);
         DALLOC(c, c->zero_page, 256);
         if (hipMemset(c->zero_page, 0, 256) != hipSuccess) return LRCN_EHIP;
+        for (auto &e : c->grad_ev)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return LRCN_EHIP;
         c->gemm_ws_bytes = 48u << 20;
         DALLOC(c, c->gemm_ws, c->gemm_ws_bytes);
         if (cfg->max_images > 0) DALLOC(c, c->vgg_ws, c->gemm_ws_bytes);
@@ -565,6 +575,12 @@ int lrcn_loss_grad(lrcn_ctx *c, const float *const p[9], const float *feats, con
     int r = loss_impl(c, p, feats, tokens, T, B, norm_B, drop, grads, nullptr);
     if (r) return r;
     return loss_host ? fetch_loss(c, loss_host) : LRCN_OK;
+}
+
+int lrcn_grad_group_wait(lrcn_ctx *c, int group, void *stream) {
+    if (!c || group < 0 || group >= LRCN_GRAD_GROUPS) return LRCN_EINVAL;
+    HIPCHK(c, hipStreamWaitEvent(reinterpret_cast<hipStream_t>(stream), c->grad_ev[group], 0));
+    return LRCN_OK;
 }
 
 int lrcn_last_loss(lrcn_ctx *c, double *loss_host) {

@@ -9,6 +9,9 @@ synchronous-SGD semantics: RCCL runs on its own stream, the compute stream waits
 On the GPU the VGG forward of step k+1 also runs on a SIDE HIP stream, concurrently with the LSTM step k (hundreds of small,
 latency-bound launches that leave most CUs idle): the frozen extractor shares nothing with the LSTM but read-only weights.
 """
+import ctypes as C
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -22,6 +25,10 @@ def shard_rows(B_global, world, rank):
         raise L.LrcnError("global batch %d is not divisible by world size %d" % (B_global, world))
     b = B_global // world
     return slice(rank * b, (rank + 1) * b)
+
+
+# lossgradient finalises the gradients in this order of groups of (adjacent) parameters -- include/lrcn.h, LRCN_GRAD_GROUPS
+GRAD_GROUPS = [(7, 8), (2, 3), (4, 5), (0, 1), (6,)]
 
 
 def flat_model_like(shapes, device="cuda"):
@@ -47,7 +54,6 @@ class HipOps:
 
     def side_stream(self):
         """A second HIP stream for the VGG forward (None = run everything in order on the caller's stream)."""
-        import os
         if os.environ.get("LRCN_OVERLAP_VGG", "1")[:1] == "0":
             return None
         return torch.cuda.Stream(device=self.ctx.device)
@@ -61,6 +67,10 @@ class HipOps:
 
     def last_loss(self):
         return L.last_loss(self.ctx)
+
+    def grad_group_wait(self, group, stream):
+        """`stream` waits until the gradients of GRAD_GROUPS[group] of the last lossgradient are final."""
+        self.ctx._call("lrcn_grad_group_wait", group, C.c_void_p(stream.cuda_stream))
 
 
 class DataParallelTrainer:
@@ -79,11 +89,36 @@ class DataParallelTrainer:
         self._side = self.ops.side_stream() if hasattr(self.ops, "side_stream") else None
         self._vgg_done = None    # event: the side stream finished the VGG forward whose output is _feats_next
         self._feats_buf = [None, None]  # ping-pong outputs of the side-stream VGG
+        self._bucket_streams = None
+
+    def _group_slices(self):
+        """Flat-buffer ranges of the gradient groups, in the order lossgradient finalises them."""
+        sizes = [g.numel() for g in self.grads]
+        offs = np.concatenate([[0], np.cumsum(sizes)])
+        return [(int(offs[min(grp)]), int(offs[max(grp) + 1])) for grp in GRAD_GROUPS]
 
     def _allreduce_async(self):
+        """-> list of pending works.  LRCN_DP_BUCKETS=0: one all-reduce of the whole flat buffer after lossgradient.
+        Default: one all-reduce per gradient group, each started as soon as ITS gradients are final (an event recorded by
+        the library in the middle of the backward pass), so most of the 159 MB move while the rest of the backward runs."""
         if self.world == 1:
-            return None
-        return dist.all_reduce(self.flat_grads, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            return []
+        if os.environ.get("LRCN_DP_BUCKETS", "1")[:1] == "0":
+            return [dist.all_reduce(self.flat_grads, op=dist.ReduceOp.SUM, group=self.group, async_op=True)]
+        works = []
+        gpu = self.flat_grads.is_cuda and hasattr(self.ops, "grad_group_wait")
+        if gpu and self._bucket_streams is None:
+            self._bucket_streams = [torch.cuda.Stream(device=self.flat_grads.device) for _ in GRAD_GROUPS]
+        for k, (a, b) in enumerate(self._group_slices()):
+            chunk = self.flat_grads[a:b]
+            if gpu:
+                s = self._bucket_streams[k]
+                self.ops.grad_group_wait(k, s)  # s waits for the group's event; RCCL's stream then waits for s
+                with torch.cuda.stream(s):
+                    works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            else:
+                works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        return works
 
     def vgg(self, img_u8):
         return self.ops.vgg(img_u8)
@@ -123,11 +158,11 @@ class DataParallelTrainer:
         # rank-dependent dropout stream: masks differ per shard like rows of one big batch would
         self.ops.lossgradient(self.param, feats, tokens, self.B_global, self.pdrop,
                               (self.seed + self.step_no) * 65536 + self.rank, self.grads)
-        work = self._allreduce_async()
+        works = self._allreduce_async()
         if next_img_u8 is not None and self._side is None:
             self._feats_next = self.vgg(next_img_u8)  # in-order variant: overlaps the all-reduce only (frozen VGG)
-        if work is not None:
-            work.wait()  # compute stream waits for RCCL
+        for w in works:
+            w.wait()  # the compute stream waits for RCCL
         self.ops.update(self.param, self.grads, self.optim)
 
     def loss_value(self):

@@ -43,3 +43,61 @@ def test_side_stream_vgg_overlap_keeps_the_trajectory(monkeypatch):
     np.testing.assert_allclose(la, lb, rtol=1e-5)
     for a, b in zip(pa, pb):
         np.testing.assert_allclose(a, b, rtol=0, atol=2e-4)
+
+
+def test_gradient_group_events_and_bucketed_allreduce_path(monkeypatch):
+    """The N > 1 code path on ONE GPU: a 1-rank RCCL process group makes all-reduce(SUM) the identity, so a trainer that
+    believes world = 2 (bucketed all-reduces on their own streams, each waiting for its gradient-group event recorded in the
+    middle of the backward pass) must reproduce the world = 1 trajectory; and a stream that waits on group 0's event sees
+    the final Wout gradient while the rest of the backward may still be running."""
+    import os
+    import socket
+    import torch.distributed as dist
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        E = H = 64
+        V, B, T = 300, 4, 5
+
+        def run(world, buckets):
+            monkeypatch.setenv("LRCN_DP_BUCKETS", buckets)
+            ctx = L.Context(E, H, H, V, max_B=B, max_T=T, lstm_dtype=lrcn_amd.LRCN_BF16)
+            param = L.initweights(ctx, seed=42)
+            tr = dp.DataParallelTrainer(ctx, param, L.initparams(param), B, world, 0, pdrop=0.4, seed=7, group=dist.group.WORLD)
+            rng = np.random.default_rng(3)
+            losses = []
+            for k in range(3):
+                feats = L.to_jl((rng.standard_normal((B, 4096)) * 0.01).astype(np.float32))
+                toks = torch.as_tensor(rng.integers(3, V, size=(T, B)).astype(np.int32)).cuda()
+                tr.step(None, toks, feats=feats)
+                losses.append(L.last_loss(ctx))
+            torch.cuda.synchronize()
+            out = [L.from_jl(p).copy() for p in param]
+            # event semantics: after one more lossgradient, a side stream gated on group 0 copies Wout's gradient
+            feats = L.to_jl((rng.standard_normal((B, 4096)) * 0.01).astype(np.float32))
+            toks = torch.as_tensor(rng.integers(3, V, size=(T, B)).astype(np.int32)).cuda()
+            grads, _ = L.lossgradient(ctx, param, feats, toks, want_loss=False) if False else L.lossgradient(ctx, param, feats, toks)
+            side = torch.cuda.Stream()
+            tr.ops.grad_group_wait(0, side)
+            with torch.cuda.stream(side):
+                early = grads[7].clone()
+            torch.cuda.synchronize()
+            assert torch.equal(early, grads[7])
+            ctx.close()
+            return losses, out
+
+        l1, p1 = run(1, "1")
+        l2, p2 = run(2, "1")   # bucketed, event-gated
+        l3, p3 = run(2, "0")   # single all-reduce
+        np.testing.assert_allclose(l1, l2, rtol=1e-5)
+        np.testing.assert_allclose(l1, l3, rtol=1e-5)
+        for a, b, c in zip(p1, p2, p3):
+            np.testing.assert_allclose(a, b, rtol=0, atol=2e-4)
+            np.testing.assert_allclose(a, c, rtol=0, atol=2e-4)
+    finally:
+        dist.destroy_process_group()
