@@ -31,6 +31,14 @@ void k_lstm_bwd(hipStream_t st, int dtype, const void *acts, int64_t ld_a, const
                 const float *dh_a, int64_t ld_dha, const float *dh_b, float *dc, int B, int H, void *dz,
                 int64_t ld_dz);
 
+// Small-batch fused recurrent steps (lstm_fused.hip; bf16, B <= 64): one launch = the recurrent GEMM of a timestep + the cell
+// update (forward) / the dh GEMM of step s + the cell backward of step s-1.
+bool lstm_fused_eligible(int dtype, int B, int H, int64_t ldh, int64_t ld4);
+hipError_t launch_lstm_rec_fwd(hipStream_t st, const void *h_prev, int64_t ldh, const void *Wh, const float *Gx, const float *c_prev, int B,
+                               int H, void *acts, int64_t ld_a, float *c_new, void *h_new, const void *zero_page);
+hipError_t launch_lstm_rec_bwd(hipStream_t st, const void *dz_s, int64_t ld4, const void *WhT, const void *acts, const float *c_prev,
+                               const float *c_new, const float *dh_ext, float *dc, int B, int H, void *dz_out, const void *zero_page);
+
 // X2[m][j<h] *= mask ; X2[m][h+j] = xcnn[b][j] * mask      (lrcn.jl:546-547)
 void k_concat_x2(hipStream_t st, int dtype, void *x2, int64_t ld_x2, const float *xcnn, int64_t ld_xc, int S, int B,
                  int h, DropSpec d);

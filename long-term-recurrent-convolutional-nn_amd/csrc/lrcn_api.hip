@@ -209,11 +209,23 @@ int prepare_weights(lrcn_ctx *c, const float *const p[9], bool need_bwd) {
 
 // One LSTM layer over all S steps.  Gx f32 [M][4H] holds the input-side pre-activations (+bias) on entry and the full
 // pre-activations on exit; acts/Call/Hall receive the per-step results.  (lrcn.jl:528-538, time-batched)
+bool lstm_fused_on(lrcn_ctx *c, int B, int H, int64_t ldH, int64_t ld4H) {
+    const char *k = getenv("LRCN_LSTM_FUSED");  // LRCN_LSTM_FUSED=0: GEMM + cell as separate launches at every batch size
+    return !(k && k[0] == '0') && lstm_fused_eligible(c->dt, B, H, ldH, ld4H);
+}
 int lstm_layer_fwd(lrcn_ctx *c, int S, int B, int H, int64_t ldH, int64_t ld4H, float *Gx, const void *Wh, void *acts,
                    float *Call, void *Hall) {
     const int dt = c->dt;
+    const bool fused = lstm_fused_on(c, B, H, ldH, ld4H);
     for (int s = 0; s < S; ++s) {
         float *G = Gx + (int64_t)s * B * 4 * H;
+        if (s > 0 && fused) {  // recurrent GEMM + cell in one launch (small batches: launch-latency bound otherwise)
+            hipError_t e = launch_lstm_rec_fwd(c->stream, boff(Hall, (int64_t)(s - 1) * B * ldH, c->esz), ldH, Wh, G,
+                                               Call + (int64_t)(s - 1) * B * H, B, H, boff(acts, (int64_t)s * B * ld4H, c->esz), ld4H,
+                                               Call + (int64_t)s * B * H, boff(Hall, (int64_t)s * B * ldH, c->esz), c->zero_page);
+            if (e != hipSuccess) FAIL(c, LRCN_EHIP, "lstm_rec_fwd: %s", hipGetErrorString(e));
+            continue;
+        }
         if (s > 0)
             GEMM(c, dt, boff(Hall, (int64_t)(s - 1) * B * ldH, c->esz), ldH, Wh, ldH, G, 4 * H, B, 4 * H, H, nullptr, true,
                  true);
@@ -230,6 +242,21 @@ int lstm_layer_bwd(lrcn_ctx *c, int S, int B, int H, int64_t ld4H, const void *a
                    const void *WhT, void *dZ) {
     const int dt = c->dt;
     HIPCHK(c, hipMemsetAsync(c->dc, 0, sizeof(float) * (size_t)B * H, c->stream));
+    if (lstm_fused_on(c, B, H, round_up64(H, 64), ld4H)) {
+        // cell backward of the last step, then one launch per step: dh_rec = dZ[s] Wh fused with the cell backward of s-1
+        k_lstm_bwd(c->stream, dt, boff(acts, (int64_t)(S - 1) * B * ld4H, c->esz), ld4H, S > 1 ? Call + (int64_t)(S - 2) * B * H : nullptr,
+                   Call + (int64_t)(S - 1) * B * H, dHall + (int64_t)(S - 1) * B * H, H, nullptr, c->dc, B, H,
+                   boff(dZ, (int64_t)(S - 1) * B * ld4H, c->esz), ld4H);
+        for (int s = S - 1; s >= 1; --s) {
+            hipError_t e = launch_lstm_rec_bwd(c->stream, boff(dZ, (int64_t)s * B * ld4H, c->esz), ld4H, WhT,
+                                               boff(acts, (int64_t)(s - 1) * B * ld4H, c->esz), s > 1 ? Call + (int64_t)(s - 2) * B * H : nullptr,
+                                               Call + (int64_t)(s - 1) * B * H, dHall + (int64_t)(s - 1) * B * H, c->dc, B, H,
+                                               boff(dZ, (int64_t)(s - 1) * B * ld4H, c->esz), c->zero_page);
+            if (e != hipSuccess) FAIL(c, LRCN_EHIP, "lstm_rec_bwd: %s", hipGetErrorString(e));
+        }
+        KCHK(c, "lstm_layer_bwd (fused)");
+        return LRCN_OK;
+    }
     for (int s = S - 1; s >= 0; --s) {
         k_lstm_bwd(c->stream, dt, boff(acts, (int64_t)s * B * ld4H, c->esz), ld4H, s ? Call + (int64_t)(s - 1) * B * H : nullptr,
                    Call + (int64_t)s * B * H, dHall + (int64_t)s * B * H, H, (s < S - 1) ? c->dhrec : nullptr, c->dc, B, H,

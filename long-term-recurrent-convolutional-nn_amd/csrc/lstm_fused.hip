@@ -1,0 +1,284 @@
+// lstm_fused.hip -- one launch per recurrent timestep for small batches (B <= 64 rows, bf16, gfx950):
+//   forward : G[s] = Gx[s] + h[s-1] Wh'  fused with the cell update of step s           (lrcn.jl:529-536)
+//   backward: dh_rec = dZ[s] Wh          fused with the cell backward of step s-1       (AutoGrad dual)
+// At 32..64 rows per GPU (what 4..8-way data parallelism leaves of a 256 batch) the LSTM step is a chain of ~130 tiny
+// launches per layer pass (GEMM + split-K combine + memset + cell kernel per timestep) whose cost is launch latency, not
+// work.  Here a workgroup owns 16 hidden units for all rows: the four gate pre-activations of a unit (forward) or the
+// four K-slices of the dh contraction (backward) are computed by the four WAVES of the workgroup, each an independent
+// [M x 16] MFMA GEMM with its own LDS-DMA ring (no barrier in the K loop -- a wave only reads what it staged itself), and
+// meet in LDS for the elementwise cell math.  63 workgroups for H = 1000.
+#include <type_traits>
+
+#include "common.h"
+#include "gemm.h"
+#include "kernels.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+template <int I, int N, class F> __device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int OFF> __device__ __forceinline__ uint4 lds_read16(unsigned addr) {
+    uint4 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
+    return r;
+}
+__device__ __forceinline__ float sigm_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// acc[i] (rows 16 i + 4 lq + r, column l15) = A[M][K-tiles kt0..kt1) * Brows[16][same K]'   for ONE wave.
+//   A: [M][lda] bf16 (rows >= M: zero page); Brow: this lane's B row pointer for staging (NULL -> zero page); ring of NBUF slots
+//   of (MT*16 + 16) rows x 128 B at LDS byte offset `ring` (wave-private).
+template <int MT, int PF>
+__device__ __forceinline__ void wave_gemm(f32x4v (&acc)[MT], const bf16_t *A, int64_t lda, int M, const bf16_t *Bbase, int64_t ldb,
+                                          int brow0, int brows_valid, int kt0, int kt1, unsigned char *smem, unsigned ring,
+                                          const void *zero_page, int lane) {
+    constexpr int NBUF = PF + 1, ROWS = MT * 16, SLOT = (ROWS + 16) * 128, APW = MT * 2, IPT = APW + 2;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const bf16_t *Zp = reinterpret_cast<const bf16_t *>(zero_page) + (lane & 7) * 8;
+    int a_off[APW];
+    bool a_ok[APW];
+#pragma unroll
+    for (int p = 0; p < APW; ++p) {
+        const int row = p * 8 + (lane >> 3);
+        a_ok[p] = row < M;
+        a_off[p] = a_ok[p] ? row * (int)lda + (((lane & 7) ^ ((row >> 1) & 7)) << 3) : 0;
+    }
+    int b_off[2];
+    bool b_ok[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int row = p * 8 + (lane >> 3);
+        b_ok[p] = row < brows_valid;
+        b_off[p] = b_ok[p] ? (brow0 + row) * (int)ldb + (((lane & 7) ^ ((row >> 1) & 7)) << 3) : 0;
+    }
+    const int KT = kt1 - kt0;
+    auto issue = [&](int t) {
+        const bool live = t < KT;
+        const int slot = t % NBUF, ko = (kt0 + (live ? t : 0)) * 64;
+#pragma unroll
+        for (int p = 0; p < APW; ++p) {
+            const bf16_t *src = (live & a_ok[p]) ? A + (a_off[p] + ko) : Zp;
+            __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(smem + ring + slot * SLOT + p * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const bf16_t *src = (live & b_ok[p]) ? Bbase + (b_off[p] + ko) : Zp;
+            __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(smem + ring + slot * SLOT + ROWS * 128 + p * 1024), 16, 0, 0);
+        }
+    };
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem + ring;
+    unsigned fa[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) fa[s] = lds0 + l15 * 128 + (((4 * s + lq) ^ ((l15 >> 1) & 7)) << 4);
+#pragma unroll
+    for (int t = 0; t < PF; ++t) issue(t);
+    for (int t = 0; t < KT; ++t) {
+        wait_vmcnt<(PF - 1) * IPT>();  // tile t (staged by this wave alone) has landed; its slot's previous reads are long done
+        issue(t + PF);
+        const unsigned base = (unsigned)((t % NBUF) * SLOT);
+        uint4 af[MT][2], b0, b1;
+        // one asm statement: outputs exist only after the wait (no consumer can be scheduled above it)
+        if constexpr (MT == 2) {
+            asm volatile(
+                "ds_read_b128 %0, %6 offset:%8\n\tds_read_b128 %1, %7 offset:%8\n\t"
+                "ds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\tds_read_b128 %4, %6 offset:2048\n\tds_read_b128 %5, %7 offset:2048\n\t"
+                "s_waitcnt lgkmcnt(0)"
+                : "=&v"(b0), "=&v"(b1), "=&v"(af[0][0]), "=&v"(af[0][1]), "=&v"(af[1][0]), "=&v"(af[1][1])
+                : "v"(fa[0] + base), "v"(fa[1] + base), "n"(ROWS * 128)
+                : "memory");
+        } else {
+            static_assert(MT == 4, "MT is 2 or 4");
+            asm volatile(
+                "ds_read_b128 %0, %10 offset:%12\n\tds_read_b128 %1, %11 offset:%12\n\t"
+                "ds_read_b128 %2, %10\n\tds_read_b128 %3, %11\n\tds_read_b128 %4, %10 offset:2048\n\tds_read_b128 %5, %11 offset:2048\n\t"
+                "ds_read_b128 %6, %10 offset:4096\n\tds_read_b128 %7, %11 offset:4096\n\tds_read_b128 %8, %10 offset:6144\n\t"
+                "ds_read_b128 %9, %11 offset:6144\n\ts_waitcnt lgkmcnt(0)"
+                : "=&v"(b0), "=&v"(b1), "=&v"(af[0][0]), "=&v"(af[0][1]), "=&v"(af[1][0]), "=&v"(af[1][1]), "=&v"(af[2][0]), "=&v"(af[2][1]),
+                  "=&v"(af[3][0]), "=&v"(af[3][1])
+                : "v"(fa[0] + base), "v"(fa[1] + base), "n"(ROWS * 128)
+                : "memory");
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[i][0]), __builtin_bit_cast(bf16x8, b0), acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[i][1]), __builtin_bit_cast(bf16x8, b1), acc[i], 0, 0, 0);
+        }
+    }
+    wait_vmcnt<0>();  // the dead tiles of the tail
+}
+
+template <int MT> struct FusedGeom {
+    static constexpr int PF = MT == 2 ? 4 : 2;
+    static constexpr int WAVE_LDS = (PF + 1) * (MT * 16 + 16) * 128;
+    static constexpr int XCH = 4 * MT * 16 * 17 * 4;  // exchange area: [4][M][17] f32 (placed over the rings after the K loops)
+    static constexpr int LDS = 4 * WAVE_LDS > XCH ? 4 * WAVE_LDS : XCH;
+};
+
+struct RecFwdArgs {
+    const bf16_t *h_prev;  // [B][ldh]
+    const bf16_t *Wh;      // [4H][ldh]   rows g*H + u
+    const float *Gx;       // [B][4H]     input-side pre-activations (+ bias) of this step
+    const float *c_prev;   // [B][H]
+    bf16_t *acts;          // [B][ld_a]   activated gates [f | i | o | g]
+    float *c_new;          // [B][H]
+    bf16_t *h_new;         // [B][ldh]
+    const void *zero_page;
+    int64_t ldh, ld_a;
+    int B, H;
+};
+
+template <int MT> __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(const RecFwdArgs a) {
+    typedef FusedGeom<MT> G;
+    extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // = gate
+    const int u0 = blockIdx.x * 16, H = a.H, M = a.B;
+    const int valid = H - u0 < 16 ? H - u0 : 16;
+    f32x4v acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    wave_gemm<MT, G::PF>(acc, a.h_prev, a.ldh, M, a.Wh, a.ldh, wave * H + u0, valid, 0, (int)(a.ldh / 64), smem, wave * G::WAVE_LDS,
+                         a.zero_page, lane);
+    __syncthreads();  // every wave is done with its ring: the exchange area may overwrite it
+    float *xch = reinterpret_cast<float *>(smem);
+    const int l15 = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xch[(wave * MT * 16 + i * 16 + 4 * lq + r) * 17 + l15] = acc[i][r];
+    __syncthreads();
+    for (int e = tid; e < M * 16; e += 256) {
+        const int m = e >> 4, u = e & 15, j = u0 + u;
+        if (j >= H) continue;
+        const float *gx = a.Gx + (int64_t)m * 4 * H;
+        const float f = sigm_f(xch[(0 * MT * 16 + m) * 17 + u] + gx[j]);
+        const float i = sigm_f(xch[(1 * MT * 16 + m) * 17 + u] + gx[H + j]);
+        const float o = sigm_f(xch[(2 * MT * 16 + m) * 17 + u] + gx[2 * H + j]);
+        const float ch = tanhf(xch[(3 * MT * 16 + m) * 17 + u] + gx[3 * H + j]);
+        const float c = a.c_prev[(int64_t)m * H + j] * f + i * ch;
+        const float h = o * tanhf(c);
+        bf16_t *ac = a.acts + (int64_t)m * a.ld_a;
+        ac[j] = (bf16_t)f;
+        ac[H + j] = (bf16_t)i;
+        ac[2 * H + j] = (bf16_t)o;
+        ac[3 * H + j] = (bf16_t)ch;
+        a.c_new[(int64_t)m * H + j] = c;
+        a.h_new[(int64_t)m * a.ldh + j] = (bf16_t)h;
+    }
+}
+
+struct RecBwdArgs {
+    const bf16_t *dz_s;    // [B][ld4]   dZ of step s
+    const bf16_t *WhT;     // [H][ld4]   row u = column u of Wh'
+    // cell backward of step s-1:
+    const bf16_t *acts;    // [B][ld4]
+    const float *c_prev;   // [B][H] or NULL (step s-1 = 0)
+    const float *c_new;    // [B][H]
+    const float *dh_ext;   // [B][H]
+    float *dc;             // [B][H] in/out
+    bf16_t *dz_out;        // [B][ld4]   dZ of step s-1
+    const void *zero_page;
+    int64_t ld4;
+    int B, H;
+};
+
+template <int MT> __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(const RecBwdArgs a) {
+    typedef FusedGeom<MT> G;
+    extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // = K slice
+    const int u0 = blockIdx.x * 16, H = a.H, M = a.B;
+    const int valid = H - u0 < 16 ? H - u0 : 16;
+    const int KT = (int)(a.ld4 / 64), per = (KT + 3) / 4;
+    const int kt0 = wave * per < KT ? wave * per : KT, kt1 = (wave + 1) * per < KT ? (wave + 1) * per : KT;
+    f32x4v acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    wave_gemm<MT, G::PF>(acc, a.dz_s, a.ld4, M, a.WhT, a.ld4, u0, valid, kt0, kt1, smem, wave * G::WAVE_LDS, a.zero_page, lane);
+    __syncthreads();
+    float *xch = reinterpret_cast<float *>(smem);
+    const int l15 = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xch[(wave * MT * 16 + i * 16 + 4 * lq + r) * 17 + l15] = acc[i][r];
+    __syncthreads();
+    for (int e = tid; e < M * 16; e += 256) {
+        const int m = e >> 4, u = e & 15, j = u0 + u;
+        if (j >= H) continue;
+        const float dh = a.dh_ext[(int64_t)m * H + j] + xch[(0 * MT * 16 + m) * 17 + u] + xch[(1 * MT * 16 + m) * 17 + u] +
+                         xch[(2 * MT * 16 + m) * 17 + u] + xch[(3 * MT * 16 + m) * 17 + u];
+        const bf16_t *ac = a.acts + (int64_t)m * a.ld4;
+        const float f = (float)ac[j], i = (float)ac[H + j], o = (float)ac[2 * H + j], g = (float)ac[3 * H + j];
+        const float tc = tanhf(a.c_new[(int64_t)m * H + j]);
+        const float dov = dh * tc;
+        const float dcv = a.dc[(int64_t)m * H + j] + dh * o * (1.0f - tc * tc);
+        const float cp = a.c_prev ? a.c_prev[(int64_t)m * H + j] : 0.0f;
+        bf16_t *z = a.dz_out + (int64_t)m * a.ld4;
+        z[j] = (bf16_t)(dcv * cp * f * (1.0f - f));
+        z[H + j] = (bf16_t)(dcv * g * i * (1.0f - i));
+        z[2 * H + j] = (bf16_t)(dov * o * (1.0f - o));
+        z[3 * H + j] = (bf16_t)(dcv * i * (1.0f - g * g));
+        a.dc[(int64_t)m * H + j] = dcv * f;
+    }
+}
+
+template <class K> hipError_t set_lds(K kern, int lds, bool &done) {
+    if (done) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess) done = true;
+    return e;
+}
+
+}  // namespace
+
+bool lstm_fused_eligible(int dtype, int B, int H, int64_t ldh, int64_t ld4) {
+    return dtype == GEMM_T_BF16 && B >= 1 && B <= 64 && H >= 16 && (ldh % 64) == 0 && (ld4 % 64) == 0 &&
+           (int64_t)B * ld4 < (1ll << 31) && (int64_t)4 * H * ldh < (1ll << 31);
+}
+
+hipError_t launch_lstm_rec_fwd(hipStream_t st, const void *h_prev, int64_t ldh, const void *Wh, const float *Gx, const float *c_prev, int B,
+                               int H, void *acts, int64_t ld_a, float *c_new, void *h_new, const void *zero_page) {
+    RecFwdArgs a{};
+    a.h_prev = (const bf16_t *)h_prev; a.Wh = (const bf16_t *)Wh; a.Gx = Gx; a.c_prev = c_prev;
+    a.acts = (bf16_t *)acts; a.c_new = c_new; a.h_new = (bf16_t *)h_new; a.zero_page = zero_page;
+    a.ldh = ldh; a.ld_a = ld_a; a.B = B; a.H = H;
+    const dim3 grid((H + 15) / 16);
+    static bool d2 = false, d4 = false;
+    hipError_t e;
+    if (B <= 32) {
+        if ((e = set_lds(lstm_rec_fwd_kernel<2>, FusedGeom<2>::LDS, d2)) != hipSuccess) return e;
+        hipLaunchKernelGGL(lstm_rec_fwd_kernel<2>, grid, dim3(256), FusedGeom<2>::LDS, st, a);
+    } else {
+        if ((e = set_lds(lstm_rec_fwd_kernel<4>, FusedGeom<4>::LDS, d4)) != hipSuccess) return e;
+        hipLaunchKernelGGL(lstm_rec_fwd_kernel<4>, grid, dim3(256), FusedGeom<4>::LDS, st, a);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_lstm_rec_bwd(hipStream_t st, const void *dz_s, int64_t ld4, const void *WhT, const void *acts, const float *c_prev,
+                               const float *c_new, const float *dh_ext, float *dc, int B, int H, void *dz_out, const void *zero_page) {
+    RecBwdArgs a{};
+    a.dz_s = (const bf16_t *)dz_s; a.WhT = (const bf16_t *)WhT; a.acts = (const bf16_t *)acts; a.c_prev = c_prev; a.c_new = c_new;
+    a.dh_ext = dh_ext; a.dc = dc; a.dz_out = (bf16_t *)dz_out; a.zero_page = zero_page;
+    a.ld4 = ld4; a.B = B; a.H = H;
+    const dim3 grid((H + 15) / 16);
+    static bool d2 = false, d4 = false;
+    hipError_t e;
+    if (B <= 32) {
+        if ((e = set_lds(lstm_rec_bwd_kernel<2>, FusedGeom<2>::LDS, d2)) != hipSuccess) return e;
+        hipLaunchKernelGGL(lstm_rec_bwd_kernel<2>, grid, dim3(256), FusedGeom<2>::LDS, st, a);
+    } else {
+        if ((e = set_lds(lstm_rec_bwd_kernel<4>, FusedGeom<4>::LDS, d4)) != hipSuccess) return e;
+        hipLaunchKernelGGL(lstm_rec_bwd_kernel<4>, grid, dim3(256), FusedGeom<4>::LDS, st, a);
+    }
+    return hipGetLastError();
+}

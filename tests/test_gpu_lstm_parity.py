@@ -140,8 +140,9 @@ def test_config1_shape_vs_oracle_fp32_and_bf16():
         assert cos > 0.99, (n, cos)
 
 
-@pytest.mark.parametrize("B,T", [(24, 5), (64, 3), (128, 2), (160, 2)])
+@pytest.mark.parametrize("B,T", [(24, 5), (7, 4), (64, 3), (128, 2), (160, 2)])
 def test_bf16_recurrent_gemms_on_skinny_kernel(B, T, monkeypatch):
+    # lstm_fused.hip (B <= 64: fused recurrent step kernels, 20 workgroups of 16 units, H = 320) and
     # gemm_skinny.hip (M = B rows: m-tile counts 2 / 4 / 8 / 16, M tails, N = 4H = 1280 and the N = h = 160 tail tile,
     # accumulate-into-G epilogue, split-K slabs for the K = 4096 image embedding) against the oracle and against the same
     # step with the kernel disabled.
@@ -156,6 +157,7 @@ def test_bf16_recurrent_gemms_on_skinny_kernel(B, T, monkeypatch):
     res = {}
     for knob in ("1", "0"):
         monkeypatch.setenv("LRCN_SKINNY", knob)
+        monkeypatch.setenv("LRCN_LSTM_FUSED", knob)  # B <= 64: lstm_fused.hip (recurrent GEMM + cell in one launch) on / off
         ctx = L.Context(E, H1, H2, V, max_B=B, max_T=T, lstm_dtype=lrcn_amd.LRCN_BF16)
         grads, val = L.lossgradient(ctx, param, L.to_jl(feats), tokens)
         res[knob] = (val, [L.from_jl(g).astype(np.float64) for g in grads])
