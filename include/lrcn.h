@@ -137,6 +137,13 @@ int lrcn_train_step(lrcn_ctx *ctx, float *const params[9], float *const grads[9]
  * *out_prob its probability (linear float32 product, no length normalisation). */
 int lrcn_beam_search(lrcn_ctx *ctx, const float *const params[9], const float *feat, int K, int nword,
                      int32_t *out_tokens, int *out_len, float *out_prob);
+/* The same decode for N images at once (new: the reference decodes image by image): feats N x 4096 column-major, N*K <= max_B.
+ * The N*K hypotheses are the rows of one batched lrcn() step; softmax, top-K, candidate ordering (stable, descending), history
+ * update and the stop test run on the device.  Host outputs: out_tokens [N][nword + 2] (bos first), out_len [N], out_prob [N]
+ * (may be NULL).  Per image identical to lrcn_beam_search. */
+#define LRCN_BEAM_MAXLEN 258
+int lrcn_beam_search_batch(lrcn_ctx *ctx, const float *const params[9], const float *feats, int N, int K, int nword,
+                           int32_t *out_tokens, int *out_len, float *out_prob);
 
 /* ---- VGG-16 to fc7 (lrcn.jl:697-748) ---- */
 /* get_params_cnn (lrcn.jl:697-721): conv_w[l] (3,3,Cin,Cout), conv_b[l] Cout, fc6_w 4096 x 25088, fc7_w 4096 x 4096

@@ -66,6 +66,8 @@ SIGNATURES = {
                                   C.POINTER(C.c_double)]),
     "lrcn_beam_search": (C.c_int, [C.c_void_p, P9, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32),
                                    C.POINTER(C.c_int), C.POINTER(C.c_float)]),
+    "lrcn_beam_search_batch": (C.c_int, [C.c_void_p, P9, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32),
+                                         C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     "lrcn_vgg_load": (C.c_int, [C.c_void_p, P13, P13, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lrcn_vgg_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "lrcn_preprocess_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_void_p]),

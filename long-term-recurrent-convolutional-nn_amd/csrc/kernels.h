@@ -125,6 +125,12 @@ void k_nhwc_to_ref(hipStream_t st, int dtype, const void *in, int W, int H, int 
 // ---- beam search (lrcn.jl:644-678) ----
 // For each of R rows of prob [R][ld]: the K largest entries in descending order, ties to the lower index.
 void k_topk_rows(hipStream_t st, const float *prob, int64_t ld, int R, int V, int K, int32_t *idx, float *val);
+// One decode step of beam bookkeeping for N images (one workgroup each): see beam_update_kernel.  K <= 32.
+void k_beam_update(hipStream_t st, const int32_t *topi, const float *topv, const int32_t *seq_in, int32_t *seq_out, float *p,
+                   int32_t *parent, int32_t *last, int32_t *done, int32_t *ndone, int32_t *res_tok, int32_t *res_len, float *res_p, int N,
+                   int K, int L, int current, int nword, int eos);
+// out[r][0..C) = in[r / K][0..C): every image row repeated K times (rows ld apart in both)
+void k_repeat_rows(hipStream_t st, int dtype, const void *in, int64_t ld, int N, int K, int C, void *out);
 // out[r][0..C) = in[src_row[r]][0..C)  (beam search parent-state gather, lrcn.jl:673-676); in != out.
 void k_gather_rows_f32(hipStream_t st, const float *in, int64_t ld, const int32_t *src_row, int R, int C, float *out);
 // out[i] = a[i] * b[i]

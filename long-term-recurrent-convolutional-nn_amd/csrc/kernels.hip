@@ -481,6 +481,76 @@ template <typename T> __global__ void nhwc_to_ref_kernel(const T *in, int W, int
     }
 }
 
+// Beam bookkeeping of ONE decode step for N images at once (lrcn.jl:657-677 per image), one workgroup per image:
+//   candidates (i, j) = hypothesis i of the image x its j-th best next word, probability topv * p[i] (linear float32 space);
+//   step 1 expands hypothesis 1 only (:662-664); stable descending order (ties: lower candidate index); keep K; stop when
+//   the best ends in eos or current > nword (:670) -> the image is frozen and its result recorded.
+// seq_in/seq_out: [N*K][L] token histories (ping-pong), p: [N*K] in/out, parent[N*K]: state row to copy, last[N*K]: token fed next.
+__global__ __launch_bounds__(256) void beam_update_kernel(const int32_t *topi, const float *topv, const int32_t *seq_in, int32_t *seq_out,
+                                                          float *p, int32_t *parent, int32_t *last, int32_t *done, int32_t *ndone,
+                                                          int32_t *res_tok, int32_t *res_len, float *res_p, int K, int L, int current,
+                                                          int nword, int eos) {
+    __shared__ float cp[1024];
+    __shared__ float newp[32];
+    __shared__ int sel[32];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int r0 = n * K;
+    if (done[n]) {  // frozen: identity parent, histories carried over
+        for (int k = tid; k < K; k += blockDim.x) {
+            parent[r0 + k] = r0 + k;
+            last[r0 + k] = eos;
+        }
+        for (int e = tid; e < K * L; e += blockDim.x) seq_out[(int64_t)r0 * L + e] = seq_in[(int64_t)r0 * L + e];
+        return;
+    }
+    const int nexp = current == 1 ? 1 : K, C = nexp * K;
+    for (int c = tid; c < C; c += blockDim.x) cp[c] = topv[(int64_t)(r0 + c / K) * K + c % K] * p[r0 + c / K];
+    __syncthreads();
+    for (int c = tid; c < C; c += blockDim.x) {
+        const float v = cp[c];
+        int rank = 0;
+        for (int q = 0; q < C; ++q) rank += (cp[q] > v) || (cp[q] == v && q < c);
+        if (rank < K) {
+            sel[rank] = c;
+            newp[rank] = v;
+        }
+    }
+    __syncthreads();
+    // K <= C always (C >= K): every rank 0..K-1 is filled.  New histories = parent's history + the chosen word.
+    for (int e = tid; e < K * L; e += blockDim.x) {
+        const int k = e / L, pos = e - k * L;
+        const int c = sel[k], i = c / K;
+        int32_t t = seq_in[(int64_t)(r0 + i) * L + pos];
+        if (pos == current) t = topi[(int64_t)(r0 + i) * K + c % K];
+        seq_out[(int64_t)(r0 + k) * L + pos] = t;
+    }
+    __syncthreads();
+    for (int k = tid; k < K; k += blockDim.x) {
+        const int c = sel[k];
+        p[r0 + k] = newp[k];
+        parent[r0 + k] = r0 + c / K;
+        last[r0 + k] = topi[(int64_t)(r0 + c / K) * K + c % K];
+    }
+    if (tid == 0) {
+        const int c = sel[0];
+        const int best_tok = topi[(int64_t)(r0 + c / K) * K + c % K];
+        if (best_tok == eos || current > nword) {
+            done[n] = 1;
+            atomicAdd(ndone, 1);
+            res_len[n] = current + 1;
+            res_p[n] = newp[0];
+        }
+    }
+    __syncthreads();
+    if (done[n])
+        for (int pos = tid; pos <= current; pos += blockDim.x) res_tok[(int64_t)n * L + pos] = seq_out[(int64_t)r0 * L + pos];
+}
+// out[r][0..C) = in[r / K][0..C)  (replicate each image row K times)
+template <typename T> __global__ void repeat_rows_kernel(const T *in, int64_t ld, int R, int K, int C, T *out) {
+    const int r = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) out[(int64_t)r * ld + c] = in[(int64_t)(r / K) * ld + c];
+}
+
 // Top-K of each row, descending, ties to the lower index (Julia's stable sortperm(rev=true), lrcn.jl:655).
 // One 256-thread block per row; K rounds of block-wide argmax with the winners masked out. K <= 32.
 __global__ __launch_bounds__(256) void topk_rows_kernel(const float *prob, int64_t ld, int R, int V, int K, int32_t *idx,
@@ -688,6 +758,15 @@ void k_nhwc_to_ref(hipStream_t st, int dtype, const void *in, int W, int H, int 
 }
 void k_topk_rows(hipStream_t st, const float *prob, int64_t ld, int R, int V, int K, int32_t *idx, float *val) {
     hipLaunchKernelGGL(topk_rows_kernel, dim3(R), dim3(256), 0, st, prob, ld, R, V, K, idx, val);
+}
+void k_beam_update(hipStream_t st, const int32_t *topi, const float *topv, const int32_t *seq_in, int32_t *seq_out, float *p,
+                   int32_t *parent, int32_t *last, int32_t *done, int32_t *ndone, int32_t *res_tok, int32_t *res_len, float *res_p, int N,
+                   int K, int L, int current, int nword, int eos) {
+    hipLaunchKernelGGL(beam_update_kernel, dim3(N), dim3(256), 0, st, topi, topv, seq_in, seq_out, p, parent, last, done, ndone, res_tok,
+                       res_len, res_p, K, L, current, nword, eos);
+}
+void k_repeat_rows(hipStream_t st, int dtype, const void *in, int64_t ld, int N, int K, int C, void *out) {
+    DISPATCH_T(dtype, hipLaunchKernelGGL(repeat_rows_kernel<T>, dim3(N * K), dim3(256), 0, st, (const T *)in, ld, N * K, K, C, (T *)out));
 }
 void k_gather_rows_f32(hipStream_t st, const float *in, int64_t ld, const int32_t *src_row, int R, int C, float *out) {
     hipLaunchKernelGGL(gather_rows_f32_kernel, dim3(R), dim3(256), 0, st, in, ld, src_row, R, C, out);

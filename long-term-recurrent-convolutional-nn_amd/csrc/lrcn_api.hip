@@ -71,6 +71,10 @@ struct lrcn_ctx {
     void *st_h1 = nullptr, *st_h2 = nullptr, *st_x = nullptr, *st_x2 = nullptr, *st_a = nullptr;
     float *st_g = nullptr, *st_logits = nullptr, *st_prob = nullptr, *st_io = nullptr, *st_topv = nullptr;
     int32_t *st_topi = nullptr, *st_parent = nullptr;
+    // batched beam search (lrcn_beam_search_batch): token histories (ping-pong), bookkeeping, results -- all on the device
+    int32_t *bs_seq[2] = {nullptr, nullptr}, *bs_last = nullptr, *bs_done = nullptr, *bs_ndone = nullptr, *bs_res_tok = nullptr,
+            *bs_res_len = nullptr;
+    float *bs_p = nullptr, *bs_res_p = nullptr;
     // VGG
     bool vgg_loaded = false;
     VggLayer conv[13];
@@ -537,6 +541,11 @@ int lrcn_create(const lrcn_config *cfg, lrcn_ctx **out) {
         DALLOC(c, c->st_io, sizeof(float) * io);
         DALLOC(c, c->st_topi, sizeof(int32_t) * B * 32); DALLOC(c, c->st_topv, sizeof(float) * B * 32);
         DALLOC(c, c->st_parent, sizeof(int32_t) * B);
+        for (int i = 0; i < 2; ++i) DALLOC(c, c->bs_seq[i], sizeof(int32_t) * B * LRCN_BEAM_MAXLEN);
+        DALLOC(c, c->bs_last, sizeof(int32_t) * B);      DALLOC(c, c->bs_done, sizeof(int32_t) * B);
+        DALLOC(c, c->bs_ndone, sizeof(int32_t) * 4);     DALLOC(c, c->bs_res_tok, sizeof(int32_t) * B * LRCN_BEAM_MAXLEN);
+        DALLOC(c, c->bs_res_len, sizeof(int32_t) * B);   DALLOC(c, c->bs_p, sizeof(float) * B);
+        DALLOC(c, c->bs_res_p, sizeof(float) * B);
         if (cfg->max_images > 0) {
             const int64_t N = cfg->max_images;
             const size_t ve = c->vesz;
@@ -787,6 +796,77 @@ int lrcn_beam_search(lrcn_ctx *c, const float *const p[9], const float *feat, in
     memcpy(out_tokens, x[0].seq.data(), sizeof(int32_t) * n);
     *out_len = n;
     if (out_prob) *out_prob = x[0].p;
+    return LRCN_OK;
+}
+
+// generate/beam_search for N images at once (lrcn.jl:585-678 per image; the reference decodes one image at a time with K
+// sequential batch-1 lrcn() calls and a device->host copy of V floats per hypothesis per step).  Here the N*K hypotheses of all
+// images are the rows of ONE batched lrcn() step; softmax, top-K, candidate ordering, history update and the stop test
+// run on the device (beam_update_kernel); the host only polls a done-counter every few steps.  Per image the result is what
+// lrcn_beam_search returns (tests/test_gpu_lstm_parity.py).  feats: N x 4096 column-major; out_tokens: [N][nword + 2]
+// (bos first), out_len[N], out_prob[N] (may be NULL) on the HOST.
+int lrcn_beam_search_batch(lrcn_ctx *c, const float *const p[9], const float *feats, int N, int K, int nword, int32_t *out_tokens,
+                           int *out_len, float *out_prob) {
+    if (!c || !p || !feats || !out_tokens || !out_len) return LRCN_EINVAL;
+    if (K < 1 || K > 32) FAIL(c, LRCN_EINVAL, "beam width K=%d must be in [1, 32]", K);
+    if (N < 1 || (int64_t)N * K > c->maxB) FAIL(c, LRCN_EINVAL, "N*K = %d*%d exceeds max_B = %d", N, K, c->maxB);
+    if (nword < 1 || nword + 2 > LRCN_BEAM_MAXLEN) FAIL(c, LRCN_EINVAL, "nword=%d outside [1,%d]", nword, LRCN_BEAM_MAXLEN - 2);
+    const int dt = c->dt, E = c->E, H1 = c->H1, H2 = c->H2, h = c->h, V = c->V;
+    const int R = N * K, Lh = nword + 2;
+    hipStream_t st = c->stream;
+    int r = prepare_weights(c, p, false);
+    if (r) return r;
+    // input = input * param[end-3] per image (lrcn.jl:611), each row repeated for the image's K hypotheses
+    k_transpose(st, dt, 1, feats, N, LRCN_CNNOUT, N, c->F, LRCN_CNNOUT, 0);
+    GEMM(c, dt, c->F, LRCN_CNNOUT, c->Wcd, LRCN_CNNOUT, c->dxcnn, c->ldh, N, h, LRCN_CNNOUT, nullptr, true);
+    k_repeat_rows(st, GEMM_T_F32, c->dxcnn, c->ldh, N, K, h, c->xcnn);
+    const int Hs[4] = {H1, H1, H2, H2};
+    for (int i = 0; i < 4; ++i) HIPCHK(c, hipMemsetAsync(c->st_f32[i], 0, sizeof(float) * (size_t)R * Hs[i], st));
+    HIPCHK(c, hipMemsetAsync(c->bs_done, 0, sizeof(int32_t) * N, st));
+    HIPCHK(c, hipMemsetAsync(c->bs_ndone, 0, sizeof(int32_t), st));
+    {   // histories = [bos], probabilities 1, next input = bos
+        std::vector<int32_t> h0((size_t)R * Lh, 0), l0(R, LRCN_BOS);
+        std::vector<float> p0(R, 1.0f);
+        for (int q = 0; q < R; ++q) h0[(size_t)q * Lh] = LRCN_BOS;
+        HIPCHK(c, hipMemcpyAsync(c->bs_seq[0], h0.data(), sizeof(int32_t) * h0.size(), hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->bs_last, l0.data(), sizeof(int32_t) * R, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->bs_p, p0.data(), sizeof(float) * R, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipStreamSynchronize(st));  // the host vectors go out of scope
+    }
+    DropSpec none{};
+    int cur = 0;
+    for (int current = 1; current <= nword + 1; ++current) {
+        k_embed_gather(st, dt, c->WeT, c->ldE, c->bs_last, 1, R, E, none, c->st_x, c->ldE);   // lrcn.jl:650
+        r = step_internal(c, p, R, none);                                                   // :651, all N*K hypotheses batched
+        if (r) return r;
+        k_softmax_rows(st, c->st_logits, c->ldV, R, V, c->st_prob, c->ldV);                  // :652
+        k_topk_rows(st, c->st_prob, c->ldV, R, V, K, c->st_topi, c->st_topv);                // :655-656
+        k_beam_update(st, c->st_topi, c->st_topv, c->bs_seq[cur], c->bs_seq[cur ^ 1], c->bs_p, c->st_parent, c->bs_last, c->bs_done,
+                      c->bs_ndone, c->bs_res_tok, c->bs_res_len, c->bs_res_p, N, K, Lh, current, nword, LRCN_EOS);
+        cur ^= 1;
+        for (int i = 0; i < 4; ++i) {                                                       // :673-676
+            k_gather_rows_f32(st, c->st_f32[i], Hs[i], c->st_parent, R, Hs[i], c->st2_f32[i]);
+            std::swap(c->st_f32[i], c->st2_f32[i]);
+        }
+        if ((current & 3) == 0 && current <= nword) {  // every image finished early?
+            int32_t nd = 0;
+            HIPCHK(c, hipMemcpyAsync(&nd, c->bs_ndone, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipStreamSynchronize(st));
+            if (nd >= N) break;
+        }
+    }
+    KCHK(c, "beam_search_batch");
+    std::vector<int32_t> tok((size_t)N * Lh), len(N);
+    std::vector<float> pr(N);
+    HIPCHK(c, hipMemcpyAsync(tok.data(), c->bs_res_tok, sizeof(int32_t) * tok.size(), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(len.data(), c->bs_res_len, sizeof(int32_t) * N, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(pr.data(), c->bs_res_p, sizeof(float) * N, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    for (int n = 0; n < N; ++n) {
+        out_len[n] = len[n];
+        memcpy(out_tokens + (size_t)n * Lh, tok.data() + (size_t)n * Lh, sizeof(int32_t) * Lh);
+        if (out_prob) out_prob[n] = pr[n];
+    }
     return LRCN_OK;
 }
 

@@ -295,6 +295,18 @@ def beam_search(ctx, param, feat, beam_width, nword):
     return list(out[:n.value]), p.value
 
 
+def beam_search_batch(ctx, param, feats, beam_width, nword):
+    """beam_search for N images in one device-resident decode (lrcn_beam_search_batch): feats N x 4096 ->
+    [(token ids incl. bos, probability)] per image; N * beam_width <= max_B."""
+    N = feats.shape[0]
+    L = nword + 2
+    out = (C.c_int32 * (N * L))()
+    n = (C.c_int * N)()
+    p = (C.c_float * N)()
+    ctx._call("lrcn_beam_search_batch", _p9(param), _ptr(feats), N, beam_width, nword, out, n, p)
+    return [(list(out[i * L:i * L + n[i]]), p[i]) for i in range(N)]
+
+
 def generate(ctx, param, feat, index_to_word, nword, beam_width, normalize=False):
     """generate (lrcn.jl:585-642): caption text "w1 w2 ... ." -- words after bos up to the first eos (:634-640)."""
     if normalize:

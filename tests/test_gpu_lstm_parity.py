@@ -86,6 +86,32 @@ def test_beam_search_vs_golden(golden_dir, name):
         assert abs(p - rp) <= 1e-4 * abs(rp)
 
 
+@pytest.mark.parametrize("dtype", [lrcn_amd.LRCN_F32, lrcn_amd.LRCN_BF16])
+def test_batched_beam_search_equals_per_image_decode(dtype):
+    # lrcn_beam_search_batch (N images x K hypotheses per lrcn() step, candidate ordering / stop test on the device) against
+    # the per-image lrcn_beam_search (itself checked against the golden decodes above): same tokens, same probability.
+    rng = np.random.default_rng(21)
+    E, H1, H2, V, K, nword, N = 48, 64, 64, 157, 5, 12, 9
+    feats = (rng.standard_normal((N, 4096)) * 0.05).astype(np.float32)
+    ctx = L.Context(E, H1, H2, V, max_B=N * K, max_T=4, lstm_dtype=dtype)
+    lens = set()
+    for eos_bias in (1.5, 0.4, -2.0):  # captions that stop at once, at mixed lengths, and only at the nword limit
+        m = orc.init_weights(E, H1, H2, V, seed=4)
+        m.p["bout"][:] = 0.0
+        m.p["bout"][0, 0] = eos_bias
+        m.p["Wout"][:] *= 6.0  # peaky distributions: no near-ties between the two code paths' GEMM shapes
+        param = L.model_from_arrays(m.p)
+        batch = L.beam_search_batch(ctx, param, L.to_jl(feats), K, nword)
+        for i in range(N):
+            toks, p = L.beam_search(ctx, param, L.to_jl(feats[i:i + 1]), K, nword)
+            assert batch[i][0] == toks, (eos_bias, i, batch[i][0], toks)
+            assert abs(batch[i][1] - p) <= 1e-3 * abs(p) + 1e-30
+            assert toks[0] == lrcn_amd._lib.BOS and len(toks) <= nword + 2
+            lens.add(len(toks))
+    assert len(lens) >= 2 and max(lens) == nword + 2, lens  # finishers at once and at the nword limit, frozen vs live images in one batch
+    ctx.close()
+
+
 def test_single_lstm_and_lrcn_step_vs_oracle():
     rng = np.random.default_rng(11)
     E, H1, H2, V, B = 24, 32, 16, 57, 5
