@@ -56,7 +56,8 @@ class HipOps:
         """A second HIP stream for the VGG forward (None = run everything in order on the caller's stream)."""
         if os.environ.get("LRCN_OVERLAP_VGG", "1")[:1] == "0":
             return None
-        return torch.cuda.Stream(device=self.ctx.device)
+        prio = int(os.environ.get("LRCN_VGG_STREAM_PRIO", "0"))  # -1 = high priority queue for the convolutions
+        return torch.cuda.Stream(device=self.ctx.device, priority=prio)
 
     def lossgradient(self, param, feats, tokens, norm_B, pdrop, seed, grads):
         L.lossgradient(self.ctx, param, feats, tokens, norm_B=norm_B, pdrop=pdrop, seed=seed, grads=grads,
