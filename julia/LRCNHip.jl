@@ -101,4 +101,18 @@ function beam_search(ctx, param, feat, beam_width, nword)
     (out[1:n[]] .+ Int32(1), p[])
 end
 
+# beam_search for N images at once (feats N x 4096): Vector of (1-based ids incl. bos, probability)   (new entry point)
+function beam_search_batch(ctx, param, feats, beam_width, nword)
+    N = size(feats, 1); L = nword + 2
+    out = Matrix{Int32}(undef, L, N); n = Vector{Cint}(undef, N); p = Vector{Cfloat}(undef, N)
+    check(ctx, ccall((:lrcn_beam_search_batch, lib), Cint,
+        (Ptr{Cvoid}, Ptr{Ptr{Cfloat}}, Ptr{Cfloat}, Cint, Cint, Cint, Ptr{Int32}, Ptr{Cint}, Ptr{Cfloat}),
+        ctx.h, ptrs(param), pointer(feats), N, beam_width, nword, out, n, p))
+    [(out[1:n[i], i] .+ Int32(1), p[i]) for i in 1:N]
+end
+
+# data parallelism: make `stream` (a hipStream_t) wait until gradient group g (0-based, see include/lrcn.h) of the last
+# lossgradient is final -- the host then starts that group's all-reduce while the rest of the backward pass runs
+grad_group_wait(ctx, g, stream) = check(ctx, ccall((:lrcn_grad_group_wait, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}), ctx.h, g, stream))
+
 end # module
