@@ -215,7 +215,8 @@ int prepare_weights(lrcn_ctx *c, const float *const p[9], bool need_bwd) {
 // pre-activations on exit; acts/Call/Hall receive the per-step results.  (lrcn.jl:528-538, time-batched)
 bool lstm_fused_on(lrcn_ctx *c, int B, int H, int64_t ldH, int64_t ld4H) {
     const char *k = getenv("LRCN_LSTM_FUSED");  // LRCN_LSTM_FUSED=0: GEMM + cell as separate launches at every batch size
-    return !(k && k[0] == '0') && lstm_fused_eligible(c->dt, B, H, ldH, ld4H);
+    const char *mb = getenv("LRCN_LSTM_FUSED_MAXB");  // kernel-development knob: largest batch routed to the fused step kernels
+    return !(k && k[0] == '0') && B <= (mb ? atoi(mb) : 128) && lstm_fused_eligible(c->dt, B, H, ldH, ld4H);
 }
 int lstm_layer_fwd(lrcn_ctx *c, int S, int B, int H, int64_t ldH, int64_t ld4H, float *Gx, const void *Wh, void *acts,
                    float *Call, void *Hall) {

@@ -1,4 +1,4 @@
-// lstm_fused.hip -- one launch per recurrent timestep for small batches (B <= 64 rows, bf16, gfx950):
+// lstm_fused.hip -- one launch per recurrent timestep for small and medium batches (bf16, gfx950; row blocks of 64):
 //   forward : G[s] = Gx[s] + h[s-1] Wh'  fused with the cell update of step s           (lrcn.jl:529-536)
 //   backward: dh_rec = dZ[s] Wh          fused with the cell backward of step s-1       (AutoGrad dual)
 // At 32..64 rows per GPU (what 4..8-way data parallelism leaves of a 256 batch) the LSTM step is a chain of ~130 tiny
@@ -6,7 +6,9 @@
 // work.  Here a workgroup owns 16 hidden units for all rows: the four gate pre-activations of a unit (forward) or the
 // four K-slices of the dh contraction (backward) are computed by the four WAVES of the workgroup, each an independent
 // [M x 16] MFMA GEMM with its own LDS-DMA ring (no barrier in the K loop -- a wave only reads what it staged itself), and
-// meet in LDS for the elementwise cell math.  63 workgroups for H = 1000.
+// meet in LDS for the elementwise cell math.  63 workgroups for H = 1000 per block of 64 rows (grid.y).  Used up to
+// B = 128 (LRCN_LSTM_FUSED_MAXB): at B = 256 it is faster alone (2.39 -> 2.21 ms per LSTM step) but its 252 LDS-heavy
+// workgroups take more from the concurrently running convolutions than the separate launches do.
 #include <type_traits>
 
 #include "common.h"
@@ -140,13 +142,15 @@ template <int MT> __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(con
     extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // = gate
-    const int u0 = blockIdx.x * 16, H = a.H, M = a.B;
+    const int u0 = blockIdx.x * 16, H = a.H;
+    const int r0 = blockIdx.y * (MT * 16);                       // row block (batches > 64 rows: several blocks of 64)
+    const int M = a.B - r0 < MT * 16 ? a.B - r0 : MT * 16;
     const int valid = H - u0 < 16 ? H - u0 : 16;
     f32x4v acc[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) acc[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
-    wave_gemm<MT, G::PF>(acc, a.h_prev, a.ldh, M, a.Wh, a.ldh, wave * H + u0, valid, 0, (int)(a.ldh / 64), smem, wave * G::WAVE_LDS,
-                         a.zero_page, lane);
+    wave_gemm<MT, G::PF>(acc, a.h_prev + (int64_t)r0 * a.ldh, a.ldh, M, a.Wh, a.ldh, wave * H + u0, valid, 0, (int)(a.ldh / 64), smem,
+                         wave * G::WAVE_LDS, a.zero_page, lane);
     __syncthreads();  // every wave is done with its ring: the exchange area may overwrite it
     float *xch = reinterpret_cast<float *>(smem);
     const int l15 = lane & 15, lq = lane >> 4;
@@ -156,13 +160,13 @@ template <int MT> __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(con
         for (int r = 0; r < 4; ++r) xch[(wave * MT * 16 + i * 16 + 4 * lq + r) * 17 + l15] = acc[i][r];
     __syncthreads();
     for (int e = tid; e < M * 16; e += 256) {
-        const int m = e >> 4, u = e & 15, j = u0 + u;
+        const int ml = e >> 4, u = e & 15, j = u0 + u, m = r0 + ml;
         if (j >= H) continue;
         const float *gx = a.Gx + (int64_t)m * 4 * H;
-        const float f = sigm_f(xch[(0 * MT * 16 + m) * 17 + u] + gx[j]);
-        const float i = sigm_f(xch[(1 * MT * 16 + m) * 17 + u] + gx[H + j]);
-        const float o = sigm_f(xch[(2 * MT * 16 + m) * 17 + u] + gx[2 * H + j]);
-        const float ch = tanhf(xch[(3 * MT * 16 + m) * 17 + u] + gx[3 * H + j]);
+        const float f = sigm_f(xch[(0 * MT * 16 + ml) * 17 + u] + gx[j]);
+        const float i = sigm_f(xch[(1 * MT * 16 + ml) * 17 + u] + gx[H + j]);
+        const float o = sigm_f(xch[(2 * MT * 16 + ml) * 17 + u] + gx[2 * H + j]);
+        const float ch = tanhf(xch[(3 * MT * 16 + ml) * 17 + u] + gx[3 * H + j]);
         const float c = a.c_prev[(int64_t)m * H + j] * f + i * ch;
         const float h = o * tanhf(c);
         bf16_t *ac = a.acts + (int64_t)m * a.ld_a;
@@ -195,14 +199,17 @@ template <int MT> __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(con
     extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // = K slice
-    const int u0 = blockIdx.x * 16, H = a.H, M = a.B;
+    const int u0 = blockIdx.x * 16, H = a.H;
+    const int r0 = blockIdx.y * (MT * 16);
+    const int M = a.B - r0 < MT * 16 ? a.B - r0 : MT * 16;
     const int valid = H - u0 < 16 ? H - u0 : 16;
     const int KT = (int)(a.ld4 / 64), per = (KT + 3) / 4;
     const int kt0 = wave * per < KT ? wave * per : KT, kt1 = (wave + 1) * per < KT ? (wave + 1) * per : KT;
     f32x4v acc[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) acc[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
-    wave_gemm<MT, G::PF>(acc, a.dz_s, a.ld4, M, a.WhT, a.ld4, u0, valid, kt0, kt1, smem, wave * G::WAVE_LDS, a.zero_page, lane);
+    wave_gemm<MT, G::PF>(acc, a.dz_s + (int64_t)r0 * a.ld4, a.ld4, M, a.WhT, a.ld4, u0, valid, kt0, kt1, smem, wave * G::WAVE_LDS, a.zero_page,
+                         lane);
     __syncthreads();
     float *xch = reinterpret_cast<float *>(smem);
     const int l15 = lane & 15, lq = lane >> 4;
@@ -212,10 +219,10 @@ template <int MT> __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(con
         for (int r = 0; r < 4; ++r) xch[(wave * MT * 16 + i * 16 + 4 * lq + r) * 17 + l15] = acc[i][r];
     __syncthreads();
     for (int e = tid; e < M * 16; e += 256) {
-        const int m = e >> 4, u = e & 15, j = u0 + u;
+        const int ml = e >> 4, u = e & 15, j = u0 + u, m = r0 + ml;
         if (j >= H) continue;
-        const float dh = a.dh_ext[(int64_t)m * H + j] + xch[(0 * MT * 16 + m) * 17 + u] + xch[(1 * MT * 16 + m) * 17 + u] +
-                         xch[(2 * MT * 16 + m) * 17 + u] + xch[(3 * MT * 16 + m) * 17 + u];
+        const float dh = a.dh_ext[(int64_t)m * H + j] + xch[(0 * MT * 16 + ml) * 17 + u] + xch[(1 * MT * 16 + ml) * 17 + u] +
+                         xch[(2 * MT * 16 + ml) * 17 + u] + xch[(3 * MT * 16 + ml) * 17 + u];
         const bf16_t *ac = a.acts + (int64_t)m * a.ld4;
         const float f = (float)ac[j], i = (float)ac[H + j], o = (float)ac[2 * H + j], g = (float)ac[3 * H + j];
         const float tc = tanhf(a.c_new[(int64_t)m * H + j]);
@@ -241,7 +248,7 @@ template <class K> hipError_t set_lds(K kern, int lds, bool &done) {
 }  // namespace
 
 bool lstm_fused_eligible(int dtype, int B, int H, int64_t ldh, int64_t ld4) {
-    return dtype == GEMM_T_BF16 && B >= 1 && B <= 64 && H >= 16 && (ldh % 64) == 0 && (ld4 % 64) == 0 &&
+    return dtype == GEMM_T_BF16 && B >= 1 && B <= 1024 && H >= 16 && (ldh % 64) == 0 && (ld4 % 64) == 0 &&
            (int64_t)B * ld4 < (1ll << 31) && (int64_t)4 * H * ldh < (1ll << 31);
 }
 
@@ -251,7 +258,7 @@ hipError_t launch_lstm_rec_fwd(hipStream_t st, const void *h_prev, int64_t ldh, 
     a.h_prev = (const bf16_t *)h_prev; a.Wh = (const bf16_t *)Wh; a.Gx = Gx; a.c_prev = c_prev;
     a.acts = (bf16_t *)acts; a.c_new = c_new; a.h_new = (bf16_t *)h_new; a.zero_page = zero_page;
     a.ldh = ldh; a.ld_a = ld_a; a.B = B; a.H = H;
-    const dim3 grid((H + 15) / 16);
+    const dim3 grid((H + 15) / 16, B <= 32 ? 1 : (B + 63) / 64);
     static bool d2 = false, d4 = false;
     hipError_t e;
     if (B <= 32) {
@@ -270,7 +277,7 @@ hipError_t launch_lstm_rec_bwd(hipStream_t st, const void *dz_s, int64_t ld4, co
     a.dz_s = (const bf16_t *)dz_s; a.WhT = (const bf16_t *)WhT; a.acts = (const bf16_t *)acts; a.c_prev = c_prev; a.c_new = c_new;
     a.dh_ext = dh_ext; a.dc = dc; a.dz_out = (bf16_t *)dz_out; a.zero_page = zero_page;
     a.ld4 = ld4; a.B = B; a.H = H;
-    const dim3 grid((H + 15) / 16);
+    const dim3 grid((H + 15) / 16, B <= 32 ? 1 : (B + 63) / 64);
     static bool d2 = false, d4 = false;
     hipError_t e;
     if (B <= 32) {
