@@ -9,8 +9,8 @@ Workload = BASELINE.json configs[3] / SURVEY.md 8(d) "C4": MS-COCO-shaped synthe
 E=H1=H2=1000 bf16 (fp32 accumulate / master weights / Adam), V=10640, T=11, GLOBAL batch 256 split by rows over the
 N ranks ("strong" scaling), dropout 0.4, one RCCL all-reduce(SUM) of the 39.8 M fp32 gradients per step.
 A step = [VGG fwd on B/N images] + lossgradient + all-reduce + update!; inputs (uint8 crops, tokens) resident in HBM.
-The VGG forward of step k+1 runs on a side HIP stream beside the LSTM work of step k (dp.py); every step's VGG forward,
-including the first one's, is inside the timed region or the warm-up that precedes it (K steps = K VGG forwards).
+The VGG forward of step k+1 runs on a side HIP stream beside the LSTM work of step k (dp.py).  The timed region is the pipeline
+in steady state: each of its K steps issues one VGG forward (of the next batch) and one LSTM step, K of each in total.
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
 """
 import argparse
@@ -123,10 +123,13 @@ def main():
     toks_all = [torch.as_tensor((rng.choice(V - 3, size=(T, Bg), p=pz) + 3).astype(np.int32)[:, rows.start:rows.stop]
                                 .copy()).cuda() for _ in range(n_sets)]
 
-    def run(nsteps, first_feats=None):
-        for k in range(nsteps):
-            nxt = imgs_all[(k + 1) % n_sets] if k + 1 < nsteps else None
-            trainer.step(imgs_all[k % n_sets], toks_all[k % n_sets], next_img_u8=nxt)
+    def run(nsteps):
+        # steady-state pipeline: EVERY step (the last one too) issues the VGG forward of the batch after it, so a run of K steps
+        # holds exactly K VGG forwards + K LSTM steps; the features a run's first step consumes were produced by the previous
+        # run's last step (the warm-up's, for the timed region), or in order if there is none.
+        for _ in range(nsteps):
+            k = trainer.step_no  # global step index: batch k uses image/token set k mod n_sets, also across warm-up -> timed region
+            trainer.step(imgs_all[k % n_sets], toks_all[k % n_sets], next_img_u8=imgs_all[(k + 1) % n_sets])
 
     def barrier():
         torch.cuda.synchronize()
