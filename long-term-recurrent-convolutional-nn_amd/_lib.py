@@ -9,7 +9,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "liblrcn_hip.so")
+LIB_PATH = os.environ.get("LRCN_HIP_LIB") or os.path.join(CSRC, "liblrcn_hip.so")  # override: A/B builds of the kernels in one session
 HEADER = os.path.normpath(os.path.join(HERE, "..", "include", "lrcn.h"))
 
 LRCN_F32, LRCN_BF16 = 0, 1
