@@ -245,40 +245,86 @@ __global__ void transpose_kernel(const Tin *in, int64_t ld_in, int R, int C, Tou
 // All shadow weights of one model in ONE launch (was 8 cast_rows + 9 transpose launches per step): for every 32 x 32 tile of
 // a parameter's memory image [R][C] (f32) write the direct copy split at column `cs` (dA[r][c], dB[r][c - cs]) and / or the
 // transposed copy (tA[c][r], tB[c - cs][r]) in T.  Padding columns of the destinations are never touched (zero since allocation).
-template <typename T> __global__ void prepare_weights_kernel(const PrepPlan plan) {
-    __shared__ float tile[32][33];
+template <typename T> __device__ __forceinline__ void store4(T *p, const float *v) {
+    struct alignas(4 * sizeof(T)) V4 { T e[4]; };
+    V4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o.e[k] = from_f32<T>(v[k]);
+    *reinterpret_cast<V4 *>(p) = o;
+}
+
+template <typename T> __global__ __launch_bounds__(256) void prepare_weights_kernel(const PrepPlan plan) {
+    // 64 x 64 tiles, 16 bytes in / 8 bytes out per thread access (bf16); generic element-wise path for f32 shadows and edges
+    __shared__ float tile[64][65];
     int d = 0;
 #pragma unroll
     for (int k = 1; k < PREP_MAX; ++k)
         if (k < plan.n && (int)blockIdx.x >= plan.d[k].tile0) d = k;
     const PrepDesc &P = plan.d[d];
     const int t = blockIdx.x - P.tile0;
-    const int tc = (P.C + 31) / 32;
-    const int r0 = (t / tc) * 32, c0 = (t % tc) * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int i = ty; i < 32; i += 8) {
-        const int r = r0 + i, c = c0 + tx;
-        const bool ok = r < P.R && c < P.C;
-        const float v = ok ? P.src[(int64_t)r * P.C + c] : 0.0f;
-        tile[i][tx] = v;
-        if (ok) {
-            if (c < P.cs) {
-                if (P.dA) reinterpret_cast<T *>(P.dA)[(int64_t)r * P.ldA + c] = from_f32<T>(v);
-            } else if (P.dB) {
-                reinterpret_cast<T *>(P.dB)[(int64_t)r * P.ldB + (c - P.cs)] = from_f32<T>(v);
+    const int tc = (P.C + 63) / 64;
+    const int r0 = (t / tc) * 64, c0 = (t % tc) * 64;
+    const int q = threadIdx.x & 15, rr = threadIdx.x >> 4;  // 16 column quads x 16 row groups
+    const bool vec = (P.C % 4) == 0 && (P.cs % 4) == 0;
+    auto al = [](const void *p, int64_t ld) { return (reinterpret_cast<uintptr_t>(p) % (4 * sizeof(T))) == 0 && (ld % 4) == 0; };
+    const bool alA = al(P.dA, P.ldA), alB = al(P.dB, P.ldB), altA = al(P.tA, P.ldtA), altB = al(P.tB, P.ldtB);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + rr + 16 * i, c = c0 + 4 * q;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (r < P.R) {
+            if (vec && c + 3 < P.C) {
+                const float4 x = *reinterpret_cast<const float4 *>(P.src + (int64_t)r * P.C + c);
+                v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (c + k < P.C) v[k] = P.src[(int64_t)r * P.C + c + k];
+            }
+            const bool sideA = c + 3 < P.cs, sideB = c >= P.cs;
+            if (vec && c + 3 < P.C && sideA && alA) {
+                if (P.dA) store4(reinterpret_cast<T *>(P.dA) + (int64_t)r * P.ldA + c, v);
+            } else if (vec && c + 3 < P.C && sideB && alB) {
+                if (P.dB) store4(reinterpret_cast<T *>(P.dB) + (int64_t)r * P.ldB + (c - P.cs), v);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int cc = c + k;
+                    if (cc >= P.C) continue;
+                    if (cc < P.cs) {
+                        if (P.dA) reinterpret_cast<T *>(P.dA)[(int64_t)r * P.ldA + cc] = from_f32<T>(v[k]);
+                    } else if (P.dB) {
+                        reinterpret_cast<T *>(P.dB)[(int64_t)r * P.ldB + (cc - P.cs)] = from_f32<T>(v[k]);
+                    }
+                }
             }
         }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tile[rr + 16 * i][4 * q + k] = v[k];
     }
     if (!P.tA && !P.tB) return;
     __syncthreads();
-    for (int i = ty; i < 32; i += 8) {
-        const int c = c0 + i, r = r0 + tx;
-        if (c < P.C && r < P.R) {
-            if (c < P.cs) {
-                if (P.tA) reinterpret_cast<T *>(P.tA)[(int64_t)c * P.ldtA + r] = from_f32<T>(tile[tx][i]);
-            } else if (P.tB) {
-                reinterpret_cast<T *>(P.tB)[(int64_t)(c - P.cs) * P.ldtB + r] = from_f32<T>(tile[tx][i]);
-            }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + rr + 16 * i;  // source column = destination row
+        if (c >= P.C) continue;
+        T *dst = nullptr;
+        if (c < P.cs) {
+            if (P.tA) dst = reinterpret_cast<T *>(P.tA) + (int64_t)c * P.ldtA;
+        } else if (P.tB) {
+            dst = reinterpret_cast<T *>(P.tB) + (int64_t)(c - P.cs) * P.ldtB;
+        }
+        if (!dst) continue;
+        const int r = r0 + 4 * q;
+        if (r + 3 < P.R && (c < P.cs ? altA : altB)) {
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = tile[4 * q + k][rr + 16 * i];
+            store4(dst + r, v);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (r + k < P.R) dst[r + k] = from_f32<T>(tile[4 * q + k][rr + 16 * i]);
         }
     }
 }
@@ -681,7 +727,7 @@ void k_prepare_weights(hipStream_t st, int dtype, PrepPlan &plan) {
     int tiles = 0;
     for (int k = 0; k < plan.n; ++k) {
         plan.d[k].tile0 = tiles;
-        tiles += cdiv(plan.d[k].R, 32) * cdiv(plan.d[k].C, 32);
+        tiles += cdiv(plan.d[k].R, 64) * cdiv(plan.d[k].C, 64);
     }
     if (tiles == 0) return;
     DISPATCH_T(dtype, hipLaunchKernelGGL(prepare_weights_kernel<T>, dim3(tiles), dim3(256), 0, st, plan));
