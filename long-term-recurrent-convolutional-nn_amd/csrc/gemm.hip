@@ -15,6 +15,7 @@
 //
 // Replaces, in the reference: cublasSgemm at lrcn.jl:529/545/550/558 (+ their AutoGrad duals), conv4+bias+relu+pool
 // at lrcn.jl:724-726, fcx at lrcn.jl:728.
+#include <cstdio>
 #include "gemm.h"
 
 #include <cstdlib>
@@ -269,7 +270,15 @@ template <typename T> hipError_t dispatch(hipStream_t s, const GemmArgs &g) {
 
 }  // namespace
 
+static hipError_t launch_gemm_routed(hipStream_t stream, const GemmArgs &g, const char **route);
 hipError_t launch_gemm(hipStream_t stream, const GemmArgs &g) {
+    static const bool trace = getenv("LRCN_GEMM_TRACE") != nullptr;  // development: print the kernel family every GEMM takes
+    const char *route = "?";
+    const hipError_t e = launch_gemm_routed(stream, g, &route);
+    if (trace) fprintf(stderr, "[gemm] M=%d N=%d K=%d lda=%ld ldb=%ld amode=%d out=%d beta=%d -> %s\n", g.M, g.N, g.K, (long)g.lda, (long)g.ldb, g.a_mode, g.out_mode, (int)g.beta, route);
+    return e;
+}
+static hipError_t launch_gemm_routed(hipStream_t stream, const GemmArgs &g, const char **route) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0 || !g.A || !g.B || !g.C) return hipErrorInvalidValue;
     // LRCN_GLDS=0 disables the direct-to-LDS path, LRCN_GLDS=force uses it whenever eligible (tests); default: when
     // the grid fills the chip.
@@ -279,18 +288,18 @@ hipError_t launch_gemm(hipStream_t stream, const GemmArgs &g) {
     const bool skinny_ok = !(knob && knob[0] == '0') && !(knobs && knobs[0] == '0') && gemm_skinny_eligible(g);
     if (!(knob && knob[0] == '0') && !(knob8 && knob8[0] == '0')) {
         int64_t blocks = 0;
-        if (gemm_8p_config(g, &blocks) >= 0 && ((knob8 && knob8[0] == 'f') || blocks >= 128)) return launch_gemm_8p(stream, g);
-        if (skinny_ok && g.M <= 128) return launch_gemm_skinny(stream, g);
+        if (gemm_8p_config(g, &blocks) >= 0 && ((knob8 && knob8[0] == 'f') || blocks >= 128)) { *route = "8p"; return launch_gemm_8p(stream, g); }
+        if (skinny_ok && g.M <= 128) { *route = "skinny"; return launch_gemm_skinny(stream, g); }
         const char *ksk = getenv("LRCN_8P_SPLITK");  // kernel-development knob: 0 disables the split-K form
         const int sk = (ksk && ksk[0] == '0') ? 0 : gemm_8p_splitk(g, &blocks);
         const char *kth = getenv("LRCN_8P_SPLITK_MIN");
-        if (sk > 1 && blocks >= (kth ? atoi(kth) : 96)) return launch_gemm_8p(stream, g, sk);
+        if (sk > 1 && blocks >= (kth ? atoi(kth) : 96)) { *route = "8p-splitk"; return launch_gemm_8p(stream, g, sk); }
     }
     if (!(knob && knob[0] == '0') && gemm_glds_eligible(g)) {
         const int64_t blocks = gemm_glds_blocks(g);
-        if (blocks > 0 && ((knob && knob[0] == 'f') || blocks >= 96)) return launch_gemm_glds(stream, g);
+        if (blocks > 0 && ((knob && knob[0] == 'f') || blocks >= 96)) { *route = "glds"; return launch_gemm_glds(stream, g); }
     }
-    if (skinny_ok) return launch_gemm_skinny(stream, g);  // 128 < M <= 256 with too few tiles for the paths above
+    if (skinny_ok) { *route = "skinny-last"; return launch_gemm_skinny(stream, g); }  // 128 < M <= 256 with too few tiles for the paths above
     const int ce = g.dtype == GEMM_T_BF16 ? 8 : 4;
     if (((uintptr_t)g.A & 15) || ((uintptr_t)g.B & 15) || (g.ldb % ce)) return hipErrorInvalidValue;
     if (g.a_mode == GEMM_A_CONV3) {
@@ -301,5 +310,6 @@ hipError_t launch_gemm(hipStream_t stream, const GemmArgs &g) {
     }
     if (g.out_mode != GEMM_OUT_PLAIN && ((g.H & 1) || (g.W & 1) || g.H <= 0 || g.W <= 0)) return hipErrorInvalidValue;
     if (g.out_mode == GEMM_OUT_POOL && (g.beta || (g.M & 3))) return hipErrorInvalidValue;
+    *route = "gemm_nt";
     return g.dtype == GEMM_T_BF16 ? dispatch<bf16_t>(stream, g) : dispatch<float>(stream, g);
 }

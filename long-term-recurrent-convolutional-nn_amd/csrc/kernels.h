@@ -12,7 +12,7 @@ struct DropSpec {
 };
 
 // tok_in[s][b] = bos (s==0) | tokens[s-1][b];  tok_tgt[s][b] = tokens[s][b] (s<T) | eos.   (lrcn.jl:556,565,569,576)
-void k_build_tokens(hipStream_t st, const int32_t *tokens, int T, int B, int V, int32_t *tok_in, int32_t *tok_tgt);
+void k_build_tokens(hipStream_t st, const int32_t *tokens, int T, int B, int V, int32_t *tok_in, int32_t *tok_tgt, double *zero_acc);
 
 // Xemb[m][e] = WembT[tok_in[m]][e] * dropmask   (lrcn.jl:556/569 gather + :542 dropout), m = s*B+b.
 void k_embed_gather(hipStream_t st, int dtype, const void *wembT, int64_t ld_w, const int32_t *tok_in, int S, int B,
@@ -28,7 +28,7 @@ void k_lstm_fwd(hipStream_t st, int dtype, const float *G, int64_t ld_g, const f
 // Reverse of the cell.  dh_a (+ dh_b, may be NULL) f32 [B][H]; dc f32 [B][H] is read and replaced by
 // dc_prev.  Writes dZ (T) [B][4H].
 void k_lstm_bwd(hipStream_t st, int dtype, const void *acts, int64_t ld_a, const float *c_prev, const float *c_new,
-                const float *dh_a, int64_t ld_dha, const float *dh_b, float *dc, int B, int H, void *dz,
+                const float *dh_a, int64_t ld_dha, const float *dh_b, float *dc, int dc_zero, int B, int H, void *dz,
                 int64_t ld_dz);
 
 // Small-batch fused recurrent steps (lstm_fused.hip; bf16, B <= 64): one launch = the recurrent GEMM of a timestep + the cell
@@ -85,6 +85,20 @@ void k_uncast_rows(hipStream_t st, int dtype, const void *in, int64_t ld_in, int
 
 // db[n] = sum_m Z[m][n]   (Z is T [M][ld]); f32 output, overwritten.
 void k_colsum(hipStream_t st, int dtype, const void *z, int64_t ld, int M, int N, float *out);
+// Several T -> T transposes in one launch: dst[c][shift + r] = src[r][c]; columns [0, shift) and [R + shift, ld_dst) of every
+// destination row are written as zeros (K padding of the GEMM that consumes it).  R == 0 zero-fills the C destination rows.
+#define TR_MAX 4
+struct TrDesc {
+    const void *src;
+    void *dst;
+    int64_t ld_src, ld_dst;
+    int R, C, shift, tile0;
+};
+struct TrPlan {
+    TrDesc d[TR_MAX];
+    int n;
+};
+void k_transpose_multi(hipStream_t st, int dtype, TrPlan &plan);
 
 struct AdamTensors {
     float *w[9];

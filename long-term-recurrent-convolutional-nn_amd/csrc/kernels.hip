@@ -39,8 +39,9 @@ __device__ __forceinline__ float drop_mult(const DropSpec &d, int s, int b, int 
 
 __device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-__global__ void build_tokens_kernel(const int32_t *tokens, int T, int B, int V, int32_t *tok_in, int32_t *tok_tgt) {
+__global__ void build_tokens_kernel(const int32_t *tokens, int T, int B, int V, int32_t *tok_in, int32_t *tok_tgt, double *zero_acc) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && zero_acc) *zero_acc = 0.0;  // the log-likelihood accumulator of softmax_xent (saves a memset launch)
     const int S = T + 1;
     if (i >= S * B) return;
     const int s = i / B, b = i - s * B;
@@ -97,7 +98,7 @@ __global__ void lstm_fwd_kernel(const float *G, int64_t ld_g, const float *c_pre
 
 template <typename T>
 __global__ void lstm_bwd_kernel(const T *acts, int64_t ld_a, const float *c_prev, const float *c_new, const float *dh_a,
-                                int64_t ld_dha, const float *dh_b, float *dc, int B, int H, T *dz, int64_t ld_dz) {
+                                int64_t ld_dha, const float *dh_b, float *dc, int dc_zero, int B, int H, T *dz, int64_t ld_dz) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
     if (j >= H) return;
     const T *a = acts + (int64_t)b * ld_a;
@@ -106,7 +107,7 @@ __global__ void lstm_bwd_kernel(const T *acts, int64_t ld_a, const float *c_prev
     float dh = dh_a[(int64_t)b * ld_dha + j];
     if (dh_b) dh += dh_b[(int64_t)b * H + j];
     const float dov = dh * tc;
-    const float dcv = dc[(int64_t)b * H + j] + dh * o * (1.0f - tc * tc);
+    const float dcv = (dc_zero ? 0.0f : dc[(int64_t)b * H + j]) + dh * o * (1.0f - tc * tc);
     const float cp = c_prev ? c_prev[(int64_t)b * H + j] : 0.0f;
     T *z = dz + (int64_t)b * ld_dz;
     z[j] = from_f32<T>(dcv * cp * f * (1.0f - f));
@@ -354,17 +355,95 @@ __global__ void uncast_rows_kernel(const T *in, int64_t ld_in, int R, int C, flo
         out[(int64_t)r * ld_out + c] = to_f32(in[(int64_t)r * ld_in + c]);
 }
 
-template <typename T> __global__ void colsum_kernel(const T *z, int64_t ld, int M, int N, float *out) {
-    // block = 64 columns x 4 row groups over a 256-row slab (blockIdx.y); slabs are combined with f32 atomics (out zeroed)
-    __shared__ float sh[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
-    const int m1 = min(M, (int)(blockIdx.y + 1) * 256);
-    float acc = 0.0f;
-    if (c < N)
-        for (int m = blockIdx.y * 256 + rg; m < m1; m += 4) acc += to_f32(z[(int64_t)m * ld + c]);
-    sh[rg][threadIdx.x & 63] = acc;
+template <typename T> __global__ __launch_bounds__(256) void colsum_kernel(const T *z, int64_t ld, int M, int N, int rows_per_slab, float *out) {
+    // block = 64 columns (16 lanes x 4 elements, one 8/16-byte load each) x 16 row groups over one slab of rows (blockIdx.y).
+    // One slab: plain store (no zeroing, deterministic).  Several slabs: f32 atomics into an output the host zeroed.
+    __shared__ float sh[16][65];
+    const int q = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + 4 * q;
+    const int m0 = blockIdx.y * rows_per_slab, m1 = min(M, m0 + rows_per_slab);
+    struct alignas(4 * sizeof(T)) V4 { T e[4]; };
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < N) {  // ld % 4 == 0 and N <= ld: the whole quad is inside the row
+#pragma unroll 4
+        for (int m = m0 + rg; m < m1; m += 16) {
+            const V4 v = *reinterpret_cast<const V4 *>(z + (int64_t)m * ld + c);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] += to_f32(v.e[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sh[rg][4 * q + k] = acc[k];
     __syncthreads();
-    if (rg == 0 && c < N) atomicAdd(out + c, sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+    if (threadIdx.x < 64) {
+        const int cc = blockIdx.x * 64 + threadIdx.x;
+        float t = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += sh[r][threadIdx.x];
+        if (cc < N) {
+            if (gridDim.y == 1) out[cc] = t;
+            else atomicAdd(out + cc, t);
+        }
+    }
+}
+
+template <typename T> __global__ __launch_bounds__(256) void transpose_multi_kernel(const TrPlan plan) {
+    __shared__ float tile[64][65];
+    int d = 0;
+#pragma unroll
+    for (int k = 1; k < TR_MAX; ++k)
+        if (k < plan.n && (int)blockIdx.x >= plan.d[k].tile0) d = k;
+    const TrDesc &P = plan.d[d];
+    const T *src = reinterpret_cast<const T *>(P.src);
+    T *dst = reinterpret_cast<T *>(P.dst);
+    const int t = blockIdx.x - P.tile0;
+    const int tc = (P.C + 63) / 64, tr = P.R > 0 ? (P.R + 63) / 64 : 1;
+    const int ty = t / tc;
+    const int r0 = ty * 64, c0 = (t % tc) * 64;
+    const int q = threadIdx.x & 15, rr = threadIdx.x >> 4;
+    struct alignas(4 * sizeof(T)) V4 { T e[4]; };
+    const bool vin = (P.ld_src % 4) == 0 && (reinterpret_cast<uintptr_t>(src) % sizeof(V4)) == 0;
+    const bool vout = (P.ld_dst % 4) == 0 && (P.shift % 4) == 0 && (reinterpret_cast<uintptr_t>(dst) % sizeof(V4)) == 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + rr + 16 * i, c = c0 + 4 * q;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (r < P.R && c < P.C) {
+            if (vin && c + 3 < P.ld_src) {
+                const V4 x = *reinterpret_cast<const V4 *>(src + (int64_t)r * P.ld_src + c);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = to_f32(x.e[k]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (c + k < P.C) v[k] = to_f32(src[(int64_t)r * P.ld_src + c + k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tile[rr + 16 * i][4 * q + k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + rr + 16 * i;  // source column = destination row
+        if (c >= P.C) continue;
+        T *row = dst + (int64_t)c * P.ld_dst;
+        const int r = r0 + 4 * q;
+        if (vout && r + 3 < P.R) {
+            V4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o.e[k] = from_f32<T>(tile[4 * q + k][rr + 16 * i]);
+            *reinterpret_cast<V4 *>(row + P.shift + r) = o;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (r + k < P.R) row[P.shift + r + k] = from_f32<T>(tile[4 * q + k][rr + 16 * i]);
+        }
+        if (ty == 0)
+            for (int x = q; x < P.shift; x += 16) row[x] = from_f32<T>(0.0f);
+        if (ty == tr - 1)
+            for (int64_t x = P.R + P.shift + q; x < P.ld_dst; x += 16) row[x] = from_f32<T>(0.0f);
+    }
 }
 
 __global__ void adam_kernel(AdamTensors t, float lr, float b1, float b2, float eps, float c1, float c2) {
@@ -666,9 +745,9 @@ inline unsigned grid1d(int64_t n, int block = 256, int64_t cap = 8192) {
 }  // namespace
 
 // ---------------------------------------------------------------- launchers
-void k_build_tokens(hipStream_t st, const int32_t *tokens, int T, int B, int V, int32_t *tok_in, int32_t *tok_tgt) {
+void k_build_tokens(hipStream_t st, const int32_t *tokens, int T, int B, int V, int32_t *tok_in, int32_t *tok_tgt, double *zero_acc) {
     const int n = (T + 1) * B;
-    hipLaunchKernelGGL(build_tokens_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, tokens, T, B, V, tok_in, tok_tgt);
+    hipLaunchKernelGGL(build_tokens_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, tokens, T, B, V, tok_in, tok_tgt, zero_acc);
 }
 void k_embed_gather(hipStream_t st, int dtype, const void *wembT, int64_t ld_w, const int32_t *tok_in, int S, int B, int E,
                     DropSpec d, void *xemb, int64_t ld_x) {
@@ -685,9 +764,9 @@ void k_lstm_fwd(hipStream_t st, int dtype, const float *G, int64_t ld_g, const f
                                          (T *)acts, ld_a, c_new, (T *)h_new, ld_h, h_new_f32));
 }
 void k_lstm_bwd(hipStream_t st, int dtype, const void *acts, int64_t ld_a, const float *c_prev, const float *c_new,
-                const float *dh_a, int64_t ld_dha, const float *dh_b, float *dc, int B, int H, void *dz, int64_t ld_dz) {
+                const float *dh_a, int64_t ld_dha, const float *dh_b, float *dc, int dc_zero, int B, int H, void *dz, int64_t ld_dz) {
     DISPATCH_T(dtype, hipLaunchKernelGGL(lstm_bwd_kernel<T>, dim3(cdiv(H, 256), B), dim3(256), 0, st, (const T *)acts, ld_a,
-                                         c_prev, c_new, dh_a, ld_dha, dh_b, dc, B, H, (T *)dz, ld_dz));
+                                         c_prev, c_new, dh_a, ld_dha, dh_b, dc, dc_zero, B, H, (T *)dz, ld_dz));
 }
 void k_concat_x2(hipStream_t st, int dtype, void *x2, int64_t ld_x2, const float *xcnn, int64_t ld_xc, int S, int B, int h,
                  DropSpec d) {
@@ -747,9 +826,24 @@ void k_uncast_rows(hipStream_t st, int dtype, const void *in, int64_t ld_in, int
                                          ld_out));
 }
 void k_colsum(hipStream_t st, int dtype, const void *z, int64_t ld, int M, int N, float *out) {
-    (void)hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, st);
-    DISPATCH_T(dtype, hipLaunchKernelGGL(colsum_kernel<T>, dim3(cdiv(N, 64), cdiv(M, 256)), dim3(256), 0, st, (const T *)z, ld,
-                                         M, N, out));
+    // enough slabs of rows to give the chip ~2 blocks per CU; a single slab needs no zeroing and no atomics
+    const int cb = cdiv(N, 64);
+    int slabs = cdiv(512, cb);
+    if (slabs > cdiv(M, 64)) slabs = cdiv(M, 64);
+    if (slabs < 1) slabs = 1;
+    const int rows = cdiv(cdiv(M, slabs), 16) * 16;
+    slabs = cdiv(M, rows);
+    if (slabs > 1) (void)hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, st);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(colsum_kernel<T>, dim3(cb, slabs), dim3(256), 0, st, (const T *)z, ld, M, N, rows, out));
+}
+void k_transpose_multi(hipStream_t st, int dtype, TrPlan &plan) {
+    int tiles = 0;
+    for (int k = 0; k < plan.n; ++k) {
+        plan.d[k].tile0 = tiles;
+        tiles += (plan.d[k].R > 0 ? cdiv(plan.d[k].R, 64) : 1) * cdiv(plan.d[k].C, 64);
+    }
+    if (tiles == 0) return;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(transpose_multi_kernel<T>, dim3(tiles), dim3(256), 0, st, plan));
 }
 void k_adam(hipStream_t st, const AdamTensors &t, int step, float lr, float b1, float b2, float eps) {
     const float c1 = (float)(1.0 - pow((double)b1, (double)step)), c2 = (float)(1.0 - pow((double)b2, (double)step));

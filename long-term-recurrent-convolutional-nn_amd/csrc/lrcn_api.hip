@@ -56,7 +56,7 @@ struct lrcn_ctx {
     float *G1 = nullptr, *C1 = nullptr, *G2 = nullptr, *C2 = nullptr, *Logits = nullptr;
     void *dLog = nullptr, *dZ1 = nullptr, *dZ2 = nullptr, *dX2 = nullptr;
     float *dH1all = nullptr, *dH2all = nullptr, *dXemb = nullptr, *dhrec = nullptr, *dc = nullptr, *dxcnn = nullptr;
-    void *TA = nullptr, *TB = nullptr;  // transposed-operand scratch: up to [max(4H,V)][ldM] and [max(E,H,4096)][ldM]
+    void *TA = nullptr, *TB = nullptr;  // transposed-operand scratch: up to [max(4H,V)][ldM] and [max(2*H2, E+H1)][ldM]
     void *dxcT = nullptr;
     double *logp = nullptr;
     void *zero_page = nullptr;
@@ -246,11 +246,10 @@ int lstm_layer_fwd(lrcn_ctx *c, int S, int B, int H, int64_t ldH, int64_t ld4H, 
 int lstm_layer_bwd(lrcn_ctx *c, int S, int B, int H, int64_t ld4H, const void *acts, const float *Call, const float *dHall,
                    const void *WhT, void *dZ) {
     const int dt = c->dt;
-    HIPCHK(c, hipMemsetAsync(c->dc, 0, sizeof(float) * (size_t)B * H, c->stream));
     if (lstm_fused_on(c, B, H, round_up64(H, 64), ld4H)) {
         // cell backward of the last step, then one launch per step: dh_rec = dZ[s] Wh fused with the cell backward of s-1
         k_lstm_bwd(c->stream, dt, boff(acts, (int64_t)(S - 1) * B * ld4H, c->esz), ld4H, S > 1 ? Call + (int64_t)(S - 2) * B * H : nullptr,
-                   Call + (int64_t)(S - 1) * B * H, dHall + (int64_t)(S - 1) * B * H, H, nullptr, c->dc, B, H,
+                   Call + (int64_t)(S - 1) * B * H, dHall + (int64_t)(S - 1) * B * H, H, nullptr, c->dc, 1, B, H,
                    boff(dZ, (int64_t)(S - 1) * B * ld4H, c->esz), ld4H);
         for (int s = S - 1; s >= 1; --s) {
             hipError_t e = launch_lstm_rec_bwd(c->stream, boff(dZ, (int64_t)s * B * ld4H, c->esz), ld4H, WhT,
@@ -264,7 +263,7 @@ int lstm_layer_bwd(lrcn_ctx *c, int S, int B, int H, int64_t ld4H, const void *a
     }
     for (int s = S - 1; s >= 0; --s) {
         k_lstm_bwd(c->stream, dt, boff(acts, (int64_t)s * B * ld4H, c->esz), ld4H, s ? Call + (int64_t)(s - 1) * B * H : nullptr,
-                   Call + (int64_t)s * B * H, dHall + (int64_t)s * B * H, H, (s < S - 1) ? c->dhrec : nullptr, c->dc, B, H,
+                   Call + (int64_t)s * B * H, dHall + (int64_t)s * B * H, H, (s < S - 1) ? c->dhrec : nullptr, c->dc, s == S - 1, B, H,
                    boff(dZ, (int64_t)s * B * ld4H, c->esz), ld4H);
         if (s > 0)  // dh_prev = dZ[s] * Wh'   (Wh' K-contiguous = WhT [H][ld4H])
             GEMM(c, dt, boff(dZ, (int64_t)s * B * ld4H, c->esz), ld4H, WhT, ld4H, c->dhrec, H, B, H, 4 * H, nullptr, true);
@@ -297,7 +296,7 @@ int loss_impl(lrcn_ctx *c, const float *const p[9], const float *feats, const in
     r = prepare_weights(c, p, bwd);
     if (r) return r;
     if (T > 0) HIPCHK(c, hipMemcpyAsync(c->tok, tokens, sizeof(int32_t) * (size_t)T * B, hipMemcpyDeviceToDevice, st));
-    k_build_tokens(st, c->tok, T, B, V, c->tok_in, c->tok_tgt);
+    k_build_tokens(st, c->tok, T, B, V, c->tok_in, c->tok_tgt, c->logp);
     // feats (B x 4096 column-major = memory [4096][B]) -> F [B][4096] (T)
     k_transpose(st, dt, 1, feats, B, LRCN_CNNOUT, B, c->F, LRCN_CNNOUT, 0);
     // input = input * param[end-3]   lrcn.jl:558
@@ -321,7 +320,6 @@ int loss_impl(lrcn_ctx *c, const float *const p[9], const float *feats, const in
         for (int s = 0; s < S; ++s)
             k_transpose_f32(st, c->Logits + (int64_t)s * B * c->ldV, c->ldV, B, V, logits_out + (int64_t)s * B * V, B);
     }
-    HIPCHK(c, hipMemsetAsync(c->logp, 0, sizeof(double), st));
     const float scale = (float)(1.0 / ((double)norm_B * (double)S));
     k_softmax_xent(st, dt, c->Logits, c->ldV, c->tok_tgt, M, V, scale, c->logp, bwd ? c->dLog : nullptr, c->ldV);
     c->last_norm = norm_B;
@@ -330,9 +328,20 @@ int loss_impl(lrcn_ctx *c, const float *const p[9], const float *feats, const in
     if (!bwd) return LRCN_OK;
 
     const int64_t ldM = ld8(M), ldB = ld8(B);
+    // Transposed operands of the weight-gradient GEMMs (contraction over the M = S*B rows) are materialised K-contiguous,
+    // several per launch; the x- and h-side inputs of one LSTM share one stacked buffer so that dW = dZ' [x | h_prev] is
+    // one GEMM per layer.
+    auto tr = [&](TrPlan &pl, const void *src, int64_t ld_src, int R, int C, void *dst, int shift) {
+        TrDesc &d = pl.d[pl.n++];
+        d.src = src; d.ld_src = ld_src; d.R = R; d.C = C; d.dst = dst; d.ld_dst = ldM; d.shift = shift;
+    };
     // ---- logits layer: dWout, dbout, dH2 ----
-    k_transpose(st, dt, 0, c->dLog, c->ldV, M, V, c->TA, ldM, 0);        // dLog^T [V][ldM]
-    k_transpose(st, dt, 0, c->H2all, c->ldH2, M, H2, c->TB, ldM, 0);     // H2all^T [H2][ldM]
+    {
+        TrPlan pl{};
+        tr(pl, c->dLog, c->ldV, M, V, c->TA, 0);      // dLog^T [V][ldM]
+        tr(pl, c->H2all, c->ldH2, M, H2, c->TB, 0);   // H2all^T [H2][ldM]
+        k_transpose_multi(st, dt, pl);
+    }
     GEMM(c, dt, c->TA, ldM, c->TB, ldM, grads[7], H2, V, H2, M, nullptr, true);
     k_colsum(st, dt, c->dLog, c->ldV, M, V, grads[8]);
     HIPCHK(c, hipEventRecord(c->grad_ev[0], st));  // group 0: Wout, bout
@@ -340,21 +349,25 @@ int loss_impl(lrcn_ctx *c, const float *const p[9], const float *feats, const in
     // ---- LSTM 2 ----
     r = lstm_layer_bwd(c, S, B, H2, c->ld4H2, c->A2, c->C2, c->dH2all, c->W2hT, c->dZ2);
     if (r) return r;
-    k_transpose(st, dt, 0, c->dZ2, c->ld4H2, M, 4 * H2, c->TA, ldM, 0);  // dZ2^T [4H2][ldM]
-    k_transpose(st, dt, 0, c->X2, c->ldH2, M, H2, c->TB, ldM, 0);        // X2^T [2h][ldM]
-    GEMM(c, dt, c->TA, ldM, c->TB, ldM, grads[2], 2 * H2, 4 * H2, H2, M, nullptr, true);
-    if (M > B)
-        k_transpose(st, dt, 0, c->H2all, c->ldH2, M - B, H2, c->TB, ldM, B);  // h2_prev^T (shifted one step)
-    else
-        HIPCHK(c, hipMemsetAsync(c->TB, 0, es * (size_t)H2 * ldM, st));
-    GEMM(c, dt, c->TA, ldM, c->TB, ldM, grads[2] + H2, 2 * H2, 4 * H2, H2, M, nullptr, true);
+    {
+        TrPlan pl{};
+        tr(pl, c->dZ2, c->ld4H2, M, 4 * H2, c->TA, 0);                              // dZ2^T [4H2][ldM]
+        tr(pl, c->X2, c->ldH2, M, H2, c->TB, 0);                                     // X2^T [2h][ldM]
+        tr(pl, c->H2all, c->ldH2, M - B, H2, boff(c->TB, (int64_t)H2 * ldM, es), M > B ? B : 0);  // h2_prev^T (one step later)
+        k_transpose_multi(st, dt, pl);
+    }
+    GEMM(c, dt, c->TA, ldM, c->TB, ldM, grads[2], 2 * H2, 4 * H2, 2 * H2, M, nullptr, true);
     k_colsum(st, dt, c->dZ2, c->ld4H2, M, 4 * H2, grads[3]);
     HIPCHK(c, hipEventRecord(c->grad_ev[1], st));  // group 1: W2, b2
     GEMM(c, dt, c->dZ2, c->ld4H2, c->W2xT, c->ld4H2, c->dX2, c->ldH2, M, H2, 4 * H2, nullptr, false);
     k_dx2_mask_reduce(st, dt, c->dX2, c->ldH2, S, B, h, d2, c->dxcnn, c->ldh);
     // ---- projection and image embedding ----
-    k_transpose(st, dt, 0, c->dX2, c->ldH2, M, h, c->TA, ldM, 0);        // dP^T [h][ldM]
-    k_transpose(st, dt, 0, c->H1all, c->ldH1, M, H1, c->TB, ldM, 0);     // H1all^T [H1][ldM]
+    {
+        TrPlan pl{};
+        tr(pl, c->dX2, c->ldH2, M, h, c->TA, 0);      // dP^T [h][ldM]
+        tr(pl, c->H1all, c->ldH1, M, H1, c->TB, 0);   // H1all^T [H1][ldM]
+        k_transpose_multi(st, dt, pl);
+    }
     GEMM(c, dt, c->TA, ldM, c->TB, ldM, grads[4], H1, h, H1, M, nullptr, true);
     GEMM(c, dt, c->dX2, c->ldH2, c->WpT, c->ldh, c->dH1all, H1, M, H1, h, nullptr, true);
     k_transpose(st, dt, 1, c->dxcnn, c->ldh, B, h, c->dxcT, ldB, 0);     // dxcnn^T [h][ldB]
@@ -364,14 +377,14 @@ int loss_impl(lrcn_ctx *c, const float *const p[9], const float *feats, const in
     // ---- LSTM 1 ----
     r = lstm_layer_bwd(c, S, B, H1, c->ld4H1, c->A1, c->C1, c->dH1all, c->W1hT, c->dZ1);
     if (r) return r;
-    k_transpose(st, dt, 0, c->dZ1, c->ld4H1, M, 4 * H1, c->TA, ldM, 0);
-    k_transpose(st, dt, 0, c->Xemb, c->ldE, M, E, c->TB, ldM, 0);
-    GEMM(c, dt, c->TA, ldM, c->TB, ldM, grads[0], E + H1, 4 * H1, E, M, nullptr, true);
-    if (M > B)
-        k_transpose(st, dt, 0, c->H1all, c->ldH1, M - B, H1, c->TB, ldM, B);
-    else
-        HIPCHK(c, hipMemsetAsync(c->TB, 0, es * (size_t)H1 * ldM, st));
-    GEMM(c, dt, c->TA, ldM, c->TB, ldM, grads[0] + E, E + H1, 4 * H1, H1, M, nullptr, true);
+    {
+        TrPlan pl{};
+        tr(pl, c->dZ1, c->ld4H1, M, 4 * H1, c->TA, 0);
+        tr(pl, c->Xemb, c->ldE, M, E, c->TB, 0);
+        tr(pl, c->H1all, c->ldH1, M - B, H1, boff(c->TB, (int64_t)E * ldM, es), M > B ? B : 0);
+        k_transpose_multi(st, dt, pl);
+    }
+    GEMM(c, dt, c->TA, ldM, c->TB, ldM, grads[0], E + H1, 4 * H1, E + H1, M, nullptr, true);
     k_colsum(st, dt, c->dZ1, c->ld4H1, M, 4 * H1, grads[1]);
     HIPCHK(c, hipEventRecord(c->grad_ev[3], st));  // group 3: W1, b1
     GEMM(c, dt, c->dZ1, c->ld4H1, c->W1xT, c->ld4H1, c->dXemb, c->ldE, M, E, 4 * H1, nullptr, true);
@@ -519,7 +532,7 @@ int lrcn_create(const lrcn_config *cfg, lrcn_ctx **out) {
         DALLOC(c, c->dhrec, sizeof(float) * B * Hm); DALLOC(c, c->dc, sizeof(float) * B * Hm);
         DALLOC(c, c->dxcnn, sizeof(float) * B * c->ldh); DALLOC(c, c->dxcT, es * h * c->ldB);
         int64_t ra = 4 * Hm; if (V > ra) ra = V;
-        int64_t rb = Hm; if (E > rb) rb = E;
+        int64_t rb = 2 * H2; if (E + H1 > rb) rb = E + H1;  // stacked [x | h_prev]^T of one LSTM
         DALLOC(c, c->TA, es * ra * c->ldM);        DALLOC(c, c->TB, es * rb * c->ldM);
         DALLOC(c, c->logp, sizeof(double) * 2);
         DALLOC(c, c->zero_page, 256);
