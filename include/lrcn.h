@@ -43,7 +43,7 @@ extern "C" {
 #define LRCN_MAX_T 28 /* captions longer than 28 tokens are skipped by the reference, lrcn.jl:353, 438 */
 
 enum { LRCN_OK = 0, LRCN_EINVAL = -1, LRCN_ENOMEM = -2, LRCN_EHIP = -3, LRCN_ESTATE = -4 };
-enum { LRCN_F32 = 0, LRCN_BF16 = 1 };
+enum { LRCN_F32 = 0, LRCN_BF16 = 1, LRCN_FP8 = 2 }; /* LRCN_FP8: vgg_dtype only (BASELINE config 5) */
 
 typedef struct lrcn_ctx lrcn_ctx;
 
@@ -54,7 +54,7 @@ typedef struct {
     int max_B;      /* largest per-call batch (rows on this device) */
     int max_T;      /* largest caption length T (<= LRCN_MAX_T); the loop runs T+1 steps */
     int lstm_dtype; /* LRCN_F32 | LRCN_BF16 */
-    int vgg_dtype;  /* LRCN_F32 | LRCN_BF16 */
+    int vgg_dtype;  /* LRCN_F32 | LRCN_BF16 | LRCN_FP8 (conv2_2..conv5_3 in OCP e4m3 after lrcn_vgg_calibrate; the rest bf16) */
     int max_images; /* VGG batch capacity; 0 = no VGG in this context */
 } lrcn_config;
 
@@ -162,6 +162,21 @@ int lrcn_vgg_forward_u8(lrcn_ctx *ctx, const uint8_t *img, int N, const float me
  * x (W,H,Cin,N) -> y (W,H,Cout,N) [or (W/2,H/2,Cout,N) with pool]; Cin, Cout multiples of 32. */
 int lrcn_conv3x3(lrcn_ctx *ctx, const float *x, int W, int H, int Cin, int N, const float *w, const float *b,
                  int Cout, int relu, int pool, float *y);
+
+/* ---- fp8 convolution stack (BASELINE config 5; the reference has no reduced-precision path, lrcn.jl:724-728 is Float32) ----
+ * vgg_dtype = LRCN_FP8: conv2_2 .. conv5_3 (Cin % 128 == 0, 79 % of the VGG FLOPs) run as v_mfma_f32_16x16x128_f8f6f4 on
+ * OCP e4m3 operands: weights e4m3(w / sw[co]) with sw[co] = amax_co / 448, activations e4m3(x / sa) with one sa per layer,
+ * f32 accumulation, epilogue e4m3(relu(acc * sa_in sw[co] / sa_out + b[co] / sa_out)) (+ fused 2x2 max-pool).  conv1_1,
+ * conv1_2, conv2_1, fc6 and fc7 stay bf16.
+ * lrcn_vgg_calibrate runs `img` (decoded uint8 crops, as lrcn_vgg_forward_u8) through the bf16 stack once, records every
+ * layer's output amax and sets sa = margin * amax / 448 (margin in [1,16]; values above saturate at 448 sa).  It must be
+ * called before the first forward (LRCN_ESTATE otherwise) and may be called again to recalibrate. */
+int lrcn_vgg_calibrate(lrcn_ctx *ctx, const uint8_t *img, int N, const float mean[3], float margin);
+/* Parity probe of one e4m3 layer, reference layouts as lrcn_conv3x3: x is quantised with sa_in, w per output channel, the
+ * result is returned dequantised (e4m3 * sa_out).  Cin % 128 == 0, Cout >= 128 and % 16 == 0, N*W*H >= 256.
+ * sw_out (device float[Cout], may be NULL) receives the weight scales so a caller can emulate the arithmetic exactly. */
+int lrcn_conv3x3_fp8(lrcn_ctx *ctx, const float *x, int W, int H, int Cin, int N, const float *w, const float *b, int Cout,
+                     int relu, int pool, float sa_in, float sa_out, float *y, float *sw_out);
 
 /* ---- measurement (bench.py "roofline") ----
  * While enabled, every VGG forward brackets its 12 implicit-GEMM convolution launches (conv1_2..conv5_3: one kernel,

@@ -5,4 +5,4 @@ Python identifier.  Layout: csrc/ = HIP kernels + the C ABI (liblrcn_hip.so); _l
 lrcn.py = mirror of lrcn.jl's functions; dp.py = data-parallel step over torch.distributed (RCCL).
 """
 from . import _lib  # noqa: F401
-from ._lib import BOS, CNNOUT, EOS, LRCN_BF16, LRCN_F32, UNK, LrcnError, build  # noqa: F401
+from ._lib import BOS, CNNOUT, EOS, LRCN_BF16, LRCN_F32, LRCN_FP8, UNK, LrcnError, build  # noqa: F401

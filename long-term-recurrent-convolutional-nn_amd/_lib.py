@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.environ.get("LRCN_HIP_LIB") or os.path.join(CSRC, "liblrcn_hip.so")  # override: A/B builds of the kernels in one session
 HEADER = os.path.normpath(os.path.join(HERE, "..", "include", "lrcn.h"))
 
-LRCN_F32, LRCN_BF16 = 0, 1
+LRCN_F32, LRCN_BF16, LRCN_FP8 = 0, 1, 2
 EOS, BOS, UNK = 0, 1, 2
 CNNOUT = 4096
 MAX_T = 28
@@ -78,6 +78,9 @@ SIGNATURES = {
     "lrcn_bench_gemm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "lrcn_conv3x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "lrcn_vgg_calibrate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_float]),
+    "lrcn_conv3x3_fp8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                   C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
 }
 
 

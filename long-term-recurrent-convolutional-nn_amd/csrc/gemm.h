@@ -6,7 +6,7 @@
 
 enum { GEMM_A_PLAIN = 0, GEMM_A_CONV3 = 1 };
 enum { GEMM_OUT_PLAIN = 0, GEMM_OUT_CONV = 1, GEMM_OUT_POOL = 2 };
-enum { GEMM_T_F32 = 0, GEMM_T_BF16 = 1 };
+enum { GEMM_T_F32 = 0, GEMM_T_BF16 = 1, GEMM_T_F8 = 2 };  // F8: OCP e4m3 A, B and C (gemm_8p.hip CONV3 only)
 
 struct GemmArgs {
     int dtype;      // GEMM_T_*: element type of A and B
@@ -18,6 +18,7 @@ struct GemmArgs {
     int64_t ldc;
     int M, N, K;    // CONV3: M = n*H*W output pixels (window-major order), K = 9*Cin
     const float *bias;  // per output column, or NULL
+    const float *scale; // GEMM_T_F8: per-output-column multiplier applied to the accumulator before the bias (dequant x requant)
     int c_f32;
     int beta;       // 1: C += result (reads C)
     int relu;

@@ -279,6 +279,12 @@ hipError_t launch_gemm(hipStream_t stream, const GemmArgs &g) {
     return e;
 }
 static hipError_t launch_gemm_routed(hipStream_t stream, const GemmArgs &g, const char **route) {
+    if (g.dtype == GEMM_T_F8) {  // e4m3: the phase-interleaved convolution kernel or nothing
+        int64_t blocks = 0;
+        if (g.M <= 0 || !g.A || !g.B || !g.C || gemm_8p_config(g, &blocks) < 0) return hipErrorInvalidValue;
+        *route = "8p-f8";
+        return launch_gemm_8p(stream, g);
+    }
     if (g.M <= 0 || g.N <= 0 || g.K <= 0 || !g.A || !g.B || !g.C) return hipErrorInvalidValue;
     // LRCN_GLDS=0 disables the direct-to-LDS path, LRCN_GLDS=force uses it whenever eligible (tests); default: when
     // the grid fills the chip.

@@ -50,8 +50,29 @@ template <int OFF> __device__ __forceinline__ uint4 lds_read16(unsigned addr) {
     return r;
 }
 
-template <int WM, int WN, int MT, int NT, int AMODE, bool SWAP>
+typedef int i32x8v __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ i32x8v pack8(const uint4 &lo, const uint4 &hi) {
+    return i32x8v{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+}
+// four f32 -> four OCP e4m3 bytes (round to nearest even, saturating at +-448)
+__device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float d) {
+    a = fminf(fmaxf(a, -448.f), 448.f); b = fminf(fmaxf(b, -448.f), 448.f);
+    c = fminf(fmaxf(c, -448.f), 448.f); d = fminf(fmaxf(d, -448.f), 448.f);
+    unsigned w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    return w;
+}
+
+// F8: A and B are OCP e4m3 bytes, a K-tile is 128 elements (the same 128-byte LDS rows), one
+// v_mfma_f32_16x16x128_f8f6f4 replaces two v_mfma_f32_16x16x32_bf16 (same cycles, twice the K), the staged epilogue
+// multiplies by g.scale[col] before the bias and writes e4m3.
+template <int WM, int WN, int MT, int NT, int AMODE, bool SWAP, bool F8>
 __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs g) {
+    using elem_t = std::conditional_t<F8, unsigned char, bf16_t>;
+    constexpr int ES = F8 ? 1 : 2;       // bytes per element
+    constexpr int KE = 128 / ES;         // elements per K-tile
+    constexpr int CE = 16 / ES;          // elements per 16-byte chunk
     static_assert(WM * WN == 8, "8 waves");
     constexpr int QM = MT * 16, QN = NT * 16;   // quadrant = QM x QN of a wave's (2 QM) x (2 QN) output tile
     constexpr int WTM = 2 * QM, WTN = 2 * QN;
@@ -77,11 +98,11 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs g) {
     const int nt = bid % tiles_n, mt = bid / tiles_n;
     const int m0 = mt * BM, n0 = nt * BN;
 
-    const bf16_t *Ab = reinterpret_cast<const bf16_t *>(g.A);
-    const bf16_t *Bb = reinterpret_cast<const bf16_t *>(g.B);
-    const bf16_t *Zp = reinterpret_cast<const bf16_t *>(g.zero_page) + (lane & 7) * 8;
+    const elem_t *Ab = reinterpret_cast<const elem_t *>(g.A);
+    const elem_t *Bb = reinterpret_cast<const elem_t *>(g.B);
+    const elem_t *Zp = reinterpret_cast<const elem_t *>(g.zero_page) + (lane & 7) * CE;
 
-    const int kpt = (AMODE == GEMM_A_CONV3) ? g.Cin / 64 : g.K / 64;
+    const int kpt = (AMODE == GEMM_A_CONV3) ? g.Cin / KE : g.K / KE;
     const int KT_all = (AMODE == GEMM_A_CONV3) ? 9 * kpt : kpt;
     const int kbeg = (int)((int64_t)KT_all * blockIdx.y / gridDim.y);
     const int KT = (int)((int64_t)KT_all * (blockIdx.y + 1) / gridDim.y) - kbeg;
@@ -111,7 +132,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs g) {
             if (m < M) {
                 if (AMODE == GEMM_A_CONV3) {
                     const PixDecode p = decode_pixel(m, g.H, g.W);
-                    a_off[hf][j] = ((p.n * g.H + p.y) * g.W + p.x) * g.Cin + src_chunk * 8;
+                    a_off[hf][j] = ((p.n * g.H + p.y) * g.W + p.x) * g.Cin + src_chunk * CE;
                     unsigned mk = 0;
 #pragma unroll
                     for (int t = 0; t < 9; ++t) {
@@ -120,7 +141,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs g) {
                     }
                     a_mask[hf][j] = mk;
                 } else {
-                    a_off[hf][j] = m * (int)g.lda + src_chunk * 8;
+                    a_off[hf][j] = m * (int)g.lda + src_chunk * CE;
                     a_mask[hf][j] = 1;
                 }
             }
@@ -131,7 +152,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs g) {
             const int n = n0 + row;
             const int src_chunk = (lane & 7) ^ ((row >> 1) & 7);
             b_ok[hf][j] = n < N;
-            b_off[hf][j] = b_ok[hf][j] ? n * (int)g.ldb + src_chunk * 8 : 0;
+            b_off[hf][j] = b_ok[hf][j] ? n * (int)g.ldb + src_chunk * CE : 0;
         }
     }
 
@@ -141,11 +162,11 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs g) {
             const int slice = kt / 9;
             k.tap = kt - 9 * slice;
             const int kh = k.tap / 3, kw = k.tap - 3 * kh;
-            k.koff = ((kh - 1) * g.W + (kw - 1)) * g.Cin + slice * 64;
-            k.kb = k.tap * g.Cin + slice * 64;
+            k.koff = ((kh - 1) * g.W + (kw - 1)) * g.Cin + slice * KE;
+            k.kb = k.tap * g.Cin + slice * KE;
         } else {
             k.tap = 0;
-            k.koff = kt * 64;
+            k.koff = kt * KE;
             k.kb = k.koff;
         }
         return k;
@@ -155,24 +176,26 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < APW; ++j) {
             const bool ok = (a_mask[hf][j] & tapbit) != 0;
-            const bf16_t *src = ok ? Ab + (a_off[hf][j] + k.koff) : Zp;
+            const elem_t *src = ok ? Ab + (a_off[hf][j] + k.koff) : Zp;
             __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(smem + buf * BUF + a_piece_row(hf, j) * 128), 16, 0, 0);
         }
     };
     auto stage_b = [&](int buf, int hf, const KStep &k, bool live) {
 #pragma unroll
         for (int j = 0; j < BPW; ++j) {
-            const bf16_t *src = (b_ok[hf][j] & live) ? Bb + (b_off[hf][j] + k.kb) : Zp;
+            const elem_t *src = (b_ok[hf][j] & live) ? Bb + (b_off[hf][j] + k.kb) : Zp;
             __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(smem + buf * BUF + A_BYTES + b_piece_row(hf, j) * 128), 16, 0,
                                              0);
         }
     };
 
-    // fragment read offsets (16x16x32 operand: lane -> row lane&15, 16-byte K chunk 4s + (lane>>4), swizzled)
+    // fragment read offsets (16x16x32 operand: lane -> row lane&15, 16-byte K chunk 4s + (lane>>4), swizzled;
+    // 16x16x128 fp8 operand: 32 consecutive K bytes per lane = chunks 2(lane>>4) + s)
     unsigned fa[2], fb[2];  // per-lane LDS byte addresses (buffer 0) of the wave's first A / B fragment, K half s
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        const unsigned fo = (lane & 15) * 128 + (((s * 4 + (lane >> 4)) ^ (((lane & 15) >> 1) & 7)) << 4);
+        const int kch = F8 ? 2 * (lane >> 4) + s : s * 4 + (lane >> 4);
+        const unsigned fo = (lane & 15) * 128 + ((kch ^ (((lane & 15) >> 1) & 7)) << 4);
         const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
         fa[s] = base + (wr * WTM) * 128 + fo;
         fb[s] = base + A_BYTES + (wc * WTN) * 128 + fo;
@@ -215,12 +238,21 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs g) {
         wait_lgkm0();                                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                                 \
         __builtin_amdgcn_s_setprio(1);                                                                                     \
-        _Pragma("unroll") for (int s = 0; s < 2; ++s) _Pragma("unroll") for (int i = 0; i < MT; ++i) _Pragma("unroll") for (int n = 0; \
+        if constexpr (F8) {                                                                                                \
+            _Pragma("unroll") for (int i = 0; i < MT; ++i) _Pragma("unroll") for (int n = 0; n < NT; ++n) {                \
+                const i32x8v av = pack8(af[i][0], af[i][1]);                                                               \
+                const i32x8v bv = pack8(BF[n][0], BF[n][1]);                                                               \
+                acc[mh][i][nh][n] = SWAP ? __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bv, av, acc[mh][i][nh][n], 0, 0, 0, 0, 0, 0) \
+                                         : __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bv, acc[mh][i][nh][n], 0, 0, 0, 0, 0, 0); \
+            }                                                                                                              \
+        } else {                                                                                                           \
+            _Pragma("unroll") for (int s = 0; s < 2; ++s) _Pragma("unroll") for (int i = 0; i < MT; ++i) _Pragma("unroll") for (int n = 0; \
                                                                                                                    n < NT; ++n) { \
-            const bf16x8 av = __builtin_bit_cast(bf16x8, af[i][s]);                                                        \
-            const bf16x8 bv = __builtin_bit_cast(bf16x8, BF[n][s]);                                                        \
-            acc[mh][i][nh][n] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(bv, av, acc[mh][i][nh][n], 0, 0, 0)         \
-                                     : __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[mh][i][nh][n], 0, 0, 0);        \
+                const bf16x8 av = __builtin_bit_cast(bf16x8, af[i][s]);                                                    \
+                const bf16x8 bv = __builtin_bit_cast(bf16x8, BF[n][s]);                                                    \
+                acc[mh][i][nh][n] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(bv, av, acc[mh][i][nh][n], 0, 0, 0)     \
+                                         : __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[mh][i][nh][n], 0, 0, 0);    \
+            }                                                                                                              \
         }                                                                                                                  \
         __builtin_amdgcn_s_setprio(0);                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                                 \
@@ -272,6 +304,84 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs g) {
 
     // ---------------------------------------------------------------- epilogue A: bf16 tile staged through LDS
     const int l15 = lane & 15, lq = lane >> 4;
+    if constexpr (F8) {
+        // e4m3 tile staged through LDS: BN bytes per row, 16-byte chunk c of row r at chunk c ^ swz(r) (two 128-byte rows
+        // share a 256-byte bank line when BN = 128).  Launch-side checks guarantee N % 16 == 0, ldc % 16 == 0, no beta/f32.
+        constexpr int CSTR = BN, CPR8 = BN / 16, RPL = 256 / BN > 1 ? 256 / BN : 1;
+        auto swz = [](int r) { return (r / RPL) & (CPR8 - 1); };
+        if (!SWAP) {
+#pragma unroll
+            for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) {
+                            const int lcol = wc * WTN + nh * QN + n * 16 + l15;
+                            const int col = n0 + lcol;
+                            const float sc = (g.scale && col < N) ? g.scale[col] : 1.0f;
+                            const float bias = (g.bias && col < N) ? g.bias[col] : 0.0f;
+                            const f32x4v a = acc[mh][i][nh][n];
+                            float v = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])) * sc + bias;  // sc > 0: max commutes
+                            if (g.relu) v = fmaxf(v, 0.0f);
+                            const int prow = (wr * WTM + mh * QM + i * 16) / 4 + lq;
+                            const int pos = ((lcol >> 4) ^ swz(prow)) * 16 + (lcol & 15);
+                            smem[prow * CSTR + pos] = (unsigned char)(pack_fp8x4(v, v, 0.f, 0.f) & 0xFF);
+                        }
+        } else {
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const int lcol = wc * WTN + nh * QN + n * 16 + lq * 4;
+                    const int col = n0 + lcol;
+                    f32x4v bias = f32x4v{0.f, 0.f, 0.f, 0.f}, sc = f32x4v{1.f, 1.f, 1.f, 1.f};
+                    if (g.bias && col < N) bias = *reinterpret_cast<const f32x4v *>(g.bias + col);
+                    if (g.scale && col < N) sc = *reinterpret_cast<const f32x4v *>(g.scale + col);
+#pragma unroll
+                    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                        for (int i = 0; i < MT; ++i) {
+                            f32x4v a = acc[mh][i][nh][n] * sc + bias;
+                            if (g.relu) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) a[r] = fmaxf(a[r], 0.0f);
+                            }
+                            const int lrow = wr * WTM + mh * QM + i * 16 + l15;
+                            const int pos = ((lcol >> 4) ^ swz(lrow)) * 16 + (lcol & 15);
+                            *reinterpret_cast<unsigned *>(smem + lrow * CSTR + pos) = pack_fp8x4(a[0], a[1], a[2], a[3]);
+                        }
+                }
+        }
+        __syncthreads();
+        const int rows_out = SWAP ? BM : BM / 4;
+        unsigned char *C8 = reinterpret_cast<unsigned char *>(g.C);
+        for (int idx = tid; idx < rows_out * CPR8; idx += 512) {
+            const int lrow = idx / CPR8, ch = idx - lrow * CPR8;
+            const int col = n0 + ch * 16;
+            if (col >= N) continue;
+            int64_t off;
+            if (!SWAP) {
+                const int prow = (m0 >> 2) + lrow;
+                if (prow >= (M >> 2)) continue;
+                off = (int64_t)prow * g.ldc + col;
+            } else {
+                const int row = m0 + lrow;
+                if (row >= M) continue;
+                if (g.out_mode == GEMM_OUT_CONV) {
+                    const PixDecode p = decode_pixel(row, g.H, g.W);
+                    off = (((int64_t)p.n * g.H + p.y) * g.W + p.x) * g.ldc + col;
+                } else {
+                    off = (int64_t)row * g.ldc + col;
+                }
+            }
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(*reinterpret_cast<const u32x4 *>(smem + lrow * CSTR + ((ch ^ swz(lrow)) << 4)),
+                                        reinterpret_cast<u32x4 *>(C8 + off));
+        }
+        return;
+    }
     const bool staged = !g.c_f32 && !g.beta && gridDim.y == 1 && (g.ldc % 8) == 0 && ((uintptr_t)g.C & 15) == 0 &&
                         (N % 8) == 0 && (!SWAP || (N % 4) == 0);
     if (staged) {
@@ -436,13 +546,13 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs g) {
                 }
 }
 
-template <int WM, int WN, int MT, int NT, int AMODE, bool SWAP> hipError_t launch_one(hipStream_t s, const GemmArgs &g, int splitk) {
+template <int WM, int WN, int MT, int NT, int AMODE, bool SWAP, bool F8 = false> hipError_t launch_one(hipStream_t s, const GemmArgs &g, int splitk) {
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
     constexpr int ring = 2 * (BM + BN) * 128, ctile = BM * BN * 2;
     constexpr int lds = ring > ctile ? ring : ctile;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_done = false;
-    auto kern = gemm8p_kernel<WM, WN, MT, NT, AMODE, SWAP>;
+    auto kern = gemm8p_kernel<WM, WN, MT, NT, AMODE, SWAP, F8>;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
@@ -454,11 +564,11 @@ template <int WM, int WN, int MT, int NT, int AMODE, bool SWAP> hipError_t launc
     return hipGetLastError();
 }
 
-template <int AMODE, bool SWAP> hipError_t dispatch(hipStream_t s, const GemmArgs &g, int cfg, int splitk) {
+template <int AMODE, bool SWAP, bool F8 = false> hipError_t dispatch(hipStream_t s, const GemmArgs &g, int cfg, int splitk) {
     switch (cfg) {
-        case 0: return launch_one<2, 4, 4, 2, AMODE, SWAP>(s, g, splitk);  // 256 x 256
-        case 1: return launch_one<4, 2, 2, 2, AMODE, SWAP>(s, g, splitk);  // 256 x 128
-        case 2: return launch_one<4, 2, 4, 2, AMODE, SWAP>(s, g, splitk);  // 512 x 128 (all 160 KiB of LDS)
+        case 0: return launch_one<2, 4, 4, 2, AMODE, SWAP, F8>(s, g, splitk);  // 256 x 256
+        case 1: return launch_one<4, 2, 2, 2, AMODE, SWAP, F8>(s, g, splitk);  // 256 x 128
+        case 2: return launch_one<4, 2, 4, 2, AMODE, SWAP, F8>(s, g, splitk);  // 512 x 128 (all 160 KiB of LDS)
         default: return hipErrorInvalidValue;
     }
 }
@@ -466,9 +576,24 @@ template <int AMODE, bool SWAP> hipError_t dispatch(hipStream_t s, const GemmArg
 }  // namespace
 
 // Tile menu of the phase-interleaved path: 256 x 256 when that gives the chip >= 200 workgroups or N > 128, else 256 x 128.
+static bool gemm_8p_f8_ok(const GemmArgs &g) {  // e4m3 3x3 convolution with an e4m3 NHWC (optionally 2x2-pooled) output
+    if (g.dtype != GEMM_T_F8 || !g.zero_page || g.a_mode != GEMM_A_CONV3 || g.out_mode == GEMM_OUT_PLAIN) return false;
+    if (((uintptr_t)g.A & 15) || ((uintptr_t)g.B & 15) || ((uintptr_t)g.C & 15) || (g.ldb % 16) || (g.ldc % 16) || (g.N % 16)) return false;
+    if (g.Cin % 128 || g.K != 9 * g.Cin || (g.H & 1) || (g.W & 1) || g.H <= 0 || g.W <= 0 || g.M % (g.H * g.W)) return false;
+    if ((int64_t)g.M * g.Cin >= (1ll << 31) || (int64_t)g.N * g.ldb >= (1ll << 31)) return false;
+    if (g.c_f32 || g.beta || (g.out_mode == GEMM_OUT_POOL && (g.M & 3))) return false;
+    return true;
+}
+
 int gemm_8p_config(const GemmArgs &g, int64_t *blocks) {
-    if (!gemm_glds_eligible(g) || g.M < 256 || g.N < 128) return -1;
-    const int kt = (g.a_mode == GEMM_A_CONV3) ? 9 * (g.Cin / 64) : g.K / 64;
+    if (g.dtype == GEMM_T_F8) {
+        if (!gemm_8p_f8_ok(g)) return -1;
+    } else if (!gemm_glds_eligible(g)) {
+        return -1;
+    }
+    if ((g.M < 256 && g.dtype != GEMM_T_F8) || g.N < 128) return -1;  // e4m3 has no other kernel: M tails are masked rows
+    const int ke = g.dtype == GEMM_T_F8 ? 128 : 64;
+    const int kt = (g.a_mode == GEMM_A_CONV3) ? 9 * (g.Cin / ke) : g.K / ke;
     if (kt < 2) return -1;
     const int64_t b0 = (int64_t)cdiv(g.M, 256) * cdiv(g.N, 256), b1 = (int64_t)cdiv(g.M, 256) * cdiv(g.N, 128);
     int cfg = (g.N > 128 && (b0 >= 200 || g.N % 256 == 0 || g.N > 384)) ? 0 : 1;
@@ -488,7 +613,7 @@ int gemm_8p_config(const GemmArgs &g, int64_t *blocks) {
 // / ReLU / output type.  (f32 atomics instead of slabs were 8x slower here: 16 scattered rows per wave instruction.)
 // Returns the number of slices (0 = not applicable).
 int gemm_8p_splitk(const GemmArgs &g, int64_t *blocks) {
-    if (!gemm_glds_eligible(g) || g.M < 256 || g.N < 128 || (g.N % 4) || g.a_mode != GEMM_A_PLAIN || g.out_mode != GEMM_OUT_PLAIN) return 0;
+    if (g.dtype != GEMM_T_BF16 || !gemm_glds_eligible(g) || g.M < 256 || g.N < 128 || (g.N % 4) || g.a_mode != GEMM_A_PLAIN || g.out_mode != GEMM_OUT_PLAIN) return 0;
     if (!g.ws || (g.ldc % 4) || ((uintptr_t)g.C & 15)) return 0;
     const int kt = g.K / 64;
     const int64_t b1 = (int64_t)cdiv(g.M, 256) * cdiv(g.N, 128);
@@ -551,6 +676,8 @@ hipError_t launch_gemm_8p(hipStream_t stream, const GemmArgs &g, int splitk) {
         splitk = 1;
     }
     const bool swap = g.out_mode != GEMM_OUT_POOL;
+    if (g.dtype == GEMM_T_F8)
+        return swap ? dispatch<GEMM_A_CONV3, true, true>(stream, g, cfg, 1) : dispatch<GEMM_A_CONV3, false, true>(stream, g, cfg, 1);
     if (g.a_mode == GEMM_A_CONV3)
         return swap ? dispatch<GEMM_A_CONV3, true>(stream, g, cfg, splitk) : dispatch<GEMM_A_CONV3, false>(stream, g, cfg, splitk);
     return swap ? dispatch<GEMM_A_PLAIN, true>(stream, g, cfg, splitk) : dispatch<GEMM_A_PLAIN, false>(stream, g, cfg, splitk);

@@ -153,3 +153,12 @@ void k_mul_f32(hipStream_t st, const float *a, const float *b, int64_t n, float 
 // w [64][32] bf16 (k = tap*3+c), out NHWC bf16 [n][y][x][64] with bias + ReLU.
 void k_conv11_fused(hipStream_t st, int src_is_u8, const void *src, int N, int S, float m0, float m1, float m2, const void *w,
                     const float *bias, void *out);
+
+// ---- fp8.hip: OCP e4m3 plumbing of the VGG convolution stack ----
+void k_quant_conv_w_fp8(hipStream_t st, const float *w, int Cin, int Cout, void *out, float *sw);
+void k_amax(hipStream_t st, int in_f32, const void *x, int64_t n, float *out);  // atomic max of |x| into *out (caller zeroes)
+void k_cast_bf16_fp8(hipStream_t st, const void *x, int64_t n, float inv_scale, void *out);  // n % 8 == 0
+void k_cast_fp8_bf16(hipStream_t st, const void *x, int64_t n, float scale, void *out);
+void k_fp8_epilogue_params(hipStream_t st, const float *b, const float *sw, int Cout, float sa_in, float sa_out, float *escale, float *ebias);
+void k_ref_to_nhwc_fp8(hipStream_t st, const float *x, int W, int H, int C, int N, float inv_scale, void *out);
+void k_nhwc_fp8_to_ref(hipStream_t st, const void *in, int W, int H, int C, int N, float scale, float *out);

@@ -33,7 +33,11 @@ struct VggLayer {
     void *w_fused = nullptr;  // conv1_1 only (bf16): [64][32] in the K order of the fused conv1_1+conv1_2 kernel
     float *b = nullptr;   // [Cout] f32
     int Cin = 0, Cout = 0, S = 0, pool = 0;
+    // LRCN_FP8 (layers conv2_2 .. conv5_3): e4m3 weights [Cout][9*Cin], per-channel weight scale, effective epilogue scale/bias
+    void *w8 = nullptr;
+    float *sw = nullptr, *escale = nullptr, *ebias = nullptr;
 };
+constexpr int kFp8First = 3;  // conv2_2: the first layer with Cin % 128 == 0
 
 struct lrcn_ctx {
     lrcn_config cfg{};
@@ -77,6 +81,9 @@ struct lrcn_ctx {
     float *bs_p = nullptr, *bs_res_p = nullptr;
     // VGG
     bool vgg_loaded = false;
+    bool vgg_fp8 = false, fp8_ready = false;  // LRCN_FP8: conv2_2..conv5_3 in e4m3 once lrcn_vgg_calibrate has run
+    float *amax_dev = nullptr;                // [13] per-layer output amax collected by the calibration pass
+    float act_scale[13] = {};                 // sa of layer l's output (l = 2..12)
     VggLayer conv[13];
     void *fc6w = nullptr, *fc7w = nullptr;
     float *fc6b = nullptr, *fc7b = nullptr;
@@ -478,8 +485,8 @@ int lrcn_create(const lrcn_config *cfg, lrcn_ctx **out) {
     int64_t sz[9];
     if (lrcn_param_sizes(cfg->E, cfg->H1, cfg->H2, cfg->V, sz) != LRCN_OK || cfg->max_B < 1 || cfg->max_T < 0 ||
         cfg->max_T > LRCN_MAX_T || (cfg->lstm_dtype != LRCN_F32 && cfg->lstm_dtype != LRCN_BF16) ||
-        (cfg->vgg_dtype != LRCN_F32 && cfg->vgg_dtype != LRCN_BF16) || cfg->max_images < 0) {
-        g_create_err = "invalid lrcn_config (need E,H1>=1, even H2>=2, V>=3, max_B>=1, 0<=max_T<=28, dtype in {F32,BF16})";
+        (cfg->vgg_dtype != LRCN_F32 && cfg->vgg_dtype != LRCN_BF16 && cfg->vgg_dtype != LRCN_FP8) || cfg->max_images < 0) {
+        g_create_err = "invalid lrcn_config (need E,H1>=1, even H2>=2, V>=3, max_B>=1, 0<=max_T<=28, lstm_dtype in {F32,BF16}, vgg_dtype in {F32,BF16,FP8})";
         return LRCN_EINVAL;
     }
     int ndev = 0;
@@ -494,7 +501,8 @@ int lrcn_create(const lrcn_config *cfg, lrcn_ctx **out) {
     lrcn_ctx *c = new lrcn_ctx();
     c->cfg = *cfg;
     c->dt = cfg->lstm_dtype == LRCN_BF16 ? GEMM_T_BF16 : GEMM_T_F32;
-    c->vdt = cfg->vgg_dtype == LRCN_BF16 ? GEMM_T_BF16 : GEMM_T_F32;
+    c->vdt = cfg->vgg_dtype == LRCN_F32 ? GEMM_T_F32 : GEMM_T_BF16;  // LRCN_FP8: bf16 everywhere outside conv2_2..conv5_3
+    c->vgg_fp8 = cfg->vgg_dtype == LRCN_FP8;
     c->esz = c->dt == GEMM_T_BF16 ? 2 : 4;
     c->vesz = c->vdt == GEMM_T_BF16 ? 2 : 4;
     c->E = cfg->E; c->H1 = cfg->H1; c->H2 = cfg->H2; c->h = cfg->H2 / 2; c->V = cfg->V;
@@ -569,6 +577,7 @@ int lrcn_create(const lrcn_config *cfg, lrcn_ctx **out) {
             DALLOC(c, c->actB, ve * N * 112 * 112 * 128);  // largest tensor ever written to the second buffer (pool1 out = N*112*112*64; conv2_1 out = N*112*112*128)
             DALLOC(c, c->f6, ve * N * 4096);
             DALLOC(c, c->featsRM, sizeof(float) * N * 4096);
+            if (c->vgg_fp8) DALLOC(c, c->amax_dev, sizeof(float) * 16);
         }
         return LRCN_OK;
     }();
@@ -915,6 +924,13 @@ int lrcn_vgg_load(lrcn_ctx *c, const float *const cw[13], const float *const cb[
         } else {
             DALLOC(c, L.w, ve * (size_t)L.Cout * 9 * Cin);
             k_repack_conv_w(st, vdt, cw[l], Cin, L.Cout, Cin, L.w);
+            if (c->vgg_fp8 && l >= kFp8First) {
+                DALLOC(c, L.w8, (size_t)L.Cout * 9 * Cin);
+                DALLOC(c, L.sw, sizeof(float) * L.Cout);
+                DALLOC(c, L.escale, sizeof(float) * L.Cout);
+                DALLOC(c, L.ebias, sizeof(float) * L.Cout);
+                k_quant_conv_w_fp8(st, cw[l], Cin, L.Cout, L.w8, L.sw);
+            }
         }
         Cin = L.Cout;
         if (L.pool) S /= 2;
@@ -968,8 +984,36 @@ int conv_layer(lrcn_ctx *c, int dtype, const void *in, const VggLayer &L, int N,
     return LRCN_OK;
 }
 
+// e4m3 in -> e4m3 out (lrcn.jl:724-728 conv4 .+ b, relu, pool at reduced precision; scales from lrcn_vgg_calibrate)
+int conv_layer_fp8(lrcn_ctx *c, const void *in, const VggLayer &L, int N, void *out) {
+    GemmArgs g{};
+    g.dtype = GEMM_T_F8;
+    g.A = in;
+    g.B = L.w8;
+    g.ldb = 9 * L.Cin;
+    g.C = out;
+    g.ldc = L.Cout;
+    g.M = N * L.S * L.S;
+    g.N = L.Cout;
+    g.K = 9 * L.Cin;
+    g.bias = L.ebias;
+    g.scale = L.escale;
+    g.relu = 1;
+    g.a_mode = GEMM_A_CONV3;
+    g.out_mode = L.pool ? GEMM_OUT_POOL : GEMM_OUT_CONV;
+    g.H = g.W = L.S;
+    g.Cin = L.Cin;
+    g.zero_page = c->zero_page;
+    hipError_t e = launch_gemm(c->stream, g);
+    if (e != hipSuccess) FAIL(c, LRCN_EHIP, "fp8 conv layer S=%d Cin=%d Cout=%d: %s", L.S, L.Cin, L.Cout, hipGetErrorString(e));
+    return LRCN_OK;
+}
+
 // source image (uint8 crops or the preprocessed float tensor) -> featsRM [N][4096] f32
-int vgg_body(lrcn_ctx *c, int N, const void *src, bool src_u8, const float *mean) {
+// calibrate: run every layer in bf16 and collect the output amax of conv2_1 .. conv5_3 (post-pool) into amax_dev
+int vgg_body(lrcn_ctx *c, int N, const void *src, bool src_u8, const float *mean, bool calibrate = false) {
+    const bool fp8 = c->vgg_fp8 && !calibrate;
+    if (fp8 && !c->fp8_ready) FAIL(c, LRCN_ESTATE, "vgg_dtype = LRCN_FP8: call lrcn_vgg_calibrate before the first forward");
     const int vdt = c->vdt;
     const float m0 = mean ? mean[0] : 0.f, m1 = mean ? mean[1] : 0.f, m2 = mean ? mean[2] : 0.f;
     const char *kf = getenv("LRCN_FUSE11");  // LRCN_FUSE11=0: conv1_1 and conv1_2 as two launches
@@ -1026,9 +1070,23 @@ int vgg_body(lrcn_ctx *c, int N, const void *src, bool src_u8, const float *mean
         std::swap(cur, nxt);
         l0 = 2;
     }
+    auto out_count = [&](int l) {
+        const VggLayer &L = c->conv[l];
+        const int64_t So = L.pool ? L.S / 2 : L.S;
+        return (int64_t)N * So * So * L.Cout;
+    };
     for (int l = l0; l < 13; ++l) {
-        int r = conv_layer(c, vdt, cur, c->conv[l], N, nxt);
+        if (fp8 && l == kFp8First) {  // conv2_1's bf16 output -> e4m3 (one elementwise pass; everything after stays e4m3)
+            k_cast_bf16_fp8(c->stream, cur, out_count(l - 1), 1.0f / c->act_scale[l - 1], nxt);
+            std::swap(cur, nxt);
+        }
+        int r = (fp8 && l >= kFp8First) ? conv_layer_fp8(c, cur, c->conv[l], N, nxt) : conv_layer(c, vdt, cur, c->conv[l], N, nxt);
         if (r) return r;
+        std::swap(cur, nxt);
+        if (calibrate && l >= kFp8First - 1) k_amax(c->stream, 0, cur, out_count(l), c->amax_dev + l);
+    }
+    if (fp8) {  // pool5 e4m3 -> bf16 for fc6
+        k_cast_fp8_bf16(c->stream, cur, out_count(12), c->act_scale[12], nxt);
         std::swap(cur, nxt);
     }
     if (ev) HIPCHK(c, hipEventRecord(ev->second, c->stream));
@@ -1265,6 +1323,88 @@ int lrcn_conv3x3(lrcn_ctx *c, const float *x, int W, int H, int Cin, int N, cons
     }
     cleanup();
     if (e != hipSuccess) FAIL(c, LRCN_EHIP, "conv3x3: %s", hipGetErrorString(e));
+    return LRCN_OK;
+}
+
+int lrcn_vgg_calibrate(lrcn_ctx *c, const uint8_t *img, int N, const float mean[3], float margin) {
+    if (!c || !img || !mean) return LRCN_EINVAL;
+    if (!c->vgg_fp8) FAIL(c, LRCN_ESTATE, "lrcn_vgg_calibrate needs a context created with vgg_dtype = LRCN_FP8");
+    if (!(margin >= 1.0f) || margin > 16.0f) FAIL(c, LRCN_EINVAL, "margin=%g outside [1,16]", margin);
+    int r = vgg_check(c, N);
+    if (r) return r;
+    HIPCHK(c, hipMemsetAsync(c->amax_dev, 0, sizeof(float) * 16, c->stream));
+    r = vgg_body(c, N, img, true, mean, true);
+    if (r) return r;
+    float amax[16];
+    HIPCHK(c, hipMemcpyAsync(amax, c->amax_dev, sizeof(float) * 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int l = kFp8First - 1; l < 13; ++l) {
+        if (!(amax[l] > 0.0f) || !std::isfinite(amax[l])) FAIL(c, LRCN_ESTATE, "calibration: layer %d output amax = %g", l, amax[l]);
+        c->act_scale[l] = margin * amax[l] / 448.0f;
+    }
+    for (int l = kFp8First; l < 13; ++l) {
+        const VggLayer &L = c->conv[l];
+        k_fp8_epilogue_params(c->stream, L.b, L.sw, L.Cout, c->act_scale[l - 1], c->act_scale[l], L.escale, L.ebias);
+    }
+    KCHK(c, "vgg_calibrate");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->fp8_ready = true;
+    return LRCN_OK;
+}
+
+int lrcn_conv3x3_fp8(lrcn_ctx *c, const float *x, int W, int H, int Cin, int N, const float *w, const float *b, int Cout, int relu,
+                     int pool, float sa_in, float sa_out, float *y, float *sw_out) {
+    if (!c || !x || !w || !b || !y) return LRCN_EINVAL;
+    if (W < 2 || H < 2 || (W & 1) || (H & 1) || Cin < 128 || (Cin % 128) || Cout < 128 || (Cout % 16) || N < 1 || (int64_t)N * W * H < 256 ||
+        !(sa_in > 0.0f) || !(sa_out > 0.0f))
+        FAIL(c, LRCN_EINVAL, "conv3x3_fp8: need even W,H, Cin %% 128 == 0, Cout >= 128 and %% 16 == 0, N*W*H >= 256, positive scales");
+    void *xin = nullptr, *wp = nullptr, *out = nullptr;
+    float *f = nullptr;  // b, sw, escale, ebias
+    const int Wo = pool ? W / 2 : W, Ho = pool ? H / 2 : H;
+    auto cleanup = [&]() {
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipFree(xin);
+        (void)hipFree(wp);
+        (void)hipFree(out);
+        (void)hipFree(f);
+    };
+    if (hipMalloc(&xin, (size_t)N * H * W * Cin) != hipSuccess || hipMalloc(&wp, (size_t)Cout * 9 * Cin) != hipSuccess ||
+        hipMalloc(&out, (size_t)N * Ho * Wo * Cout) != hipSuccess || hipMalloc((void **)&f, sizeof(float) * 4 * Cout) != hipSuccess) {
+        cleanup();
+        FAIL(c, LRCN_ENOMEM, "conv3x3_fp8 scratch");
+    }
+    float *bd = f, *sw = f + Cout, *es = f + 2 * Cout, *eb = f + 3 * Cout;
+    (void)hipMemcpyAsync(bd, b, sizeof(float) * Cout, hipMemcpyDeviceToDevice, c->stream);
+    k_ref_to_nhwc_fp8(c->stream, x, W, H, Cin, N, 1.0f / sa_in, xin);
+    k_quant_conv_w_fp8(c->stream, w, Cin, Cout, wp, sw);
+    k_fp8_epilogue_params(c->stream, bd, sw, Cout, sa_in, sa_out, es, eb);
+    if (sw_out) (void)hipMemcpyAsync(sw_out, sw, sizeof(float) * Cout, hipMemcpyDeviceToDevice, c->stream);
+    GemmArgs g{};
+    g.dtype = GEMM_T_F8;
+    g.A = xin;
+    g.B = wp;
+    g.ldb = 9 * Cin;
+    g.C = out;
+    g.ldc = Cout;
+    g.M = N * H * W;
+    g.N = Cout;
+    g.K = 9 * Cin;
+    g.bias = eb;
+    g.scale = es;
+    g.relu = relu;
+    g.a_mode = GEMM_A_CONV3;
+    g.out_mode = pool ? GEMM_OUT_POOL : GEMM_OUT_CONV;
+    g.H = H;
+    g.W = W;
+    g.Cin = Cin;
+    g.zero_page = c->zero_page;
+    hipError_t e = launch_gemm(c->stream, g);
+    if (e == hipSuccess) {
+        k_nhwc_fp8_to_ref(c->stream, out, Wo, Ho, Cout, N, sa_out, y);
+        e = hipGetLastError();
+    }
+    cleanup();
+    if (e != hipSuccess) FAIL(c, LRCN_EHIP, "conv3x3_fp8: %s", hipGetErrorString(e));
     return LRCN_OK;
 }
 

@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import BOS, CNNOUT, EOS, LRCN_BF16, LRCN_F32, UNK, LrcnError  # noqa: F401
+from ._lib import BOS, CNNOUT, EOS, LRCN_BF16, LRCN_F32, LRCN_FP8, UNK, LrcnError  # noqa: F401
 
 PARAM_NAMES = ("W1", "b1", "W2", "b2", "Wproj", "Wcnn", "Wembed", "Wout", "bout")
 VGG_COUT = (64, 64, 128, 128, 256, 256, 256, 512, 512, 512, 512, 512, 512)
@@ -362,6 +362,24 @@ def conv3x3(ctx, x, w, b, relu=True, pool=False):
     y = jl_empty(W // 2 if pool else W, H // 2 if pool else H, Cout, N)
     ctx._call("lrcn_conv3x3", _ptr(x), W, H, Cin, N, _ptr(w), _ptr(b), Cout, int(relu), int(pool), _ptr(y))
     return y
+
+
+def vgg_calibrate(ctx, img_u8, mean=VGG_MEAN, margin=1.25):
+    """vgg_dtype = LRCN_FP8 only: one bf16 pass over `img_u8` (uint8 crops [n][row][col][c]) that fixes the per-layer
+    activation scales of the e4m3 layers (include/lrcn.h lrcn_vgg_calibrate).  No counterpart in the reference."""
+    m = (C.c_float * 3)(*mean)
+    ctx._call("lrcn_vgg_calibrate", C.c_void_p(img_u8.data_ptr()), img_u8.shape[0], m, float(margin))
+
+
+def conv3x3_fp8(ctx, x, w, b, sa_in, sa_out, relu=True, pool=False):
+    """e4m3 probe of one layer (include/lrcn.h lrcn_conv3x3_fp8) -> (y dequantised, per-channel weight scales)."""
+    W, H, Cin, N = x.shape
+    Cout = w.shape[3]
+    y = jl_empty(W // 2 if pool else W, H // 2 if pool else H, Cout, N)
+    sw = torch.empty(Cout, dtype=torch.float32, device=x.device)
+    ctx._call("lrcn_conv3x3_fp8", _ptr(x), W, H, Cin, N, _ptr(w), _ptr(b), Cout, int(relu), int(pool), float(sa_in), float(sa_out),
+              _ptr(y), C.c_void_p(sw.data_ptr()))
+    return y, sw
 
 
 def synthetic_vgg_weights(seed=1, device="cuda"):

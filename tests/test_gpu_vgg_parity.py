@@ -177,3 +177,71 @@ def test_fused_conv1_1_conv1_2_matches_two_launch_path(vgg_setup, monkeypatch):
         ctx.close()
         assert rel_max_err(outs[knob][:2], ref) <= 3e-2 and rel_max_err(outs[knob][2:], ref3) <= 3e-2
     assert rel_max_err(outs["1"], outs["0"]) <= 1.5e-2
+
+
+# ---------------------------------------------------------------------------------------------- fp8 (BASELINE config 5)
+def _e4m3(a):
+    """round-to-nearest-even OCP e4m3 with saturation at +-448, returned as float32 (torch's float8_e4m3fn cast)."""
+    t = torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).clamp(-448.0, 448.0)
+    return t.to(torch.float8_e4m3fn).to(torch.float32).numpy()
+
+
+@pytest.mark.parametrize("W,H,Cin,Cout,N", [(16, 16, 128, 128, 1), (16, 16, 256, 256, 2), (12, 20, 128, 512, 3), (28, 28, 512, 512, 1)])
+def test_fp8_conv_layer_matches_emulated_arithmetic(W, H, Cin, Cout, N):
+    # gemm_8p.hip F8 (v_mfma_f32_16x16x128_f8f6f4, e4m3 staged epilogue): the kernel's result must equal the same
+    # arithmetic carried out on the host -- quantise x and w exactly as fp8.hip does, convolve the quantised values with
+    # the CPU oracle (fp32), scale / bias / ReLU / pool / e4m3 -- except where fp32 summation order moves a value across
+    # an e4m3 rounding boundary (one ulp = 2^-3 relative).  M = N*W*H covers a 256-row tile edge (720) and a full one.
+    rng = np.random.default_rng(Cin + Cout + N)
+    x = np.abs(rng.standard_normal((W, H, Cin, N))).astype(np.float32)  # post-ReLU-like inputs
+    w = (rng.standard_normal((3, 3, Cin, Cout)) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
+    b = (rng.standard_normal(Cout) * 0.05).astype(np.float32)
+    ref32 = orc.conv3x3(x, w, b, relu=True)
+    sa_in = np.float32(x.max() / 448.0)
+    ctx = small_ctx()
+    for pool in (False, True):
+        tgt = orc.pool2(ref32) if pool else ref32
+        sa_out = np.float32(tgt.max() / 448.0)
+        y, sw = L.conv3x3_fp8(ctx, L.to_jl(x), L.to_jl(w), torch.as_tensor(b).cuda(), float(sa_in), float(sa_out), relu=True, pool=pool)
+        y, sw = L.from_jl(y), sw.cpu().numpy()
+        np.testing.assert_allclose(sw, np.abs(w).max(axis=(0, 1, 2)) / np.float32(448.0), rtol=1e-6)
+        xq = _e4m3(x * (np.float32(1.0) / sa_in))
+        wq = _e4m3(w * (np.float32(1.0) / sw)[None, None, None, :])
+        acc = orc.conv3x3(xq, wq, np.zeros(Cout, np.float32), relu=False)
+        if pool:
+            acc = orc.pool2(acc)
+        v = np.maximum(acc * (sa_in * sw / sa_out)[None, None, :, None] + (b / sa_out)[None, None, :, None], 0.0).astype(np.float32)
+        emu = _e4m3(v) * sa_out
+        diff = np.abs(y - emu)
+        # never more than one e4m3 step (2^-3 relative); below 2^-6 (e4m3 subnormals, < 0.004 % of the tensor's max) the
+        # hardware conversion may land two subnormal steps away from round-to-nearest
+        assert (diff <= 0.126 * np.abs(emu) + 2.0 ** -7 * sa_out).all(), float(diff.max())
+        assert (diff == 0).mean() > 0.99, float((diff == 0).mean())
+        # and the quantised layer is close to the fp32 layer: e4m3 keeps 3 mantissa bits per operand and per output
+        err = np.linalg.norm(y - tgt) / np.linalg.norm(tgt)
+        assert err < 0.06, err
+    ctx.close()
+
+
+def test_full_vgg_fp8_vs_oracle(vgg_setup):
+    # conv2_2 .. conv5_3 in e4m3 (calibrated on the same two images), the rest bf16, against the fp32 CPU oracle.
+    # Stated tolerance of the fp8 path: cosine >= 0.99 per image and relative L2 error <= 0.15 on the fc7 features
+    # (ten e4m3 layers in sequence; the bf16 path holds 3e-2 of the max).  Not a claim about the reference, which has no
+    # reduced-precision path.
+    w, img, x, ref = vgg_setup
+    ctx = small_ctx(lrcn_amd.LRCN_FP8, max_images=2)
+    L.vgg_load(ctx, *w)
+    imgs = torch.as_tensor(img).cuda()
+    with pytest.raises(lrcn_amd.LrcnError):
+        L.convnet_u8(ctx, imgs)  # not calibrated yet
+    L.vgg_calibrate(ctx, imgs)
+    got = L.from_jl(L.convnet_u8(ctx, imgs))
+    assert np.isfinite(got).all()
+    for n in range(2):
+        cos = float((got[n] * ref[n]).sum() / (np.linalg.norm(got[n]) * np.linalg.norm(ref[n])))
+        rel = float(np.linalg.norm(got[n] - ref[n]) / np.linalg.norm(ref[n]))
+        print("fp8 vgg image %d: cosine %.5f rel L2 %.4f" % (n, cos, rel))
+        assert cos >= 0.99 and rel <= 0.15, (cos, rel)
+    got1 = L.from_jl(L.convnet_u8(ctx, imgs[1:2]))
+    np.testing.assert_allclose(got1[0], got[1], rtol=0, atol=1e-5 * np.abs(ref).max())
+    ctx.close()
