@@ -154,6 +154,12 @@ void k_mul_f32(hipStream_t st, const float *a, const float *b, int64_t n, float 
 void k_conv11_fused(hipStream_t st, int src_is_u8, const void *src, int N, int S, float m0, float m1, float m2, const void *w,
                     const float *bias, void *out);
 
+// softmax + top-K of every row in one pass (false: V too large for the register-resident form, use the two kernels)
+bool k_softmax_topk_rows(hipStream_t st, const float *logits, int64_t ld, int R, int V, int K, int32_t *idx, float *val);
+// out[i][r][:] = in[i][parent[r]][:] for the four recurrent states (row stride C[i]); hT[i] != NULL also receives a T copy (ld ldT[i])
+void k_gather_state(hipStream_t st, int dtype, const float *const in[4], float *const out[4], void *const hT[4], const int64_t ldT[4],
+                    const int C[4], const int32_t *parent, int R);
+
 // ---- fp8.hip: OCP e4m3 plumbing of the VGG convolution stack ----
 void k_quant_conv_w_fp8(hipStream_t st, const float *w, int Cin, int Cout, void *out, float *sw);
 void k_amax(hipStream_t st, int in_f32, const void *x, int64_t n, float *out);  // atomic max of |x| into *out (caller zeroes)

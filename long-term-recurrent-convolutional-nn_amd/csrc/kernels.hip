@@ -725,6 +725,102 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float *prob, int64
     }
 }
 
+// softmax_rows + topk_rows in one pass for V <= 256 * 64: the row of logits stays in registers, the probabilities are the
+// same expressions (expf(x - (max + logf(sum)))) in the same accumulation order as softmax_rows_kernel, the K rounds of
+// block-wide argmax use the same order (value descending, ties to the lower index) as topk_rows_kernel.
+#define STK_PT 64
+__global__ __launch_bounds__(256) void softmax_topk_rows_kernel(const float *logits, int64_t ld, int R, int V, int K, int32_t *idx,
+                                                                float *val) {
+    __shared__ float sh[8];
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    const int r = blockIdx.x;
+    const float *row = logits + (int64_t)r * ld;
+    float x[STK_PT];
+#pragma unroll
+    for (int i = 0; i < STK_PT; ++i) {
+        const int v = threadIdx.x + i * 256;
+        x[i] = v < V ? row[v] : -INFINITY;
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < STK_PT; ++i) mx = fmaxf(mx, x[i]);
+    mx = block_max(mx, sh);
+    float se = 0.0f;
+#pragma unroll
+    for (int i = 0; i < STK_PT; ++i)
+        if (threadIdx.x + i * 256 < V) se += expf(x[i] - mx);
+    se = block_sum(se, sh);
+    const float lse = mx + logf(se);
+#pragma unroll
+    for (int i = 0; i < STK_PT; ++i) x[i] = (threadIdx.x + i * 256 < V) ? expf(x[i] - lse) : -INFINITY;  // probabilities
+    for (int k = 0; k < K; ++k) {
+        float bv = -INFINITY;
+        int bi = 0x7FFFFFFF;
+#pragma unroll
+        for (int i = 0; i < STK_PT; ++i)
+            if (x[i] > bv) {  // increasing index: strict > keeps the lowest index among equals
+                bv = x[i];
+                bi = threadIdx.x + i * 256;
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o);
+            const int oi = __shfl_xor(bi, o);
+            if (ov > bv || (ov == bv && oi < bi)) {
+                bv = ov;
+                bi = oi;
+            }
+        }
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) {
+            sv[threadIdx.x >> 6] = bv;
+            si[threadIdx.x >> 6] = bi;
+        }
+        __syncthreads();
+        bv = sv[0];
+        bi = si[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) {
+                bv = sv[w];
+                bi = si[w];
+            }
+        if (threadIdx.x == 0) {
+            idx[r * K + k] = bi;
+            val[r * K + k] = bv;
+        }
+        if ((bi & 255) == (int)threadIdx.x) {  // the owner retires the winner
+            const int slot = bi >> 8;
+#pragma unroll
+            for (int i = 0; i < STK_PT; ++i)
+                if (i == slot) x[i] = -INFINITY;
+        }
+    }
+}
+
+// Beam reordering of the four recurrent state tensors in one launch (lrcn.jl:673-676): out[i][r] = in[i][parent[r]], plus
+// the K-contiguous T copies of h1 / h2 that the next step's recurrent GEMMs read.
+struct GatherState {
+    const float *in[4];
+    float *out[4];
+    void *hT[4];     // T copy of state i (or NULL)
+    int64_t ldT[4];
+    int C[4];
+};
+template <typename T> __global__ void gather_state_kernel(const GatherState g, const int32_t *parent) {
+    const int r = blockIdx.x, i = blockIdx.y;
+    const int C = g.C[i];
+    const float *s = g.in[i] + (int64_t)parent[r] * C;
+    float *o = g.out[i] + (int64_t)r * C;
+    T *t = g.hT[i] ? reinterpret_cast<T *>(g.hT[i]) + (int64_t)r * g.ldT[i] : nullptr;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float v = s[c];
+        o[c] = v;
+        if (t) t[c] = from_f32<T>(v);
+    }
+}
+
 __global__ void gather_rows_f32_kernel(const float *in, int64_t ld, const int32_t *src_row, int R, int C, float *out) {
     const int r = blockIdx.x;
     const float *s = in + (int64_t)src_row[r] * ld;
@@ -907,6 +1003,19 @@ void k_beam_update(hipStream_t st, const int32_t *topi, const float *topv, const
 }
 void k_repeat_rows(hipStream_t st, int dtype, const void *in, int64_t ld, int N, int K, int C, void *out) {
     DISPATCH_T(dtype, hipLaunchKernelGGL(repeat_rows_kernel<T>, dim3(N * K), dim3(256), 0, st, (const T *)in, ld, N * K, K, C, (T *)out));
+}
+bool k_softmax_topk_rows(hipStream_t st, const float *logits, int64_t ld, int R, int V, int K, int32_t *idx, float *val) {
+    if (V > 256 * STK_PT || K > 32) return false;
+    hipLaunchKernelGGL(softmax_topk_rows_kernel, dim3(R), dim3(256), 0, st, logits, ld, R, V, K, idx, val);
+    return true;
+}
+void k_gather_state(hipStream_t st, int dtype, const float *const in[4], float *const out[4], void *const hT[4], const int64_t ldT[4],
+                    const int C[4], const int32_t *parent, int R) {
+    GatherState g;
+    for (int i = 0; i < 4; ++i) {
+        g.in[i] = in[i]; g.out[i] = out[i]; g.hT[i] = hT[i]; g.ldT[i] = ldT[i]; g.C[i] = C[i];
+    }
+    DISPATCH_T(dtype, hipLaunchKernelGGL(gather_state_kernel<T>, dim3(R, 4), dim3(256), 0, st, g, parent));
 }
 void k_gather_rows_f32(hipStream_t st, const float *in, int64_t ld, const int32_t *src_row, int R, int C, float *out) {
     hipLaunchKernelGGL(gather_rows_f32_kernel, dim3(R), dim3(256), 0, st, in, ld, src_row, R, C, out);

@@ -412,11 +412,11 @@ int fetch_loss(lrcn_ctx *c, double *out) {
 
 // lrcn() on internal single-step buffers: state st_f32 (f32 row-major), inputs st_x (T [B][ldE]) and xcnn (f32 [B][ldh]).
 // m2: dropout for the concatenated LSTM-2 input. Leaves logits in st_logits [B][ldV].
-int step_internal(lrcn_ctx *c, const float *const p[9], int B, const DropSpec &d2) {
+int step_internal(lrcn_ctx *c, const float *const p[9], int B, const DropSpec &d2, bool h_ready = false) {
     const int dt = c->dt, E = c->E, H1 = c->H1, H2 = c->H2, h = c->h, V = c->V;
     hipStream_t st = c->stream;
     // LSTM 1: gates = x*W1x' + h1*W1h' + b1
-    k_cast_rows(st, dt, c->st_f32[0], H1, B, H1, c->st_h1, c->ldH1);
+    if (!h_ready) k_cast_rows(st, dt, c->st_f32[0], H1, B, H1, c->st_h1, c->ldH1);  // h_ready: st_h1 / st_h2 already hold T(h)
     GEMM(c, dt, c->st_x, c->ldE, c->W1x, c->ldE, c->st_g, 4 * H1, B, 4 * H1, E, p[1], true);
     GEMM(c, dt, c->st_h1, c->ldH1, c->W1h, c->ldH1, c->st_g, 4 * H1, B, 4 * H1, H1, nullptr, true, true);
     k_lstm_fwd(st, dt, c->st_g, 4 * H1, c->st_f32[1], B, H1, c->st_a, c->ld4H1, c->st_f32[1], c->st_h1, c->ldH1, c->st_f32[0]);
@@ -424,7 +424,7 @@ int step_internal(lrcn_ctx *c, const float *const p[9], int B, const DropSpec &d
     GEMM(c, dt, c->st_h1, c->ldH1, c->Wpd, c->ldH1, c->st_x2, c->ldH2, B, h, H1, nullptr, false);
     k_concat_x2(st, dt, c->st_x2, c->ldH2, c->xcnn, c->ldh, 1, B, h, d2);
     // LSTM 2
-    k_cast_rows(st, dt, c->st_f32[2], H2, B, H2, c->st_h2, c->ldH2);
+    if (!h_ready) k_cast_rows(st, dt, c->st_f32[2], H2, B, H2, c->st_h2, c->ldH2);
     GEMM(c, dt, c->st_x2, c->ldH2, c->W2x, c->ldH2, c->st_g, 4 * H2, B, 4 * H2, H2, p[3], true);
     GEMM(c, dt, c->st_h2, c->ldH2, c->W2h, c->ldH2, c->st_g, 4 * H2, B, 4 * H2, H2, nullptr, true, true);
     k_lstm_fwd(st, dt, c->st_g, 4 * H2, c->st_f32[3], B, H2, c->st_a, c->ld4H2, c->st_f32[3], c->st_h2, c->ldH2, c->st_f32[2]);
@@ -777,8 +777,10 @@ int lrcn_beam_search(lrcn_ctx *c, const float *const p[9], const float *feat, in
         k_embed_gather(st, dt, c->WeT, c->ldE, c->st_parent, 1, K, E, none, c->st_x, c->ldE);  // lrcn.jl:650
         r = step_internal(c, p, K, none);                                                    // lrcn.jl:651 (K hypotheses batched)
         if (r) return r;
-        k_softmax_rows(st, c->st_logits, c->ldV, K, V, c->st_prob, c->ldV);                   // :652
-        k_topk_rows(st, c->st_prob, c->ldV, K, V, K, c->st_topi, c->st_topv);                 // :655-656 on device
+        if (!k_softmax_topk_rows(st, c->st_logits, c->ldV, K, V, K, c->st_topi, c->st_topv)) {  // :652, :655-656 on device
+            k_softmax_rows(st, c->st_logits, c->ldV, K, V, c->st_prob, c->ldV);
+            k_topk_rows(st, c->st_prob, c->ldV, K, V, K, c->st_topi, c->st_topv);
+        }
         HIPCHK(c, hipMemcpyAsync(topi.data(), c->st_topi, sizeof(int32_t) * K * K, hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipMemcpyAsync(topv.data(), c->st_topv, sizeof(float) * K * K, hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
@@ -845,6 +847,8 @@ int lrcn_beam_search_batch(lrcn_ctx *c, const float *const p[9], const float *fe
     k_repeat_rows(st, GEMM_T_F32, c->dxcnn, c->ldh, N, K, h, c->xcnn);
     const int Hs[4] = {H1, H1, H2, H2};
     for (int i = 0; i < 4; ++i) HIPCHK(c, hipMemsetAsync(c->st_f32[i], 0, sizeof(float) * (size_t)R * Hs[i], st));
+    HIPCHK(c, hipMemsetAsync(c->st_h1, 0, c->esz * (size_t)R * c->ldH1, st));  // T copies of the zero initial h1 / h2
+    HIPCHK(c, hipMemsetAsync(c->st_h2, 0, c->esz * (size_t)R * c->ldH2, st));
     HIPCHK(c, hipMemsetAsync(c->bs_done, 0, sizeof(int32_t) * N, st));
     HIPCHK(c, hipMemsetAsync(c->bs_ndone, 0, sizeof(int32_t), st));
     {   // histories = [bos], probabilities 1, next input = bos
@@ -860,16 +864,20 @@ int lrcn_beam_search_batch(lrcn_ctx *c, const float *const p[9], const float *fe
     int cur = 0;
     for (int current = 1; current <= nword + 1; ++current) {
         k_embed_gather(st, dt, c->WeT, c->ldE, c->bs_last, 1, R, E, none, c->st_x, c->ldE);   // lrcn.jl:650
-        r = step_internal(c, p, R, none);                                                   // :651, all N*K hypotheses batched
+        r = step_internal(c, p, R, none, true);                                             // :651, all N*K hypotheses batched
         if (r) return r;
-        k_softmax_rows(st, c->st_logits, c->ldV, R, V, c->st_prob, c->ldV);                  // :652
-        k_topk_rows(st, c->st_prob, c->ldV, R, V, K, c->st_topi, c->st_topv);                // :655-656
+        if (!k_softmax_topk_rows(st, c->st_logits, c->ldV, R, V, K, c->st_topi, c->st_topv)) {  // :652, :655-656 in one pass
+            k_softmax_rows(st, c->st_logits, c->ldV, R, V, c->st_prob, c->ldV);
+            k_topk_rows(st, c->st_prob, c->ldV, R, V, K, c->st_topi, c->st_topv);
+        }
         k_beam_update(st, c->st_topi, c->st_topv, c->bs_seq[cur], c->bs_seq[cur ^ 1], c->bs_p, c->st_parent, c->bs_last, c->bs_done,
                       c->bs_ndone, c->bs_res_tok, c->bs_res_len, c->bs_res_p, N, K, Lh, current, nword, LRCN_EOS);
         cur ^= 1;
-        for (int i = 0; i < 4; ++i) {                                                       // :673-676
-            k_gather_rows_f32(st, c->st_f32[i], Hs[i], c->st_parent, R, Hs[i], c->st2_f32[i]);
-            std::swap(c->st_f32[i], c->st2_f32[i]);
+        {   // :673-676: the four states follow their parents; the T copies of h1 / h2 for the next step's GEMMs ride along
+            void *const hT[4] = {c->st_h1, nullptr, c->st_h2, nullptr};
+            const int64_t ldT[4] = {c->ldH1, 0, c->ldH2, 0};
+            k_gather_state(st, dt, c->st_f32, c->st2_f32, hT, ldT, Hs, c->st_parent, R);
+            for (int i = 0; i < 4; ++i) std::swap(c->st_f32[i], c->st2_f32[i]);
         }
         if ((current & 3) == 0 && current <= nword) {  // every image finished early?
             int32_t nd = 0;

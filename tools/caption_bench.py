@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[4]: MS-COCO-shaped caption generation -- fp8 (e4m3) VGG-16 convolution stack + bf16 LSTM,
+beam-search-5, nword 30 -- captions/s on 1 GPU, or on N GPUs as N independent replicas (images are independent:
+SURVEY.md 8(e) "replicas only", no collective on the data path; one barrier + max-over-ranks timing as bench.py).
+
+  python tools/caption_bench.py [--images 256] [--chunk 64] [--iters 5] [--vgg fp8|bf16]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/caption_bench.py ...
+
+Synthetic uint8 crops, He-normal VGG weights, random LRCN weights (E = H = 1000, V = 10640): throughput only; the
+caption text of the fp8 path is compared with the bf16 path's on the same images and reported (agreement is not
+expected to be 100 %: random weights give near-uniform word distributions, the worst case for any perturbation)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import lrcn_amd  # noqa: E402
+from lrcn_amd import lrcn as L  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--images", type=int, default=256, help="images per VGG forward (per GPU)")
+    ap.add_argument("--chunk", type=int, default=64, help="images per batched beam search")
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--vgg", default="fp8", choices=["fp8", "bf16"])
+    a = ap.parse_args()
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    K, nword, V, N = 5, 30, 10640, a.images
+    vdt = lrcn_amd.LRCN_FP8 if a.vgg == "fp8" else lrcn_amd.LRCN_BF16
+    ctx = L.Context(1000, 1000, 1000, V, max_B=a.chunk * K, max_T=1, lstm_dtype=lrcn_amd.LRCN_BF16, vgg_dtype=vdt, max_images=N,
+                    device=local)
+    L.vgg_load(ctx, *L.synthetic_vgg_weights(seed=1))
+    param = L.initweights(ctx, seed=42)
+    img = torch.as_tensor(np.random.default_rng(1234 + rank).integers(0, 256, size=(N, 224, 224, 3), dtype=np.uint8)).cuda()
+    if vdt == lrcn_amd.LRCN_FP8:
+        L.vgg_calibrate(ctx, img[: min(N, 32)])
+    feats = L.jl_empty(N, L.CNNOUT)
+
+    def one_pass():
+        L.convnet_u8(ctx, img, feats=feats)
+        outs = []
+        for s in range(0, N, a.chunk):
+            outs += L.beam_search_batch(ctx, param, L.to_jl(feats[s:min(N, s + a.chunk)]), K, nword)
+        return outs
+
+    one_pass()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.iters):
+        outs = one_pass()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    # split of one pass on this rank (not part of the timed region)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    L.convnet_u8(ctx, img, feats=feats)
+    torch.cuda.synchronize()
+    t_vgg = time.perf_counter() - t1
+    if rank == 0:
+        print(json.dumps({"metric": "caption generation throughput (VGG-16 -> fc7 + beam-search-5, nword 30)", "value": world * N * a.iters / dt,
+                          "unit": "captions/sec", "n_gpus": world, "scaling": "weak (replicas only)", "vgg_dtype": a.vgg, "lstm_dtype": "bf16",
+                          "images_per_gpu_per_pass": N, "beam_chunk": a.chunk, "ms_per_pass": dt / a.iters * 1e3,
+                          "ms_vgg_forward": t_vgg * 1e3, "mean_caption_len": float(np.mean([len(t) for t, _ in outs])), "data": "synthetic"}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
