@@ -50,6 +50,9 @@ struct lrcn_ctx {
     int64_t ldE = 0, ldH1 = 0, ldH2 = 0, ldh = 0, ld4H1 = 0, ld4H2 = 0, ldV = 0, ldM = 0, ldB = 0;
     // shadow weights (T)
     void *W1x = nullptr, *W1h = nullptr, *W1xT = nullptr, *W1hT = nullptr;
+    // decode only: [x | h] concatenated along K -- weights [4H][ldXH] and the step inputs [B][ldXH]: one gate GEMM per LSTM
+    void *W1cat = nullptr, *W2cat = nullptr, *st_xh1 = nullptr, *st_xh2 = nullptr;
+    int64_t ldXH1 = 0, ldXH2 = 0;
     void *W2x = nullptr, *W2h = nullptr, *W2xT = nullptr, *W2hT = nullptr;
     void *Wpd = nullptr, *WpT = nullptr, *Wcd = nullptr, *WeT = nullptr, *Wod = nullptr, *WoT = nullptr;
     // activations
@@ -194,7 +197,7 @@ DropSpec make_drop(const lrcn_dropout *d, int which) {
 }
 
 // f32 column-major params -> K-contiguous shadows in T (direct and transposed).  See DESIGN.md "shadow weights".
-int prepare_weights(lrcn_ctx *c, const float *const p[9], bool need_bwd) {
+int prepare_weights(lrcn_ctx *c, const float *const p[9], bool need_bwd, bool cat = false) {
     const int dt = c->dt, E = c->E, H1 = c->H1, H2 = c->H2, h = c->h, V = c->V;
     hipStream_t st = c->stream;
     PrepPlan plan{};
@@ -213,6 +216,10 @@ int prepare_weights(lrcn_ctx *c, const float *const p[9], bool need_bwd) {
     add(p[5], h, LRCN_CNNOUT, LRCN_CNNOUT, c->Wcd, LRCN_CNNOUT, nullptr, 0, nullptr, 0, nullptr, 0);   // Wcnn: memory [h][4096]
     add(p[6], E, V, V, nullptr, 0, nullptr, 0, c->WeT, c->ldE, nullptr, 0);                          // Wembed (V x E): memory [E][V] -> [V][ldE]
     add(p[7], V, H2, H2, c->Wod, c->ldH2, nullptr, 0, b ? c->WoT : nullptr, c->ldV, nullptr, 0);   // Wout (H2 x V): memory [V][H2]
+    if (cat) {  // batched decode: W1 / W2 with the x and h column blocks each padded to whole K-steps, side by side
+        add(p[0], 4 * H1, E + H1, E, c->W1cat, c->ldXH1, boff(c->W1cat, c->ldE, c->esz), c->ldXH1, nullptr, 0, nullptr, 0);
+        add(p[2], 4 * H2, 2 * H2, H2, c->W2cat, c->ldXH2, boff(c->W2cat, c->ldH2, c->esz), c->ldXH2, nullptr, 0, nullptr, 0);
+    }
     k_prepare_weights(st, dt, plan);
     KCHK(c, "prepare_weights");
     return LRCN_OK;
@@ -433,6 +440,23 @@ int step_internal(lrcn_ctx *c, const float *const p[9], int B, const DropSpec &d
     return LRCN_OK;
 }
 
+// The same step for the batched beam decode, on the concatenated buffers: st_xh1 = [x | h1], st_xh2 = [x2 | h2] (T, the
+// h blocks already hold this step's input states), one GEMM per LSTM against W1cat / W2cat.
+int step_decode(lrcn_ctx *c, const float *const p[9], int B, const DropSpec &d2) {
+    const int dt = c->dt, H1 = c->H1, H2 = c->H2, h = c->h, V = c->V;
+    hipStream_t st = c->stream;
+    void *h1T = boff(c->st_xh1, c->ldE, c->esz), *h2T = boff(c->st_xh2, c->ldH2, c->esz);
+    GEMM(c, dt, c->st_xh1, c->ldXH1, c->W1cat, c->ldXH1, c->st_g, 4 * H1, B, 4 * H1, (int)c->ldE + H1, p[1], true);
+    k_lstm_fwd(st, dt, c->st_g, 4 * H1, c->st_f32[1], B, H1, c->st_a, c->ld4H1, c->st_f32[1], h1T, c->ldXH1, c->st_f32[0]);
+    GEMM(c, dt, h1T, c->ldXH1, c->Wpd, c->ldH1, c->st_xh2, c->ldXH2, B, h, H1, nullptr, false);
+    k_concat_x2(st, dt, c->st_xh2, c->ldXH2, c->xcnn, c->ldh, 1, B, h, d2);
+    GEMM(c, dt, c->st_xh2, c->ldXH2, c->W2cat, c->ldXH2, c->st_g, 4 * H2, B, 4 * H2, (int)c->ldH2 + H2, p[3], true);
+    k_lstm_fwd(st, dt, c->st_g, 4 * H2, c->st_f32[3], B, H2, c->st_a, c->ld4H2, c->st_f32[3], h2T, c->ldXH2, c->st_f32[2]);
+    GEMM(c, dt, h2T, c->ldXH2, c->Wod, c->ldH2, c->st_logits, c->ldV, B, V, H2, p[8], true);
+    KCHK(c, "step_decode");
+    return LRCN_OK;
+}
+
 }  // namespace
 
 // =====================================================================================================
@@ -513,6 +537,9 @@ int lrcn_create(const lrcn_config *cfg, lrcn_ctx **out) {
     c->ldV = ld8(V); c->ldM = ld8(M); c->ldB = ld8(B);
     const size_t es = c->esz;
     int rc = [&]() -> int {
+        c->ldXH1 = c->ldE + c->ldH1; c->ldXH2 = 2 * c->ldH2;
+        DALLOC(c, c->W1cat, es * 4 * H1 * c->ldXH1); DALLOC(c, c->W2cat, es * 4 * H2 * c->ldXH2);
+        DALLOC(c, c->st_xh1, es * B * c->ldXH1);     DALLOC(c, c->st_xh2, es * B * c->ldXH2);
         DALLOC(c, c->W1x, es * 4 * H1 * c->ldE);   DALLOC(c, c->W1h, es * 4 * H1 * c->ldH1);
         DALLOC(c, c->W1xT, es * E * c->ld4H1);     DALLOC(c, c->W1hT, es * H1 * c->ld4H1);
         DALLOC(c, c->W2x, es * 4 * H2 * c->ldH2);  DALLOC(c, c->W2h, es * 4 * H2 * c->ldH2);
@@ -839,7 +866,7 @@ int lrcn_beam_search_batch(lrcn_ctx *c, const float *const p[9], const float *fe
     const int dt = c->dt, E = c->E, H1 = c->H1, H2 = c->H2, h = c->h, V = c->V;
     const int R = N * K, Lh = nword + 2;
     hipStream_t st = c->stream;
-    int r = prepare_weights(c, p, false);
+    int r = prepare_weights(c, p, false, true);
     if (r) return r;
     // input = input * param[end-3] per image (lrcn.jl:611), each row repeated for the image's K hypotheses
     k_transpose(st, dt, 1, feats, N, LRCN_CNNOUT, N, c->F, LRCN_CNNOUT, 0);
@@ -847,8 +874,8 @@ int lrcn_beam_search_batch(lrcn_ctx *c, const float *const p[9], const float *fe
     k_repeat_rows(st, GEMM_T_F32, c->dxcnn, c->ldh, N, K, h, c->xcnn);
     const int Hs[4] = {H1, H1, H2, H2};
     for (int i = 0; i < 4; ++i) HIPCHK(c, hipMemsetAsync(c->st_f32[i], 0, sizeof(float) * (size_t)R * Hs[i], st));
-    HIPCHK(c, hipMemsetAsync(c->st_h1, 0, c->esz * (size_t)R * c->ldH1, st));  // T copies of the zero initial h1 / h2
-    HIPCHK(c, hipMemsetAsync(c->st_h2, 0, c->esz * (size_t)R * c->ldH2, st));
+    HIPCHK(c, hipMemsetAsync(c->st_xh1, 0, c->esz * (size_t)R * c->ldXH1, st));  // zero initial h1 / h2 (T copies) and K padding
+    HIPCHK(c, hipMemsetAsync(c->st_xh2, 0, c->esz * (size_t)R * c->ldXH2, st));
     HIPCHK(c, hipMemsetAsync(c->bs_done, 0, sizeof(int32_t) * N, st));
     HIPCHK(c, hipMemsetAsync(c->bs_ndone, 0, sizeof(int32_t), st));
     {   // histories = [bos], probabilities 1, next input = bos
@@ -863,8 +890,8 @@ int lrcn_beam_search_batch(lrcn_ctx *c, const float *const p[9], const float *fe
     DropSpec none{};
     int cur = 0;
     for (int current = 1; current <= nword + 1; ++current) {
-        k_embed_gather(st, dt, c->WeT, c->ldE, c->bs_last, 1, R, E, none, c->st_x, c->ldE);   // lrcn.jl:650
-        r = step_internal(c, p, R, none, true);                                             // :651, all N*K hypotheses batched
+        k_embed_gather(st, dt, c->WeT, c->ldE, c->bs_last, 1, R, E, none, c->st_xh1, c->ldXH1);  // lrcn.jl:650
+        r = step_decode(c, p, R, none);                                                     // :651, all N*K hypotheses batched
         if (r) return r;
         if (!k_softmax_topk_rows(st, c->st_logits, c->ldV, R, V, K, c->st_topi, c->st_topv)) {  // :652, :655-656 in one pass
             k_softmax_rows(st, c->st_logits, c->ldV, R, V, c->st_prob, c->ldV);
@@ -874,8 +901,8 @@ int lrcn_beam_search_batch(lrcn_ctx *c, const float *const p[9], const float *fe
                       c->bs_ndone, c->bs_res_tok, c->bs_res_len, c->bs_res_p, N, K, Lh, current, nword, LRCN_EOS);
         cur ^= 1;
         {   // :673-676: the four states follow their parents; the T copies of h1 / h2 for the next step's GEMMs ride along
-            void *const hT[4] = {c->st_h1, nullptr, c->st_h2, nullptr};
-            const int64_t ldT[4] = {c->ldH1, 0, c->ldH2, 0};
+            void *const hT[4] = {boff(c->st_xh1, c->ldE, c->esz), nullptr, boff(c->st_xh2, c->ldH2, c->esz), nullptr};
+            const int64_t ldT[4] = {c->ldXH1, 0, c->ldXH2, 0};
             k_gather_state(st, dt, c->st_f32, c->st2_f32, hT, ldT, Hs, c->st_parent, R);
             for (int i = 0; i < 4; ++i) std::swap(c->st_f32[i], c->st2_f32[i]);
         }
