@@ -305,7 +305,11 @@ static hipError_t launch_gemm_routed(hipStream_t stream, const GemmArgs &g, cons
         const int64_t blocks = gemm_glds_blocks(g);
         if (blocks > 0 && ((knob && knob[0] == 'f') || blocks >= 96)) { *route = "glds"; return launch_gemm_glds(stream, g); }
     }
-    if (skinny_ok) { *route = "skinny-last"; return launch_gemm_skinny(stream, g); }  // 128 < M <= 256 with too few tiles for the paths above
+    if (skinny_ok) { *route = "skinny-last"; return launch_gemm_skinny(stream, g); }
+    if (!(knob && knob[0] == '0') && gemm_glds_eligible(g) && gemm_glds_blocks(g) >= 16) {  // few tiles, but still far ahead of gemm_nt
+        *route = "glds-small";
+        return launch_gemm_glds(stream, g);
+    }  // 128 < M <= 256 with too few tiles for the paths above
     const int ce = g.dtype == GEMM_T_BF16 ? 8 : 4;
     if (((uintptr_t)g.A & 15) || ((uintptr_t)g.B & 15) || (g.ldb % ce)) return hipErrorInvalidValue;
     if (g.a_mode == GEMM_A_CONV3) {

@@ -728,41 +728,54 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float *prob, int64
 // softmax_rows + topk_rows in one pass for V <= 256 * 64: the row of logits stays in registers, the probabilities are the
 // same expressions (expf(x - (max + logf(sum)))) in the same accumulation order as softmax_rows_kernel, the K rounds of
 // block-wide argmax use the same order (value descending, ties to the lower index) as topk_rows_kernel.
-#define STK_PT 64
+#define STK_Q 16  // float4 loads per thread: V <= 256 * 4 * STK_Q = 16384
 __global__ __launch_bounds__(256) void softmax_topk_rows_kernel(const float *logits, int64_t ld, int R, int V, int K, int32_t *idx,
                                                                 float *val) {
     __shared__ float sh[8];
     __shared__ float sv[4];
     __shared__ int si[4];
     const int r = blockIdx.x;
-    const float *row = logits + (int64_t)r * ld;
-    float x[STK_PT];
+    const float *row = logits + (int64_t)r * ld;  // ld % 4 == 0, 16-byte aligned rows: columns [V, ld) may be read, never used
+    float x[STK_Q][4];
+    // thread t owns columns 4 (t + 256 q) .. + 3
 #pragma unroll
-    for (int i = 0; i < STK_PT; ++i) {
-        const int v = threadIdx.x + i * 256;
-        x[i] = v < V ? row[v] : -INFINITY;
+    for (int q = 0; q < STK_Q; ++q) {
+        const int v0 = 4 * (threadIdx.x + 256 * q);
+        float4 f = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        if (v0 < V) f = *reinterpret_cast<const float4 *>(row + v0);
+        x[q][0] = f.x;
+        x[q][1] = v0 + 1 < V ? f.y : -INFINITY;
+        x[q][2] = v0 + 2 < V ? f.z : -INFINITY;
+        x[q][3] = v0 + 3 < V ? f.w : -INFINITY;
     }
     float mx = -INFINITY;
 #pragma unroll
-    for (int i = 0; i < STK_PT; ++i) mx = fmaxf(mx, x[i]);
+    for (int q = 0; q < STK_Q; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mx = fmaxf(mx, x[q][j]);
     mx = block_max(mx, sh);
     float se = 0.0f;
 #pragma unroll
-    for (int i = 0; i < STK_PT; ++i)
-        if (threadIdx.x + i * 256 < V) se += expf(x[i] - mx);
+    for (int q = 0; q < STK_Q; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) se += expf(x[q][j] - mx);  // expf(-inf) = 0 for the padding
     se = block_sum(se, sh);
     const float lse = mx + logf(se);
 #pragma unroll
-    for (int i = 0; i < STK_PT; ++i) x[i] = (threadIdx.x + i * 256 < V) ? expf(x[i] - lse) : -INFINITY;  // probabilities
+    for (int q = 0; q < STK_Q; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[q][j] = (4 * (threadIdx.x + 256 * q) + j < V) ? expf(x[q][j] - lse) : -INFINITY;  // probabilities
     for (int k = 0; k < K; ++k) {
         float bv = -INFINITY;
         int bi = 0x7FFFFFFF;
 #pragma unroll
-        for (int i = 0; i < STK_PT; ++i)
-            if (x[i] > bv) {  // increasing index: strict > keeps the lowest index among equals
-                bv = x[i];
-                bi = threadIdx.x + i * 256;
-            }
+        for (int q = 0; q < STK_Q; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (x[q][j] > bv) {  // increasing index: strict > keeps the lowest index among equals
+                    bv = x[q][j];
+                    bi = 4 * (threadIdx.x + 256 * q) + j;
+                }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const float ov = __shfl_xor(bv, o);
@@ -790,11 +803,13 @@ __global__ __launch_bounds__(256) void softmax_topk_rows_kernel(const float *log
             idx[r * K + k] = bi;
             val[r * K + k] = bv;
         }
-        if ((bi & 255) == (int)threadIdx.x) {  // the owner retires the winner
-            const int slot = bi >> 8;
+        if (((bi >> 2) & 255) == (int)threadIdx.x) {  // the owner retires the winner
+            const int slot = bi >> 10, j0 = bi & 3;
 #pragma unroll
-            for (int i = 0; i < STK_PT; ++i)
-                if (i == slot) x[i] = -INFINITY;
+            for (int q = 0; q < STK_Q; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (q == slot && j == j0) x[q][j] = -INFINITY;
         }
     }
 }
@@ -1005,7 +1020,7 @@ void k_repeat_rows(hipStream_t st, int dtype, const void *in, int64_t ld, int N,
     DISPATCH_T(dtype, hipLaunchKernelGGL(repeat_rows_kernel<T>, dim3(N * K), dim3(256), 0, st, (const T *)in, ld, N * K, K, C, (T *)out));
 }
 bool k_softmax_topk_rows(hipStream_t st, const float *logits, int64_t ld, int R, int V, int K, int32_t *idx, float *val) {
-    if (V > 256 * STK_PT || K > 32) return false;
+    if (V > 256 * 4 * STK_Q || K > 32 || (ld % 4) || (reinterpret_cast<uintptr_t>(logits) & 15)) return false;
     hipLaunchKernelGGL(softmax_topk_rows_kernel, dim3(R), dim3(256), 0, st, logits, ld, R, V, K, idx, val);
     return true;
 }
