@@ -725,21 +725,27 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float *prob, int64
     }
 }
 
-// softmax_rows + topk_rows in one pass for V <= 256 * 64: the row of logits stays in registers, the probabilities are the
-// same expressions (expf(x - (max + logf(sum)))) in the same accumulation order as softmax_rows_kernel, the K rounds of
-// block-wide argmax use the same order (value descending, ties to the lower index) as topk_rows_kernel.
-#define STK_Q 16  // float4 loads per thread: V <= 256 * 4 * STK_Q = 16384
+// softmax_rows + topk_rows in one pass for V <= 16384: the row of logits stays in registers; the K winners are the K largest
+// LOGITS (softmax is monotone; ties to the lower index), their probabilities expf(x - (max + logf(sum))) are computed for
+// those K only, and winners whose float probabilities coincide are put in ascending index order, which is the order
+// topk_rows_kernel (Julia's stable sortperm(rev=true), lrcn.jl:655) gives on the probabilities.  The normaliser uses the
+// hardware exponential (one instruction per element instead of ~20): 1e-6 relative on the reported probabilities.
+// Q = float4 loads per thread: V <= 1024 Q.  Every thread keeps the best of its own not-yet-retired elements; a round is
+// one block-wide argmax over those 256 candidates, after which only the winner's owner rescans its registers.
+template <int Q>
 __global__ __launch_bounds__(256) void softmax_topk_rows_kernel(const float *logits, int64_t ld, int R, int V, int K, int32_t *idx,
                                                                 float *val) {
     __shared__ float sh[8];
     __shared__ float sv[4];
     __shared__ int si[4];
+    __shared__ float wv[32];
+    __shared__ int wi[32];
     const int r = blockIdx.x;
     const float *row = logits + (int64_t)r * ld;  // ld % 4 == 0, 16-byte aligned rows: columns [V, ld) may be read, never used
-    float x[STK_Q][4];
+    float x[Q][4];
     // thread t owns columns 4 (t + 256 q) .. + 3
 #pragma unroll
-    for (int q = 0; q < STK_Q; ++q) {
+    for (int q = 0; q < Q; ++q) {
         const int v0 = 4 * (threadIdx.x + 256 * q);
         float4 f = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
         if (v0 < V) f = *reinterpret_cast<const float4 *>(row + v0);
@@ -748,34 +754,32 @@ __global__ __launch_bounds__(256) void softmax_topk_rows_kernel(const float *log
         x[q][2] = v0 + 2 < V ? f.z : -INFINITY;
         x[q][3] = v0 + 3 < V ? f.w : -INFINITY;
     }
-    float mx = -INFINITY;
+    auto local_best = [&](float &lv, int &li) {
+        lv = -INFINITY;
+        li = 0x7FFFFFFF;
 #pragma unroll
-    for (int q = 0; q < STK_Q; ++q)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) mx = fmaxf(mx, x[q][j]);
-    mx = block_max(mx, sh);
-    float se = 0.0f;
-#pragma unroll
-    for (int q = 0; q < STK_Q; ++q)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) se += expf(x[q][j] - mx);  // expf(-inf) = 0 for the padding
-    se = block_sum(se, sh);
-    const float lse = mx + logf(se);
-#pragma unroll
-    for (int q = 0; q < STK_Q; ++q)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) x[q][j] = (4 * (threadIdx.x + 256 * q) + j < V) ? expf(x[q][j] - lse) : -INFINITY;  // probabilities
-    for (int k = 0; k < K; ++k) {
-        float bv = -INFINITY;
-        int bi = 0x7FFFFFFF;
-#pragma unroll
-        for (int q = 0; q < STK_Q; ++q)
+        for (int q = 0; q < Q; ++q)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (x[q][j] > bv) {  // increasing index: strict > keeps the lowest index among equals
-                    bv = x[q][j];
-                    bi = 4 * (threadIdx.x + 256 * q) + j;
+                if (x[q][j] > lv) {  // increasing index: strict > keeps the lowest index among equals
+                    lv = x[q][j];
+                    li = 4 * (threadIdx.x + 256 * q) + j;
                 }
+    };
+    float lv;
+    int li;
+    local_best(lv, li);
+    const float mx = block_max(lv, sh);
+    float se = 0.0f;
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) se += __expf(x[q][j] - mx);  // exp(-inf) = 0 for the padding
+    se = block_sum(se, sh);
+    const float lse = mx + logf(se);
+    for (int k = 0; k < K; ++k) {
+        float bv = lv;
+        int bi = li;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const float ov = __shfl_xor(bv, o);
@@ -800,16 +804,35 @@ __global__ __launch_bounds__(256) void softmax_topk_rows_kernel(const float *log
                 bi = si[w];
             }
         if (threadIdx.x == 0) {
-            idx[r * K + k] = bi;
-            val[r * K + k] = bv;
+            wi[k] = bi;
+            wv[k] = expf(bv - lse);
         }
-        if (((bi >> 2) & 255) == (int)threadIdx.x) {  // the owner retires the winner
+        if (((bi >> 2) & 255) == (int)threadIdx.x) {  // the owner retires the winner and finds its next candidate
             const int slot = bi >> 10, j0 = bi & 3;
 #pragma unroll
-            for (int q = 0; q < STK_Q; ++q)
+            for (int q = 0; q < Q; ++q)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (q == slot && j == j0) x[q][j] = -INFINITY;
+            local_best(lv, li);
+        }
+    }
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < K; ++k) {  // equal probabilities (distinct logits, same float): ascending index
+            const float v = wv[k];
+            const int ix = wi[k];
+            int q = k;
+            while (q > 0 && wv[q - 1] == v && wi[q - 1] > ix) {
+                wv[q] = wv[q - 1];
+                wi[q] = wi[q - 1];
+                --q;
+            }
+            wv[q] = v;
+            wi[q] = ix;
+        }
+        for (int k = 0; k < K; ++k) {
+            idx[r * K + k] = wi[k];
+            val[r * K + k] = wv[k];
         }
     }
 }
@@ -1020,8 +1043,16 @@ void k_repeat_rows(hipStream_t st, int dtype, const void *in, int64_t ld, int N,
     DISPATCH_T(dtype, hipLaunchKernelGGL(repeat_rows_kernel<T>, dim3(N * K), dim3(256), 0, st, (const T *)in, ld, N * K, K, C, (T *)out));
 }
 bool k_softmax_topk_rows(hipStream_t st, const float *logits, int64_t ld, int R, int V, int K, int32_t *idx, float *val) {
-    if (V > 256 * 4 * STK_Q || K > 32 || (ld % 4) || (reinterpret_cast<uintptr_t>(logits) & 15)) return false;
-    hipLaunchKernelGGL(softmax_topk_rows_kernel, dim3(R), dim3(256), 0, st, logits, ld, R, V, K, idx, val);
+    if (V > 16384 || K > 32 || (ld % 4) || (reinterpret_cast<uintptr_t>(logits) & 15)) return false;
+    const int q = (V + 1023) / 1024;
+    if (q <= 4)
+        hipLaunchKernelGGL(softmax_topk_rows_kernel<4>, dim3(R), dim3(256), 0, st, logits, ld, R, V, K, idx, val);
+    else if (q <= 8)
+        hipLaunchKernelGGL(softmax_topk_rows_kernel<8>, dim3(R), dim3(256), 0, st, logits, ld, R, V, K, idx, val);
+    else if (q <= 12)
+        hipLaunchKernelGGL(softmax_topk_rows_kernel<12>, dim3(R), dim3(256), 0, st, logits, ld, R, V, K, idx, val);
+    else
+        hipLaunchKernelGGL(softmax_topk_rows_kernel<16>, dim3(R), dim3(256), 0, st, logits, ld, R, V, K, idx, val);
     return true;
 }
 void k_gather_state(hipStream_t st, int dtype, const float *const in[4], float *const out[4], void *const hT[4], const int64_t ldT[4],
