@@ -66,6 +66,7 @@ struct Conv64Args {
     const bf16_t *img16;
     const bf16_t *w11;
     const float *b11;
+    float f8_inv_scale;  // > 0 (non-pool, non-fused kernel only): write OCP e4m3(relu(acc + b) * f8_inv_scale), 8 bytes per lane
 };
 
 template <int I, int N, class F> __device__ __forceinline__ void static_for(F &&f) {
@@ -438,6 +439,25 @@ template <bool POOL, bool FUSE> __global__ __launch_bounds__(512) void conv64_ke
                         o[r2] = (bf16_t)p0;
                         o[4 + r2] = (bf16_t)p1;
                     }
+                    if constexpr (!FUSE) {
+                        if (a.f8_inv_scale > 0.0f) {  // wave-uniform: the e4m3 input of the fp8 convolution stack (fp8.hip)
+                            float q[8];
+#pragma unroll
+                            for (int r2 = 0; r2 < 4; ++r2) {
+                                q[r2] = fminf(fmaxf(u0[r2], 0.0f) * a.f8_inv_scale, 448.0f);
+                                q[4 + r2] = fminf(fmaxf(u1[r2], 0.0f) * a.f8_inv_scale, 448.0f);
+                            }
+                            uint2 o8;
+                            o8.x = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], 0, false);
+                            o8.x = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], o8.x, true);
+                            o8.y = __builtin_amdgcn_cvt_pk_fp8_f32(q[4], q[5], 0, false);
+                            o8.y = __builtin_amdgcn_cvt_pk_fp8_f32(q[6], q[7], o8.y, true);
+                            unsigned char *d8 = reinterpret_cast<unsigned char *>(a.out) + ((size_t)(n_img * H + y) * W + x) * a.Cout + cc * 64 +
+                                                wq * 32 + lq * 8;
+                            *reinterpret_cast<uint2 *>(d8) = o8;
+                            continue;
+                        }
+                    }
                     bf16_t *dst = a.out + ((size_t)(n_img * H + y) * W + x) * a.Cout + cc * 64 + wq * 32 + lq * 8;
                     *reinterpret_cast<bf16x8v *>(dst) = o;
                 }
@@ -463,7 +483,8 @@ bool conv64_eligible(int dtype, int Cin, int Cout, int H, int W) {
 }
 
 hipError_t launch_conv64(hipStream_t stream, const void *in, const void *w, const float *bias, void *out, int N, int H, int W, int Cout,
-                         int relu, int pool, const void *zero_page) {
+                         int relu, int pool, const void *zero_page, float f8_inv_scale) {
+    if (f8_inv_scale > 0.0f && (pool || !relu)) return hipErrorInvalidValue;  // e4m3 output: the non-pool ReLU epilogue only
     if (!conv64_eligible(GEMM_T_BF16, 64, Cout, H, W) || !in || !w || !out || !zero_page || N < 1) return hipErrorInvalidValue;
     if ((int64_t)N * H * W * 64 >= (1ll << 31)) return hipErrorInvalidValue;  // 32-bit element offsets into the input
     Conv64Args a{};
@@ -473,6 +494,7 @@ hipError_t launch_conv64(hipStream_t stream, const void *in, const void *w, cons
     a.out = reinterpret_cast<bf16_t *>(out);
     a.zero_page = zero_page;
     a.N = N; a.H = H; a.W = W; a.Cout = Cout; a.relu = relu;
+    a.f8_inv_scale = f8_inv_scale;
     a.tiles_y = H / 16; a.tiles_x = W / 16; a.ntiles = N * a.tiles_y * a.tiles_x;
     const int chunks = Cout / 64;
     int gx = 256 / chunks;  // one workgroup per CU (all of LDS)

@@ -989,9 +989,13 @@ bool conv64_enabled() {
     const char *k = getenv("LRCN_CONV64");  // LRCN_CONV64=0 routes the Cin = 64 layers back to the implicit-GEMM kernels
     return !(k && k[0] == '0');
 }
-int conv_layer(lrcn_ctx *c, int dtype, const void *in, const VggLayer &L, int N, void *out) {
+// f8_inv_scale > 0: write e4m3(out * f8_inv_scale) if the layer's kernel can (returns *wrote_f8), else bf16 as usual
+int conv_layer(lrcn_ctx *c, int dtype, const void *in, const VggLayer &L, int N, void *out, float f8_inv_scale = 0.0f, bool *wrote_f8 = nullptr) {
+    if (wrote_f8) *wrote_f8 = false;
     if (conv64_enabled() && conv64_eligible(dtype, L.Cin, L.Cout, L.S, L.S)) {
-        hipError_t e = launch_conv64(c->stream, in, L.w, L.b, out, N, L.S, L.S, L.Cout, 1, L.pool, c->zero_page);
+        const bool f8 = f8_inv_scale > 0.0f && !L.pool;
+        if (wrote_f8) *wrote_f8 = f8;
+        hipError_t e = launch_conv64(c->stream, in, L.w, L.b, out, N, L.S, L.S, L.Cout, 1, L.pool, c->zero_page, f8 ? f8_inv_scale : 0.0f);
         if (e != hipSuccess) FAIL(c, LRCN_EHIP, "conv64 layer S=%d Cout=%d: %s", L.S, L.Cout, hipGetErrorString(e));
         return LRCN_OK;
     }
@@ -1110,12 +1114,17 @@ int vgg_body(lrcn_ctx *c, int N, const void *src, bool src_u8, const float *mean
         const int64_t So = L.pool ? L.S / 2 : L.S;
         return (int64_t)N * So * So * L.Cout;
     };
+    bool in_is_f8 = false;
     for (int l = l0; l < 13; ++l) {
-        if (fp8 && l == kFp8First) {  // conv2_1's bf16 output -> e4m3 (one elementwise pass; everything after stays e4m3)
+        if (fp8 && l == kFp8First && !in_is_f8) {  // conv2_1 ran on a kernel without the e4m3 epilogue: one elementwise pass
             k_cast_bf16_fp8(c->stream, cur, out_count(l - 1), 1.0f / c->act_scale[l - 1], nxt);
             std::swap(cur, nxt);
         }
-        int r = (fp8 && l >= kFp8First) ? conv_layer_fp8(c, cur, c->conv[l], N, nxt) : conv_layer(c, vdt, cur, c->conv[l], N, nxt);
+        int r;
+        if (fp8 && l >= kFp8First)
+            r = conv_layer_fp8(c, cur, c->conv[l], N, nxt);
+        else  // conv2_1 writes the e4m3 input of conv2_2 directly when it runs on conv64.hip
+            r = conv_layer(c, vdt, cur, c->conv[l], N, nxt, (fp8 && l == kFp8First - 1) ? 1.0f / c->act_scale[l] : 0.0f, &in_is_f8);
         if (r) return r;
         std::swap(cur, nxt);
         if (calibrate && l >= kFp8First - 1) k_amax(c->stream, 0, cur, out_count(l), c->amax_dev + l);
