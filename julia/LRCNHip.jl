@@ -116,7 +116,7 @@ end
 grad_group_wait(ctx, g, stream) = check(ctx, ccall((:lrcn_grad_group_wait, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}), ctx.h, g, stream))
 
 # vgg_dtype = LRCN_FP8 contexts: fix the e4m3 activation scales from one bf16 pass over uint8 crops img[c, col, row, n]   (new entry point)
-vgg_calibrate(ctx, img::Array{UInt8,4}, mean::Vector{Cfloat}; margin = 1.25f0) = check(ctx, ccall((:lrcn_vgg_calibrate, lib), Cint,
+vgg_calibrate(ctx, img, mean::Vector{Cfloat}; margin = 1.25f0) = check(ctx, ccall((:lrcn_vgg_calibrate, lib), Cint,
     (Ptr{Cvoid}, Ptr{UInt8}, Cint, Ptr{Cfloat}, Cfloat), ctx.h, pointer(img), size(img, 4), mean, margin))
 
 end # module

@@ -130,17 +130,16 @@ __global__ void concat_x2_kernel(T *x2, int64_t ld_x2, const float *xcnn, int64_
 
 template <typename T>
 __global__ void dx2_mask_reduce_kernel(T *dx2, int64_t ld, int S, int B, int h, DropSpec d, float *dxcnn, int64_t ld_dxc) {
-    const int b = blockIdx.x;
-    for (int j = threadIdx.x; j < 2 * h; j += blockDim.x) {
-        float acc = 0.0f;
-        for (int s = 0; s < S; ++s) {
-            T *p = dx2 + (int64_t)(s * B + b) * ld + j;
-            const float v = to_f32(*p) * drop_mult(d, s, b, j, B, 2 * h);
-            *p = from_f32<T>(v);
-            acc += v;
-        }
-        if (j >= h) dxcnn[(int64_t)b * ld_dxc + (j - h)] = acc;
+    const int b = blockIdx.x, j = blockIdx.y * blockDim.x + threadIdx.x;
+    if (j >= 2 * h) return;
+    float acc = 0.0f;
+    for (int s = 0; s < S; ++s) {
+        T *p = dx2 + (int64_t)(s * B + b) * ld + j;
+        const float v = to_f32(*p) * drop_mult(d, s, b, j, B, 2 * h);
+        *p = from_f32<T>(v);
+        acc += v;
     }
+    if (j >= h) dxcnn[(int64_t)b * ld_dxc + (j - h)] = acc;
 }
 
 __device__ __forceinline__ float wave_max(float v) {
@@ -198,6 +197,71 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel(const float *logits, 
     }
 }
 
+template <typename T> __device__ __forceinline__ void store4(T *p, const float *v) {
+    struct alignas(4 * sizeof(T)) V4 { T e[4]; };
+    V4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o.e[k] = from_f32<T>(v[k]);
+    *reinterpret_cast<V4 *>(p) = o;
+}
+
+// The same for V <= 1024 Q with the row held in registers: one expf per element (e = expf(x - max), p = e / sum) instead of
+// two, 16-byte loads; the log-likelihood term is unchanged (x[t] - (max + logf(sum))).
+template <typename T, int Q>
+__global__ __launch_bounds__(256) void softmax_xent_reg_kernel(const float *logits, int64_t ld_l, const int32_t *tgt, int M, int V,
+                                                               float scale, double *logp_sum, T *dlog, int64_t ld_d) {
+    __shared__ float sh[8];
+    const int m = blockIdx.x;
+    const float *row = logits + (int64_t)m * ld_l;  // ld_l % 4 == 0, 16-byte aligned rows
+    float x[Q][4];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int v0 = 4 * (threadIdx.x + 256 * q);
+        float4 f = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        if (v0 < V) f = *reinterpret_cast<const float4 *>(row + v0);
+        x[q][0] = f.x;
+        x[q][1] = v0 + 1 < V ? f.y : -INFINITY;
+        x[q][2] = v0 + 2 < V ? f.z : -INFINITY;
+        x[q][3] = v0 + 3 < V ? f.w : -INFINITY;
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mx = fmaxf(mx, x[q][j]);
+    mx = block_max(mx, sh);
+    float se = 0.0f;
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            x[q][j] = expf(x[q][j] - mx);  // 0 for the padding
+            se += x[q][j];
+        }
+    se = block_sum(se, sh);
+    const int t = tgt[m];
+    if (threadIdx.x == 0) atomicAdd(logp_sum, (double)(row[t] - (mx + logf(se))));
+    if (dlog) {
+        T *drow = dlog + (int64_t)m * ld_d;
+        const float inv = 1.0f / se;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int v0 = 4 * (threadIdx.x + 256 * q);
+            if (v0 >= V) continue;
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (x[q][j] * inv - (v0 + j == t ? 1.0f : 0.0f)) * scale;
+            if (v0 + 3 < V && (ld_d % 4) == 0) {
+                store4(drow + v0, o);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (v0 + j < V) drow[v0 + j] = from_f32<T>(o[j]);
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float *logits, int64_t ld_l, int M, int V, float *prob,
                                                            int64_t ld_p) {
     __shared__ float sh[8];
@@ -246,14 +310,6 @@ __global__ void transpose_kernel(const Tin *in, int64_t ld_in, int R, int C, Tou
 // All shadow weights of one model in ONE launch (was 8 cast_rows + 9 transpose launches per step): for every 32 x 32 tile of
 // a parameter's memory image [R][C] (f32) write the direct copy split at column `cs` (dA[r][c], dB[r][c - cs]) and / or the
 // transposed copy (tA[c][r], tB[c - cs][r]) in T.  Padding columns of the destinations are never touched (zero since allocation).
-template <typename T> __device__ __forceinline__ void store4(T *p, const float *v) {
-    struct alignas(4 * sizeof(T)) V4 { T e[4]; };
-    V4 o;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) o.e[k] = from_f32<T>(v[k]);
-    *reinterpret_cast<V4 *>(p) = o;
-}
-
 template <typename T> __global__ __launch_bounds__(256) void prepare_weights_kernel(const PrepPlan plan) {
     // 64 x 64 tiles, 16 bytes in / 8 bytes out per thread access (bf16); generic element-wise path for f32 shadows and edges
     __shared__ float tile[64][65];
@@ -909,11 +965,26 @@ void k_concat_x2(hipStream_t st, int dtype, void *x2, int64_t ld_x2, const float
 }
 void k_dx2_mask_reduce(hipStream_t st, int dtype, void *dx2, int64_t ld, int S, int B, int h, DropSpec d, float *dxcnn,
                        int64_t ld_dxc) {
-    DISPATCH_T(dtype, hipLaunchKernelGGL(dx2_mask_reduce_kernel<T>, dim3(B), dim3(256), 0, st, (T *)dx2, ld, S, B, h, d,
+    DISPATCH_T(dtype, hipLaunchKernelGGL(dx2_mask_reduce_kernel<T>, dim3(B, cdiv(2 * h, 256)), dim3(256), 0, st, (T *)dx2, ld, S, B, h, d,
                                          dxcnn, ld_dxc));
 }
 void k_softmax_xent(hipStream_t st, int dtype, const float *logits, int64_t ld_l, const int32_t *tgt, int M, int V,
                     float scale, double *logp_sum, void *dlog, int64_t ld_d) {
+    const bool reg = V <= 16384 && (ld_l % 4) == 0 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0 &&
+                     (reinterpret_cast<uintptr_t>(dlog) & 15) == 0;
+    if (reg) {
+        const int q = (V + 1023) / 1024;
+#define SX_LAUNCH(QQ)                                                                                                              \
+    DISPATCH_T(dtype, hipLaunchKernelGGL((softmax_xent_reg_kernel<T, QQ>), dim3(M), dim3(256), 0, st, logits, ld_l, tgt, M, V, scale, \
+                                         logp_sum, (T *)dlog, ld_d))
+        if (q <= 2) SX_LAUNCH(2);
+        else if (q <= 4) SX_LAUNCH(4);
+        else if (q <= 8) SX_LAUNCH(8);
+        else if (q <= 12) SX_LAUNCH(12);
+        else SX_LAUNCH(16);
+#undef SX_LAUNCH
+        return;
+    }
     DISPATCH_T(dtype, hipLaunchKernelGGL(softmax_xent_kernel<T>, dim3(M), dim3(256), 0, st, logits, ld_l, tgt, M, V, scale,
                                          logp_sum, (T *)dlog, ld_d));
 }
