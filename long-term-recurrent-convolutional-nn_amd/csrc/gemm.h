@@ -21,6 +21,7 @@ struct GemmArgs {
     const float *scale; // GEMM_T_F8: per-output-column multiplier applied to the accumulator before the bias (dequant x requant)
     int c_f32;
     int beta;       // 1: C += result (reads C)
+    int c_is_zero;  // caller guarantees C holds zeros: a split-K-by-atomics kernel may skip its own memset
     int relu;
     int a_mode, out_mode;
     int H, W, Cin;  // conv geometry (square-agnostic; H, W even)

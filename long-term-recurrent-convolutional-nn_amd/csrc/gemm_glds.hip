@@ -394,7 +394,7 @@ template <int AMODE> hipError_t dispatch(hipStream_t s, const GemmArgs &g) {
     int64_t blocks = 0;
     const int cfg = choose_cfg(g, &blocks);
     const int sk = (AMODE == GEMM_A_PLAIN) ? choose_splitk(g, blocks) : 1;
-    if (sk > 1 && !g.beta) {
+    if (sk > 1 && !g.beta && !g.c_is_zero) {
         hipError_t e = hipMemsetAsync(g.C, 0, sizeof(float) * (size_t)g.M * g.N, s);
         if (e != hipSuccess) return e;
     }

@@ -28,7 +28,7 @@ void k_lstm_fwd(hipStream_t st, int dtype, const float *G, int64_t ld_g, const f
 // Reverse of the cell.  dh_a (+ dh_b, may be NULL) f32 [B][H]; dc f32 [B][H] is read and replaced by
 // dc_prev.  Writes dZ (T) [B][4H].
 void k_lstm_bwd(hipStream_t st, int dtype, const void *acts, int64_t ld_a, const float *c_prev, const float *c_new,
-                const float *dh_a, int64_t ld_dha, const float *dh_b, float *dc, int dc_zero, int B, int H, void *dz,
+                const float *dh_a, int64_t ld_dha, float *dh_b, int dh_b_read, float *dc, int dc_zero, int B, int H, void *dz,
                 int64_t ld_dz);
 
 // Small-batch fused recurrent steps (lstm_fused.hip; bf16, B <= 64): one launch = the recurrent GEMM of a timestep + the cell

@@ -151,7 +151,7 @@ inline const char *boff(const void *p, int64_t elems, size_t esz) {
 
 // C[M][N] (+)= A[M][K] * B[N][K]^T
 int gemm(lrcn_ctx *c, int dtype, const void *A, int64_t lda, const void *B, int64_t ldb, void *C, int64_t ldc, int M, int N,
-         int K, const float *bias, bool c_f32, bool beta = false, bool relu = false) {
+         int K, const float *bias, bool c_f32, bool beta = false, bool relu = false, bool c_is_zero = false) {
     GemmArgs g{};
     g.dtype = dtype;
     g.A = A;
@@ -168,6 +168,7 @@ int gemm(lrcn_ctx *c, int dtype, const void *A, int64_t lda, const void *B, int6
     g.bias = bias;
     g.c_f32 = c_f32;
     g.beta = beta;
+    g.c_is_zero = c_is_zero;
     g.relu = relu;
     g.a_mode = GEMM_A_PLAIN;
     g.out_mode = GEMM_OUT_PLAIN;
@@ -263,7 +264,7 @@ int lstm_layer_bwd(lrcn_ctx *c, int S, int B, int H, int64_t ld4H, const void *a
     if (lstm_fused_on(c, B, H, round_up64(H, 64), ld4H)) {
         // cell backward of the last step, then one launch per step: dh_rec = dZ[s] Wh fused with the cell backward of s-1
         k_lstm_bwd(c->stream, dt, boff(acts, (int64_t)(S - 1) * B * ld4H, c->esz), ld4H, S > 1 ? Call + (int64_t)(S - 2) * B * H : nullptr,
-                   Call + (int64_t)(S - 1) * B * H, dHall + (int64_t)(S - 1) * B * H, H, nullptr, c->dc, 1, B, H,
+                   Call + (int64_t)(S - 1) * B * H, dHall + (int64_t)(S - 1) * B * H, H, nullptr, 0, c->dc, 1, B, H,
                    boff(dZ, (int64_t)(S - 1) * B * ld4H, c->esz), ld4H);
         for (int s = S - 1; s >= 1; --s) {
             hipError_t e = launch_lstm_rec_bwd(c->stream, boff(dZ, (int64_t)s * B * ld4H, c->esz), ld4H, WhT,
@@ -277,10 +278,10 @@ int lstm_layer_bwd(lrcn_ctx *c, int S, int B, int H, int64_t ld4H, const void *a
     }
     for (int s = S - 1; s >= 0; --s) {
         k_lstm_bwd(c->stream, dt, boff(acts, (int64_t)s * B * ld4H, c->esz), ld4H, s ? Call + (int64_t)(s - 1) * B * H : nullptr,
-                   Call + (int64_t)s * B * H, dHall + (int64_t)s * B * H, H, (s < S - 1) ? c->dhrec : nullptr, c->dc, s == S - 1, B, H,
+                   Call + (int64_t)s * B * H, dHall + (int64_t)s * B * H, H, c->dhrec, s < S - 1, c->dc, s == S - 1, B, H,
                    boff(dZ, (int64_t)s * B * ld4H, c->esz), ld4H);
-        if (s > 0)  // dh_prev = dZ[s] * Wh'   (Wh' K-contiguous = WhT [H][ld4H])
-            GEMM(c, dt, boff(dZ, (int64_t)s * B * ld4H, c->esz), ld4H, WhT, ld4H, c->dhrec, H, B, H, 4 * H, nullptr, true);
+        if (s > 0)  // dh_prev = dZ[s] * Wh'   (Wh' K-contiguous = WhT [H][ld4H]); dhrec was zeroed by the cell kernel above
+            GEMM(c, dt, boff(dZ, (int64_t)s * B * ld4H, c->esz), ld4H, WhT, ld4H, c->dhrec, H, B, H, 4 * H, nullptr, true, false, false, true);
     }
     KCHK(c, "lstm_layer_bwd");
     return LRCN_OK;
