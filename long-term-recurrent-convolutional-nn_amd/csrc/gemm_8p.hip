@@ -274,26 +274,32 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs g) {
         if (grp == 1) __builtin_amdgcn_s_barrier();  // stagger
     }
     KStep kn = kstep_of(kbeg + (KT > 1 ? 1 : 0));  // tile t+1
+    const bool late_wait = !(g.dbg & 4);  // LRCN_DBG=4: the single wait per K-tile (two phases of latency budget)
     for (int t = 0; t < KT; ++t) {
         const int cur = t & 1, nxt = cur ^ 1;
         const bool live1 = t + 1 < KT, live2 = t + 2 < KT;
         const KStep k2 = kstep_of(kbeg + (live2 ? t + 2 : 0));
-        // phase 0: quadrant (0,0)
+        // Every half-tile is retired ONE phase before its first read (the barrier after the wait publishes it), i.e. four
+        // phases after its DMA was issued: the four younger half-tiles stay in flight across each wait.
+        // phase 0: quadrant (0,0); retire B1 of this tile (read in phase 1)
         read_a(cur, I0);
         read_b(cur, I0, bf0);
         stage_b(nxt, 1, kn, live1);
+        if (late_wait) wait_vmcnt<2 * (APW + BPW)>();
         MFMA_QUADRANT(0, 0, bf0);
-        // phase 1: quadrant (0,1)
+        // phase 1: quadrant (0,1); retire A1 of this tile (read in phase 2)
         read_b(cur, I1, bf1);
         stage_a(nxt, 1, kn, live1);
+        if (late_wait) wait_vmcnt<2 * (APW + BPW)>();
         MFMA_QUADRANT(0, 1, bf1);
         // phase 2: quadrant (1,1)
         read_a(cur, I1);
         stage_a(cur, 0, k2, live2);
         MFMA_QUADRANT(1, 1, bf1);
-        // phase 3: quadrant (1,0); retire everything of tile t+1 (leaves A0, B0 of tile t+2 in flight)
+        // phase 3: quadrant (1,0); retire A0, B0 of tile t+1 (read in its phase 0)
         stage_b(cur, 0, k2, live2);
-        wait_vmcnt<APW + BPW>();
+        if (late_wait) wait_vmcnt<2 * (APW + BPW)>();
+        else wait_vmcnt<APW + BPW>();
         MFMA_QUADRANT(1, 0, bf0);
         kn = k2;
     }
@@ -663,7 +669,10 @@ hipError_t launch_splitk_reduce(hipStream_t stream, const GemmArgs &g, int split
     return hipGetLastError();
 }
 
-hipError_t launch_gemm_8p(hipStream_t stream, const GemmArgs &g, int splitk) {
+hipError_t launch_gemm_8p(hipStream_t stream, const GemmArgs &g0, int splitk) {
+    GemmArgs g = g0;
+    static const char *dbg = getenv("LRCN_DBG");  // kernel-development ablation flags (gemm.h)
+    g.dbg = dbg ? atoi(dbg) : 0;
     int64_t blocks = 0;
     int cfg = gemm_8p_config(g, &blocks);
     if (cfg < 0) return hipErrorInvalidValue;
