@@ -40,8 +40,9 @@ def build_parser():
     p.add_argument("--lr", type=float, default=0.001, help="Adam learning rate (the reference always ran 0.001).")
     p.add_argument("--gclip", type=float, default=0.0, help="Gradient-norm clip (0 = off, as in the reference).")
     p.add_argument("--seed", type=int, default=-1)
-    p.add_argument("--atype", default="bf16", choices=["bf16", "f32", "KnetArray{Float32}", "Array{Float32}"],
-                   help="arithmetic type of the LSTM/VGG kernels (the reference's array-type strings select f32)")
+    p.add_argument("--atype", default="bf16", choices=["bf16", "f32", "fp8", "KnetArray{Float32}", "Array{Float32}"],
+                   help="arithmetic type of the LSTM/VGG kernels (the reference's array-type strings select f32; fp8 = e4m3 "
+                        "conv2_2..conv5_3 for --generate / --extfeatures, calibrated on the first batch of crops, bf16 elsewhere)")
     p.add_argument("--train", action="store_true")
     p.add_argument("--cnn", action="store_true", help="load the VGG-16 weights")
     p.add_argument("--extfeatures", action="store_true", help="extract fc7 features for the first caption file's images")
@@ -89,6 +90,9 @@ def main(argv=None):
         np.random.seed(o.seed)
     rng = np.random.default_rng(o.seed if o.seed > 0 else None)
     dt = lrcn_amd.LRCN_F32 if o.atype in ("f32", "KnetArray{Float32}", "Array{Float32}") else lrcn_amd.LRCN_BF16
+    vdt = lrcn_amd.LRCN_FP8 if o.atype == "fp8" else dt
+    if vdt == lrcn_amd.LRCN_FP8 and o.train and o.cnn:
+        raise SystemExit("--atype fp8 is the caption-generation / feature-extraction precision; train with bf16 or f32")
     vocab, lists = None, []
     if o.datafiles:
         print("Tokenization starts")
@@ -107,7 +111,7 @@ def main(argv=None):
         raise SystemExit("--hidden takes two sizes, the second even (LRCN-2f, lrcn.jl:496-504)")
     H1, H2 = o.hidden
     gen_chunk = 64  # images decoded together by the batched beam search
-    ctx = L.Context(o.embed, H1, H2, V, max_B=max(o.batchsize, o.beam_width * (gen_chunk if o.generate > 0 else 1), 10), lstm_dtype=dt, vgg_dtype=dt,
+    ctx = L.Context(o.embed, H1, H2, V, max_B=max(o.batchsize, o.beam_width * (gen_chunk if o.generate > 0 else 1), 10), lstm_dtype=dt, vgg_dtype=vdt,
                     max_images=max(o.batchsize, 1) if o.cnn else 0)
     param = L.initweights(ctx, seed=o.seed if o.seed > 0 else 42) if host_model is None else L.model_from_arrays(host_model)
     print("LSTM is initialized")
@@ -131,6 +135,8 @@ def main(argv=None):
         if o.cnn:
             from PIL import Image
             crop = fmt.center_crop_224(Image.open(o.image))
+            if vdt == lrcn_amd.LRCN_FP8:
+                L.vgg_calibrate(ctx, torch.as_tensor(crop[None]).cuda(), mean=mean)
             f = L.from_jl(L.convnet_u8(ctx, torch.as_tensor(crop[None]).cuda(), mean=mean))[0]
             toks, _ = L.beam_search(ctx, param, L.to_jl((f / f.sum())[None].astype(np.float32)), o.beam_width, o.generate)
             print(cap.caption_text(toks, idx2word))
@@ -163,6 +169,8 @@ def main(argv=None):
             chunk = ids[s:s + B]
             crops = np.stack([fmt.center_crop_224(Image.open(os.path.join(o.imagedir, "%s%012d.jpg" % (o.prefix, i) if o.prefix
                                                                         else "%d.jpg" % i))) for i in chunk])
+            if vdt == lrcn_amd.LRCN_FP8 and s == 0:  # activation scales of the e4m3 layers from the first batch
+                L.vgg_calibrate(ctx, torch.as_tensor(crops).cuda(), mean=mean)
             f = L.from_jl(L.convnet_u8(ctx, torch.as_tensor(crops).cuda(), mean=mean))
             for i, row in zip(chunk, f):
                 table[i] = row.copy()
