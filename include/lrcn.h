@@ -63,6 +63,10 @@ int lrcn_create(const lrcn_config *cfg, lrcn_ctx **out);
 void lrcn_destroy(lrcn_ctx *ctx);
 const char *lrcn_last_error(const lrcn_ctx *ctx); /* ctx may be NULL: last creation error */
 int lrcn_set_stream(lrcn_ctx *ctx, void *hip_stream);  /* hipStream_t; NULL = null stream */
+/* Cap the grids of the VGG convolution kernels at `cap` workgroups (0 = one per tile / CU): the kernels then walk their
+ * tiles persistently.  The data-parallel step sets a cap below the CU count at small per-GPU batches so that the LSTM
+ * stream's chain of small dependent launches finds idle CUs while the VGG forward of the next step runs beside it. */
+int lrcn_vgg_set_wg_cap(lrcn_ctx *ctx, int cap);
 int lrcn_sync(lrcn_ctx *ctx);
 int lrcn_malloc(void **dev_ptr, size_t bytes);
 int lrcn_free(void *dev_ptr);

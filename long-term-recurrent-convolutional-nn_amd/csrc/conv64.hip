@@ -483,7 +483,7 @@ bool conv64_eligible(int dtype, int Cin, int Cout, int H, int W) {
 }
 
 hipError_t launch_conv64(hipStream_t stream, const void *in, const void *w, const float *bias, void *out, int N, int H, int W, int Cout,
-                         int relu, int pool, const void *zero_page, float f8_inv_scale) {
+                         int relu, int pool, const void *zero_page, float f8_inv_scale, int wg_cap) {
     if (f8_inv_scale > 0.0f && (pool || !relu)) return hipErrorInvalidValue;  // e4m3 output: the non-pool ReLU epilogue only
     if (!conv64_eligible(GEMM_T_BF16, 64, Cout, H, W) || !in || !w || !out || !zero_page || N < 1) return hipErrorInvalidValue;
     if ((int64_t)N * H * W * 64 >= (1ll << 31)) return hipErrorInvalidValue;  // 32-bit element offsets into the input
@@ -497,7 +497,8 @@ hipError_t launch_conv64(hipStream_t stream, const void *in, const void *w, cons
     a.f8_inv_scale = f8_inv_scale;
     a.tiles_y = H / 16; a.tiles_x = W / 16; a.ntiles = N * a.tiles_y * a.tiles_x;
     const int chunks = Cout / 64;
-    int gx = 256 / chunks;  // one workgroup per CU (all of LDS)
+    int gx = (wg_cap >= 8 ? wg_cap : 256) / chunks;  // one workgroup per CU (all of LDS); capped: leaves CUs to the other stream
+    if (gx < 1) gx = 1;
     if (gx > a.ntiles) gx = a.ntiles;
     static bool attr_done[2] = {false, false};
     auto kern = pool ? conv64_kernel<true, false> : conv64_kernel<false, false>;
@@ -514,7 +515,7 @@ hipError_t launch_conv64(hipStream_t stream, const void *in, const void *w, cons
 // FUSE note at the top.  w11 = conv1_1 weights [64][32] in
 // the k' order (k_repack_conv11_w_fused), S = crop size (multiple of 16), out = pooled NHWC [N][S/2][S/2][64].
 hipError_t launch_conv64_fused11(hipStream_t stream, const void *img16, const void *w11, const float *b11, const void *w,
-                                 const float *bias, void *out, int N, int S, const void *zero_page) {
+                                 const float *bias, void *out, int N, int S, const void *zero_page, int wg_cap) {
     if (!img16 || !w11 || !b11 || !w || !out || !zero_page || N < 1 || S < 16 || (S % 16)) return hipErrorInvalidValue;
     if ((int64_t)N * S * S * 3 >= (1ll << 31)) return hipErrorInvalidValue;
     Conv64Args a{};
@@ -527,7 +528,7 @@ hipError_t launch_conv64_fused11(hipStream_t stream, const void *img16, const vo
     a.img16 = reinterpret_cast<const bf16_t *>(img16);
     a.w11 = reinterpret_cast<const bf16_t *>(w11);
     a.b11 = b11;
-    int gx = 256;
+    int gx = wg_cap >= 8 ? wg_cap : 256;
     if (gx > a.ntiles) gx = a.ntiles;
     static bool attr_done = false;
     auto kern = conv64_kernel<true, true>;

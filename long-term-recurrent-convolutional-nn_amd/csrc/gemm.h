@@ -25,6 +25,7 @@ struct GemmArgs {
     int relu;
     int a_mode, out_mode;
     int H, W, Cin;  // conv geometry (square-agnostic; H, W even)
+    int wg_cap;             // > 0: at most this many workgroups (gemm_8p.hip / conv64.hip walk the tiles persistently)
     int dbg;                // kernel-development ablation flags (LRCN_DBG env): 1 = skip steady-state DMA, 2 = skip LDS reads + MFMA
     const void *zero_page;  // >= 256 zero bytes, 16-byte aligned (source of padding rows for the direct-to-LDS path) or NULL
     void *ws;               // split-K workspace (f32 slabs [slices][M][N]) or NULL: enables gemm_8p's split-K form
@@ -57,7 +58,7 @@ hipError_t launch_gemm_skinny(hipStream_t stream, const GemmArgs &g);
 bool conv64_eligible(int dtype, int Cin, int Cout, int H, int W);
 // f8_inv_scale > 0 (ReLU, no pool): the output is OCP e4m3(relu(.) * f8_inv_scale) instead of bf16
 hipError_t launch_conv64(hipStream_t stream, const void *in, const void *w, const float *bias, void *out, int N, int H, int W, int Cout,
-                         int relu, int pool, const void *zero_page, float f8_inv_scale = 0.0f);
+                         int relu, int pool, const void *zero_page, float f8_inv_scale = 0.0f, int wg_cap = 0);
 // conv1_1 + conv1_2 (+ pool) fused, from mean-subtracted bf16 crops (conv64.hip FUSE): w11 from k_repack_conv11_w_fused
 hipError_t launch_conv64_fused11(hipStream_t stream, const void *img16, const void *w11, const float *b11, const void *w,
-                                 const float *bias, void *out, int N, int S, const void *zero_page);
+                                 const float *bias, void *out, int N, int S, const void *zero_page, int wg_cap = 0);

@@ -68,7 +68,7 @@ __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float 
 // v_mfma_f32_16x16x128_f8f6f4 replaces two v_mfma_f32_16x16x32_bf16 (same cycles, twice the K), the staged epilogue
 // multiplies by g.scale[col] before the bias and writes e4m3.
 template <int WM, int WN, int MT, int NT, int AMODE, bool SWAP, bool F8>
-__global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs g) {
+__device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *smem, const int tile, const int ntiles_xy) {
     using elem_t = std::conditional_t<F8, unsigned char, bf16_t>;
     constexpr int ES = F8 ? 1 : 2;       // bytes per element
     constexpr int KE = 128 / ES;         // elements per K-tile
@@ -82,17 +82,16 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs g) {
     static_assert(APW >= 1 && BPW >= 1 && APW * 128 == BM && BPW * 128 == BN, "tile must be a multiple of 128");
     constexpr int CPR = BN / 8;                     // 16-byte chunks per staged C row
     static_assert(CPR >= 16, "epilogue swizzle needs >= 16 chunks per row");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WN, wc = wave % WN;
     const int grp = wave >> 2;  // waves 4..7 run one barrier behind waves 0..3
     const int M = g.M, N = g.N;
     const int tiles_n = (N + BN - 1) / BN;
-    int bid = blockIdx.x;
+    int bid = tile;
     {   // bijective XCD renumbering: the N-tiles of one im2col panel (consecutive logical ids) share an XCD's L2
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        // (workgroup w sits on XCD w % 8 and visits tiles w, w + G, ...: tile % 8 == w % 8 as long as 8 divides G)
+        const int nwg = ntiles_xy, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
     const int nt = bid % tiles_n, mt = bid / tiles_n;
@@ -552,6 +551,20 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs g) {
                 }
 }
 
+// One workgroup per output tile, or -- g.wg_cap > 0 -- a capped, persistent grid that walks the tiles: the data-parallel
+// step caps the convolution grids below the CU count at small per-GPU batches so that the LSTM stream's chain of small
+// dependent launches always finds idle CUs (DESIGN.md "Stream structure").
+template <int WM, int WN, int MT, int NT, int AMODE, bool SWAP, bool F8>
+__global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
+    const int ntiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        gemm8p_tile<WM, WN, MT, NT, AMODE, SWAP, F8>(g, smem, tile, ntiles);
+        if (tile + (int)gridDim.x < ntiles) __syncthreads();  // the staged output tile / ring are reused by the next tile
+    }
+}
+
 template <int WM, int WN, int MT, int NT, int AMODE, bool SWAP, bool F8 = false> hipError_t launch_one(hipStream_t s, const GemmArgs &g, int splitk) {
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
     constexpr int ring = 2 * (BM + BN) * 128, ctile = BM * BN * 2;
@@ -566,7 +579,9 @@ template <int WM, int WN, int MT, int NT, int AMODE, bool SWAP, bool F8 = false>
     }
     const int64_t blocks = (int64_t)cdiv(g.M, BM) * cdiv(g.N, BN);
     if (blocks <= 0 || blocks > 0x7FFFFFFF) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)splitk), dim3(512), lds, s, g);
+    int64_t grid = blocks;
+    if (g.wg_cap >= 8 && grid > g.wg_cap) grid = g.wg_cap & ~7;  // a multiple of 8 keeps tile -> XCD stable
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)splitk), dim3(512), lds, s, g);
     return hipGetLastError();
 }
 

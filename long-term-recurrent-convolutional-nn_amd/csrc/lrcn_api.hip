@@ -83,6 +83,7 @@ struct lrcn_ctx {
             *bs_res_len = nullptr;
     float *bs_p = nullptr, *bs_res_p = nullptr;
     // VGG
+    int vgg_wg_cap = 0;  // > 0: cap on the convolution grids (lrcn_vgg_set_wg_cap)
     bool vgg_loaded = false;
     bool vgg_fp8 = false, fp8_ready = false;  // LRCN_FP8: conv2_2..conv5_3 in e4m3 once lrcn_vgg_calibrate has run
     float *amax_dev = nullptr;                // [13] per-layer output amax collected by the calibration pass
@@ -618,6 +619,13 @@ int lrcn_create(const lrcn_config *cfg, lrcn_ctx **out) {
     return LRCN_OK;
 }
 
+int lrcn_vgg_set_wg_cap(lrcn_ctx *c, int cap) {
+    if (!c) return LRCN_EINVAL;
+    if (cap < 0 || (cap > 0 && cap < 8)) FAIL(c, LRCN_EINVAL, "wg_cap=%d must be 0 (off) or >= 8", cap);
+    c->vgg_wg_cap = cap;
+    return LRCN_OK;
+}
+
 int lrcn_set_stream(lrcn_ctx *c, void *s) {
     if (!c) return LRCN_EINVAL;
     c->stream = reinterpret_cast<hipStream_t>(s);
@@ -996,7 +1004,7 @@ int conv_layer(lrcn_ctx *c, int dtype, const void *in, const VggLayer &L, int N,
     if (conv64_enabled() && conv64_eligible(dtype, L.Cin, L.Cout, L.S, L.S)) {
         const bool f8 = f8_inv_scale > 0.0f && !L.pool;
         if (wrote_f8) *wrote_f8 = f8;
-        hipError_t e = launch_conv64(c->stream, in, L.w, L.b, out, N, L.S, L.S, L.Cout, 1, L.pool, c->zero_page, f8 ? f8_inv_scale : 0.0f);
+        hipError_t e = launch_conv64(c->stream, in, L.w, L.b, out, N, L.S, L.S, L.Cout, 1, L.pool, c->zero_page, f8 ? f8_inv_scale : 0.0f, c->vgg_wg_cap);
         if (e != hipSuccess) FAIL(c, LRCN_EHIP, "conv64 layer S=%d Cout=%d: %s", L.S, L.Cout, hipGetErrorString(e));
         return LRCN_OK;
     }
@@ -1019,6 +1027,7 @@ int conv_layer(lrcn_ctx *c, int dtype, const void *in, const VggLayer &L, int N,
     g.zero_page = c->zero_page;
     g.ws = c->gemm_ws;
     g.ws_bytes = c->gemm_ws_bytes;
+    g.wg_cap = c->vgg_wg_cap;
     hipError_t e = launch_gemm(c->stream, g);
     if (e != hipSuccess) FAIL(c, LRCN_EHIP, "conv layer S=%d Cin=%d Cout=%d: %s", L.S, L.Cin, L.Cout, hipGetErrorString(e));
     return LRCN_OK;
@@ -1044,6 +1053,7 @@ int conv_layer_fp8(lrcn_ctx *c, const void *in, const VggLayer &L, int N, void *
     g.H = g.W = L.S;
     g.Cin = L.Cin;
     g.zero_page = c->zero_page;
+    g.wg_cap = c->vgg_wg_cap;
     hipError_t e = launch_gemm(c->stream, g);
     if (e != hipSuccess) FAIL(c, LRCN_EHIP, "fp8 conv layer S=%d Cin=%d Cout=%d: %s", L.S, L.Cin, L.Cout, hipGetErrorString(e));
     return LRCN_OK;
@@ -1105,7 +1115,7 @@ int vgg_body(lrcn_ctx *c, int N, const void *src, bool src_u8, const float *mean
     int l0 = 1;
     if (fuse11) {  // conv1_1 + conv1_2 + pool1 in one launch, straight from the uint8 crops: actA is never written
         hipError_t e = launch_conv64_fused11(c->stream, c->img16, c->conv[0].w_fused, c->conv[0].b, c->conv[1].w, c->conv[1].b, nxt, N, 224,
-                                             c->zero_page);
+                                             c->zero_page, c->vgg_wg_cap);
         if (e != hipSuccess) FAIL(c, LRCN_EHIP, "fused conv1_1+conv1_2: %s", hipGetErrorString(e));
         std::swap(cur, nxt);
         l0 = 2;

@@ -364,6 +364,11 @@ def conv3x3(ctx, x, w, b, relu=True, pool=False):
     return y
 
 
+def vgg_set_wg_cap(ctx, cap):
+    """Cap the VGG convolution grids at `cap` workgroups (0 = off): include/lrcn.h lrcn_vgg_set_wg_cap."""
+    ctx._call("lrcn_vgg_set_wg_cap", int(cap))
+
+
 def vgg_calibrate(ctx, img_u8, mean=VGG_MEAN, margin=1.25):
     """vgg_dtype = LRCN_FP8 only: one bf16 pass over `img_u8` (uint8 crops [n][row][col][c]) that fixes the per-layer
     activation scales of the e4m3 layers (include/lrcn.h lrcn_vgg_calibrate).  No counterpart in the reference."""

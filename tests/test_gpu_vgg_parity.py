@@ -245,3 +245,22 @@ def test_full_vgg_fp8_vs_oracle(vgg_setup):
     got1 = L.from_jl(L.convnet_u8(ctx, imgs[1:2]))
     np.testing.assert_allclose(got1[0], got[1], rtol=0, atol=1e-5 * np.abs(ref).max())
     ctx.close()
+
+
+def test_capped_persistent_conv_grids_are_bit_identical(vgg_setup):
+    # lrcn_vgg_set_wg_cap: the convolution kernels walk several tiles per workgroup (cap 8: up to 49 tiles each here;
+    # cap 224: what the data-parallel step uses) -- same tiles, same arithmetic, so the features must not change at all.
+    w, img, x, ref = vgg_setup
+    imgs = torch.as_tensor(np.concatenate([img, img[::-1]])).cuda()
+    for dt in (lrcn_amd.LRCN_BF16, lrcn_amd.LRCN_FP8):
+        ctx = small_ctx(dt, max_images=4)
+        L.vgg_load(ctx, *w)
+        if dt == lrcn_amd.LRCN_FP8:
+            L.vgg_calibrate(ctx, imgs)
+        base = L.from_jl(L.convnet_u8(ctx, imgs)).copy()
+        for cap in (8, 224):
+            L.vgg_set_wg_cap(ctx, cap)
+            np.testing.assert_array_equal(L.from_jl(L.convnet_u8(ctx, imgs)), base)
+        with pytest.raises(lrcn_amd.LrcnError):
+            L.vgg_set_wg_cap(ctx, 3)
+        ctx.close()
