@@ -3,18 +3,21 @@
 // Same contract as gemm_glds.hip (GemmArgs, NT operands, im2col formed by the LDS-DMA source addresses, window-major conv
 // rows, XOR-swizzled 128-byte LDS rows), re-scheduled the way a CDNA4 CU wants to be fed (cdna guide 5, "8-phase"):
 //   * 256-row tiles, 8 waves (two per SIMD), v_mfma_f32_16x16x32_bf16 (holds a higher clock than 32x32x16 on random data);
-//   * a K-tile (64 deep) is processed in 4 phases, one quadrant of the wave's output tile each.  A phase is
-//       [ds_read this quadrant's new fragments | issue one half-tile of LDS-DMA prefetch]  s_barrier
-//       [16 (or 8) MFMAs under s_setprio 1]                                                s_barrier
+//   * a K-tile (64 deep) is processed in 2 super-phases, two quadrants of the wave's output tile each.  A super-phase is
+//       [ds_read the new fragments | issue LDS-DMA prefetch of the next K-tile | counted vmcnt]   s_barrier
+//       [32 (or 16) MFMAs under s_setprio 1]                                                      s_barrier
+//     (the first version ran 4 phases of 16 MFMAs: the per-barrier-pair overhead is roughly constant, halving the pairs
+//     is +6-8 % on every convolution layer);
 //   * waves 4..7 run ONE barrier behind waves 0..3, so on every SIMD one wave is in its MFMA cluster while its partner
 //     reads LDS / issues DMA: the matrix pipe is never idle waiting for fragment reads;
-//   * LDS = 2 K-tile buffers x {A half 0, A half 1, B half 0, B half 1}.  A half-tile slot is refilled two phases after its
-//     last read, so 2-3 half-tiles are always in flight; one counted s_waitcnt vmcnt per K-tile, never 0 in the loop;
+//   * LDS = 2 K-tile buffers x {A half 0, A half 1, B half 0, B half 1}.  A half-tile slot is refilled a whole K-tile
+//     after its last read and retired one super-phase after its DMA was issued; counted s_waitcnt vmcnt, never 0 in the loop;
 //   * D = B_frag x A_frag ("swapped": lane = pixel, 4 registers = 4 consecutive channels) for plain/conv outputs, so
 //     the epilogue moves 8/16 bytes per lane; D = A_frag x B_frag for the fused 2x2 max-pool (4 registers = the 4 pixels
 //     of one pool window, SURVEY conv rows / DESIGN.md).
-// Hazards (two wave groups one barrier apart): a half-tile is read one phase AFTER the phase whose first barrier
-// follows the wait that retires it; a slot is re-staged >= 2 phases after its last ds_read.
+// Hazards (two wave groups one barrier apart): a half-tile is read one super-phase AFTER the one whose first barrier
+// follows the wait that retires it (every wave retires its own pieces, the barrier publishes them); a slot is re-staged
+// >= 3 barriers after the leading group's last ds_read of it (>= 2 after the trailing group's).
 #include <cstdlib>
 #include <type_traits>
 
@@ -231,12 +234,8 @@ __device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *sm
     };
     constexpr std::integral_constant<int, 0> I0{};
     constexpr std::integral_constant<int, 1> I1{};
-#define MFMA_QUADRANT(mh, nh, BF)                                                                                          \
+#define MFMA_BODY(mh, nh, BF)                                                                                              \
     do {                                                                                                                   \
-        __builtin_amdgcn_s_barrier();                                                                                      \
-        wait_lgkm0();                                                                                                      \
-        __builtin_amdgcn_sched_barrier(0);                                                                                 \
-        __builtin_amdgcn_s_setprio(1);                                                                                     \
         if constexpr (F8) {                                                                                                \
             _Pragma("unroll") for (int i = 0; i < MT; ++i) _Pragma("unroll") for (int n = 0; n < NT; ++n) {                \
                 const i32x8v av = pack8(af[i][0], af[i][1]);                                                               \
@@ -253,56 +252,60 @@ __device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *sm
                                          : __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[mh][i][nh][n], 0, 0, 0);    \
             }                                                                                                              \
         }                                                                                                                  \
+    } while (0)
+// Two quadrants per barrier pair; the first starts as soon as ITS fragments have arrived (LGKM1 later reads may still fly).
+#define MFMA_PAIR(mh1, nh1, BF1, mh2, nh2, BF2, LGKM1)                                                                     \
+    do {                                                                                                                   \
+        __builtin_amdgcn_s_barrier();                                                                                      \
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(LGKM1) : "memory");                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+        __builtin_amdgcn_s_setprio(1);                                                                                     \
+        MFMA_BODY(mh1, nh1, BF1);                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+        wait_lgkm0();                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+        MFMA_BODY(mh2, nh2, BF2);                                                                                          \
         __builtin_amdgcn_s_setprio(0);                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                                 \
         __builtin_amdgcn_s_barrier();                                                                                      \
     } while (0)
 
-    // ---- prologue: all of tile 0, then A0 and B0 of tile 1 (the two half-tiles phases 2 and 3 of the previous tile issue) ----
+    // ---- prologue: all of tile 0 ----
     {
         const KStep k0 = kstep_of(kbeg);
-        const KStep k1 = kstep_of(kbeg + (KT > 1 ? 1 : 0));
         stage_a(0, 0, k0, true);
         stage_b(0, 0, k0, true);
         stage_b(0, 1, k0, true);
         stage_a(0, 1, k0, true);
-        stage_a(1, 0, k1, KT > 1);
-        stage_b(1, 0, k1, KT > 1);
-        wait_vmcnt<APW + BPW>();
+        wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         if (grp == 1) __builtin_amdgcn_s_barrier();  // stagger
     }
     KStep kn = kstep_of(kbeg + (KT > 1 ? 1 : 0));  // tile t+1
-    const bool late_wait = !(g.dbg & 4);  // LRCN_DBG=4: the single wait per K-tile (two phases of latency budget)
+    // Two super-phases per K-tile, one barrier pair each:
+    //   [read A0, B0, B1 | stage A0, B0, B1 of tile t+1 | retire A1 of tile t]   32 MFMAs: quadrants (0,0), (0,1)
+    //   [read A1         | stage A1 of tile t+1         | retire A0, B0, B1 of t+1]   32 MFMAs: quadrants (1,1), (1,0)
+    // (four barrier pairs of 16 MFMAs per K-tile ran the matrix pipe 59 % of a resident workgroup's cycles: the barrier /
+    // wait overhead per pair is about constant, so two pairs of 32 are +6-8 % on every conv layer.)
     for (int t = 0; t < KT; ++t) {
         const int cur = t & 1, nxt = cur ^ 1;
-        const bool live1 = t + 1 < KT, live2 = t + 2 < KT;
-        const KStep k2 = kstep_of(kbeg + (live2 ? t + 2 : 0));
-        // Every half-tile is retired ONE phase before its first read (the barrier after the wait publishes it), i.e. four
-        // phases after its DMA was issued: the four younger half-tiles stay in flight across each wait.
-        // phase 0: quadrant (0,0); retire B1 of this tile (read in phase 1)
+        const bool live1 = t + 1 < KT;
         read_a(cur, I0);
         read_b(cur, I0, bf0);
-        stage_b(nxt, 1, kn, live1);
-        if (late_wait) wait_vmcnt<2 * (APW + BPW)>();
-        MFMA_QUADRANT(0, 0, bf0);
-        // phase 1: quadrant (0,1); retire A1 of this tile (read in phase 2)
         read_b(cur, I1, bf1);
-        stage_a(nxt, 1, kn, live1);
-        if (late_wait) wait_vmcnt<2 * (APW + BPW)>();
-        MFMA_QUADRANT(0, 1, bf1);
-        // phase 2: quadrant (1,1)
+        stage_a(nxt, 0, kn, live1);
+        stage_b(nxt, 0, kn, live1);
+        stage_b(nxt, 1, kn, live1);
+        wait_vmcnt<APW + 2 * BPW>();  // A1 of this tile (read in the second super-phase)
+        MFMA_PAIR(0, 0, bf0, 0, 1, bf1, 2 * NT);
         read_a(cur, I1);
-        stage_a(cur, 0, k2, live2);
-        MFMA_QUADRANT(1, 1, bf1);
-        // phase 3: quadrant (1,0); retire A0, B0 of tile t+1 (read in its phase 0)
-        stage_b(cur, 0, k2, live2);
-        if (late_wait) wait_vmcnt<2 * (APW + BPW)>();
-        else wait_vmcnt<APW + BPW>();
-        MFMA_QUADRANT(1, 0, bf0);
-        kn = k2;
+        stage_a(nxt, 1, kn, live1);
+        wait_vmcnt<APW>();            // A0, B0, B1 of tile t+1
+        MFMA_PAIR(1, 1, bf1, 1, 0, bf0, 0);
+        kn = kstep_of(kbeg + (t + 2 < KT ? t + 2 : 0));
     }
-#undef MFMA_QUADRANT
+#undef MFMA_PAIR
+#undef MFMA_BODY
     if (grp == 0) __builtin_amdgcn_s_barrier();  // un-stagger
     wait_vmcnt<0>();                             // the tail's dummy pieces
     __builtin_amdgcn_s_barrier();                // nobody reads or DMA-writes the ring any more

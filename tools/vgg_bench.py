@@ -19,6 +19,8 @@ res = {}
 for name, dt in (("bf16", lrcn_amd.LRCN_BF16), ("fp8", lrcn_amd.LRCN_FP8)):
     ctx = L.Context(8, 8, 8, 17, max_B=2, max_T=1, vgg_dtype=dt, max_images=N)
     L.vgg_load(ctx, *w)
+    if os.environ.get("LRCN_VGG_WG_CAP"):  # the capped persistent grids of the data-parallel step, alone on the chip
+        L.vgg_set_wg_cap(ctx, int(os.environ["LRCN_VGG_WG_CAP"]))
     if dt == lrcn_amd.LRCN_FP8:
         L.vgg_calibrate(ctx, img[: min(N, 32)])
     feats = L.jl_empty(N, L.CNNOUT)
