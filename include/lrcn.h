@@ -129,6 +129,14 @@ int lrcn_forward_logits(lrcn_ctx *ctx, const float *const params[9], const float
  * beta1 0.9, beta2 0.999, eps 1e-8). step = 1-based count of this update. One launch for all 9 tensors. */
 int lrcn_adam_update(lrcn_ctx *ctx, float *const params[9], const float *const grads[9], float *const mom[9],
                      float *const var[9], int step, float lr, float beta1, float beta2, float eps);
+/* The same update restricted to the tensors of gradient group `group` (0 .. LRCN_GRAD_GROUPS-1, the groups of
+ * lrcn_grad_group_wait: {Wout,bout}, {W2,b2}, {Wproj,Wcnn}, {W1,b1}, {Wembed}), enqueued on `hip_stream` (NULL = the
+ * context's stream).  Lets a data-parallel host run each group's Adam as soon as that group's gradients are final
+ * (and reduced) while the rest of the backward pass is still running: the backward reads the K-contiguous shadows made at
+ * the start of lrcn_loss_grad, never the f32 parameters.  Call once per group with the same `step`. */
+int lrcn_adam_update_group(lrcn_ctx *ctx, float *const params[9], const float *const grads[9], float *const mom[9],
+                           float *const var[9], int group, int step, float lr, float beta1, float beta2, float eps,
+                           void *hip_stream);
 
 /* Body of train1's loop (lrcn.jl:369-394) on one device: lossgradient + update!.  feats: B x 4096. */
 int lrcn_train_step(lrcn_ctx *ctx, float *const params[9], float *const grads[9], float *const mom[9],

@@ -115,6 +115,12 @@ end
 # lossgradient is final -- the host then starts that group's all-reduce while the rest of the backward pass runs
 grad_group_wait(ctx, g, stream) = check(ctx, ccall((:lrcn_grad_group_wait, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}), ctx.h, g, stream))
 
+# update! for one gradient group on `stream`, right after that group's all-reduce (new entry point)
+adam_update_group(ctx, param, grads, mom, var, group, step; lr = 0.001f0, b1 = 0.9f0, b2 = 0.999f0, eps = 1f-8, stream = C_NULL) =
+    check(ctx, ccall((:lrcn_adam_update_group, lib), Cint,
+        (Ptr{Cvoid}, Ptr{Ptr{Cfloat}}, Ptr{Ptr{Cfloat}}, Ptr{Ptr{Cfloat}}, Ptr{Ptr{Cfloat}}, Cint, Cint, Cfloat, Cfloat, Cfloat, Cfloat, Ptr{Cvoid}),
+        ctx.h, ptrs(param), ptrs(grads), ptrs(mom), ptrs(var), group, step, lr, b1, b2, eps, stream))
+
 # vgg_dtype = LRCN_FP8 contexts: fix the e4m3 activation scales from one bf16 pass over uint8 crops img[c, col, row, n]   (new entry point)
 vgg_calibrate(ctx, img, mean::Vector{Cfloat}; margin = 1.25f0) = check(ctx, ccall((:lrcn_vgg_calibrate, lib), Cint,
     (Ptr{Cvoid}, Ptr{UInt8}, Cint, Ptr{Cfloat}, Cfloat), ctx.h, pointer(img), size(img, 4), mean, margin))

@@ -61,6 +61,8 @@ SIGNATURES = {
     "lrcn_last_loss": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "lrcn_forward_logits": (C.c_int, [C.c_void_p, P9, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "lrcn_adam_update": (C.c_int, [C.c_void_p, P9, P9, P9, P9, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]),
+    "lrcn_adam_update_group": (C.c_int, [C.c_void_p, P9, P9, P9, P9, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
+                                         C.c_void_p]),
     "lrcn_train_step": (C.c_int, [C.c_void_p, P9, P9, P9, P9, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                   C.POINTER(Dropout), C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
                                   C.POINTER(C.c_double)]),

@@ -707,6 +707,27 @@ int lrcn_adam_update(lrcn_ctx *c, float *const p[9], const float *const g[9], fl
     return LRCN_OK;
 }
 
+int lrcn_adam_update_group(lrcn_ctx *c, float *const p[9], const float *const g[9], float *const m[9], float *const v[9], int group,
+                           int step, float lr, float b1, float b2, float eps, void *stream) {
+    if (!c || !p || !g || !m || !v || step < 1) return LRCN_EINVAL;
+    if (group < 0 || group >= LRCN_GRAD_GROUPS) FAIL(c, LRCN_EINVAL, "group=%d outside [0,%d)", group, LRCN_GRAD_GROUPS);
+    static const int kGroup[LRCN_GRAD_GROUPS][2] = {{7, 8}, {2, 3}, {4, 5}, {0, 1}, {6, 6}};  // order of the grad_ev records
+    AdamTensors t;
+    int64_t sz[9];
+    lrcn_param_sizes(c->E, c->H1, c->H2, c->V, sz);
+    for (int k = 0; k < 9; ++k) {
+        const bool in = k == kGroup[group][0] || k == kGroup[group][1];
+        t.w[k] = p[k];
+        t.g[k] = g[k];
+        t.m[k] = m[k];
+        t.v[k] = v[k];
+        t.n[k] = in ? sz[k] : 0;
+    }
+    k_adam(stream ? reinterpret_cast<hipStream_t>(stream) : c->stream, t, step, lr, b1, b2, eps);
+    KCHK(c, "adam (group)");
+    return LRCN_OK;
+}
+
 int lrcn_train_step(lrcn_ctx *c, float *const p[9], float *const g[9], float *const m[9], float *const v[9], const float *feats,
                     const int32_t *tokens, int T, int B, int norm_B, const lrcn_dropout *drop, int step, float lr, float b1,
                     float b2, float eps, double *loss_host) {

@@ -258,6 +258,13 @@ def update(ctx, param, grads, optim):
               optim.beta2, optim.eps)
 
 
+def update_group(ctx, param, grads, optim, group, stream=None):
+    """update! for the tensors of one gradient group (include/lrcn.h lrcn_adam_update_group) on `stream`; the caller
+    advances optim.t once per step, before the first group."""
+    ctx._call("lrcn_adam_update_group", _p9(param), _p9(grads), _p9(optim.m), _p9(optim.v), int(group), optim.t, optim.lr,
+              optim.beta1, optim.beta2, optim.eps, C.c_void_p(stream.cuda_stream) if stream is not None else None)
+
+
 def train_step(ctx, param, optim, grads, feats, tokens, norm_B=None, pdrop=0.4, seed=0, want_loss=False):
     """Body of train1's batch loop (lrcn.jl:369-394): lossgradient + update!, one C call."""
     tok = _tokens(tokens, feats.device)

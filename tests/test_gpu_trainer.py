@@ -64,8 +64,9 @@ def test_gradient_group_events_and_bucketed_allreduce_path(monkeypatch):
         E = H = 64
         V, B, T = 300, 4, 5
 
-        def run(world, buckets):
+        def run(world, buckets, group_adam="1"):
             monkeypatch.setenv("LRCN_DP_BUCKETS", buckets)
+            monkeypatch.setenv("LRCN_DP_GROUP_ADAM", group_adam)  # per-group [all-reduce -> Adam] pipeline on / off
             ctx = L.Context(E, H, H, V, max_B=B, max_T=T, lstm_dtype=lrcn_amd.LRCN_BF16)
             param = L.initweights(ctx, seed=42)
             tr = dp.DataParallelTrainer(ctx, param, L.initparams(param), B, world, 0, pdrop=0.4, seed=7, group=dist.group.WORLD)
@@ -94,10 +95,12 @@ def test_gradient_group_events_and_bucketed_allreduce_path(monkeypatch):
         l1, p1 = run(1, "1")
         l2, p2 = run(2, "1")   # bucketed, event-gated
         l3, p3 = run(2, "0")   # single all-reduce
-        np.testing.assert_allclose(l1, l2, rtol=1e-5)
-        np.testing.assert_allclose(l1, l3, rtol=1e-5)
-        for a, b, c in zip(p1, p2, p3):
-            np.testing.assert_allclose(a, b, rtol=0, atol=2e-4)
-            np.testing.assert_allclose(a, c, rtol=0, atol=2e-4)
+        l4, p4 = run(2, "1", "0")  # bucketed all-reduces, one Adam launch after the last
+        l5, p5 = run(1, "1", "0")  # one rank, one Adam launch (the world = 1 default)
+        for l in (l2, l3, l4, l5):
+            np.testing.assert_allclose(l1, l, rtol=1e-5)
+        for other in (p2, p3, p4, p5):
+            for a, b in zip(p1, other):
+                np.testing.assert_allclose(a, b, rtol=0, atol=2e-4)
     finally:
         dist.destroy_process_group()
