@@ -583,7 +583,13 @@ template <int WM, int WN, int MT, int NT, int AMODE, bool SWAP, bool F8 = false>
     const int64_t blocks = (int64_t)cdiv(g.M, BM) * cdiv(g.N, BN);
     if (blocks <= 0 || blocks > 0x7FFFFFFF) return hipErrorInvalidValue;
     int64_t grid = blocks;
-    if (g.wg_cap >= 8 && grid > g.wg_cap) grid = g.wg_cap & ~7;  // a multiple of 8 keeps tile -> XCD stable
+    if (g.wg_cap >= 8 && grid > g.wg_cap) {
+        // the fewest workgroups that still finish in ceil(tiles / cap) rounds (conv5 at 256 images: 392 tiles, cap 224 -> two
+        // rounds either way, 200 workgroups instead of 224), as a multiple of 8 so that tile -> XCD stays stable
+        const int64_t cap = g.wg_cap & ~7, rounds = (blocks + cap - 1) / cap;
+        grid = (((blocks + rounds - 1) / rounds) + 7) & ~7ll;
+        if (grid > cap) grid = cap;
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)splitk), dim3(512), lds, s, g);
     return hipGetLastError();
 }
