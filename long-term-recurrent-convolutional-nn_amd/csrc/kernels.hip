@@ -1036,7 +1036,7 @@ void k_uncast_rows(hipStream_t st, int dtype, const void *in, int64_t ld_in, int
 void k_colsum(hipStream_t st, int dtype, const void *z, int64_t ld, int M, int N, float *out) {
     // enough slabs of rows to give the chip ~2 blocks per CU; a single slab needs no zeroing and no atomics
     const int cb = cdiv(N, 64);
-    int slabs = cdiv(512, cb);
+    int slabs = M <= 512 ? 1 : cdiv(512, cb);  // few rows: one pass, no memset launch (the step is launch-bound there)
     if (slabs > cdiv(M, 64)) slabs = cdiv(M, 64);
     if (slabs < 1) slabs = 1;
     const int rows = cdiv(cdiv(M, slabs), 16) * 16;

@@ -311,8 +311,7 @@ int loss_impl(lrcn_ctx *c, const float *const p[9], const float *feats, const in
 
     r = prepare_weights(c, p, bwd);
     if (r) return r;
-    if (T > 0) HIPCHK(c, hipMemcpyAsync(c->tok, tokens, sizeof(int32_t) * (size_t)T * B, hipMemcpyDeviceToDevice, st));
-    k_build_tokens(st, c->tok, T, B, V, c->tok_in, c->tok_tgt, c->logp);
+    k_build_tokens(st, tokens, T, B, V, c->tok_in, c->tok_tgt, c->logp);  // reads the caller's (T, B) ids once (T = 0: never)
     // feats (B x 4096 column-major = memory [4096][B]) -> F [B][4096] (T)
     k_transpose(st, dt, 1, feats, B, LRCN_CNNOUT, B, c->F, LRCN_CNNOUT, 0);
     // input = input * param[end-3]   lrcn.jl:558
