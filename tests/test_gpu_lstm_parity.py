@@ -283,3 +283,30 @@ def test_error_paths_do_not_abort():
     # out-of-range token ids are clamped to unk rather than faulting
     v = L.loss(ctx, param, feats, np.full((2, 4), 1000, np.int32))
     assert np.isfinite(v)
+
+
+def test_adam_by_gradient_group_equals_one_launch():
+    # lrcn_adam_update_group (the data-parallel step runs each group's update right after that group's all-reduce):
+    # the five groups cover all nine tensors exactly once and give bit-identical parameters and moments.
+    rng = np.random.default_rng(8)
+    E, H, V = 24, 32, 57
+    ctx = L.Context(E, H, H, V, max_B=2, max_T=1)
+    res = []
+    for by_group in (False, True):
+        param = L.initweights(ctx, seed=5)
+        optim = L.initparams(param)
+        for it in range(3):
+            grads = [L.to_jl(np.random.default_rng(100 * it + k).standard_normal(tuple(p.shape)).astype(np.float32) * 0.1) for k, p in enumerate(param)]
+            if by_group:
+                optim.t += 1
+                for g in (3, 0, 4, 1, 2):  # any order
+                    L.update_group(ctx, param, grads, optim, g)
+            else:
+                L.update(ctx, param, grads, optim)
+        torch.cuda.synchronize()
+        res.append([L.from_jl(t).copy() for t in param] + [L.from_jl(t).copy() for t in optim.m] + [L.from_jl(t).copy() for t in optim.v])
+    for a, b in zip(*res):
+        np.testing.assert_array_equal(a, b)
+    with pytest.raises(lrcn_amd.LrcnError):
+        L.update_group(ctx, param, grads, optim, 5)
+    ctx.close()
