@@ -264,3 +264,27 @@ def test_capped_persistent_conv_grids_are_bit_identical(vgg_setup):
         with pytest.raises(lrcn_amd.LrcnError):
             L.vgg_set_wg_cap(ctx, 3)
         ctx.close()
+
+
+def test_config2_end_to_end_fp32_images_to_loss(vgg_setup):
+    # BASELINE configs[1] composed end to end in fp32 on the parity scale: uint8 crops -> VGG-16 -> fc7 (exact-fp32 MFMA)
+    # -> LSTM-512 loss and gradients, against the CPU oracle run on the same crops (features and loss from the oracle's
+    # own VGG forward).  Two images; the full-size shapes are covered by test_gpu_fullsize.py / test_config1_shape_*.
+    w, img, x, ref = vgg_setup
+    E = H = 512
+    V, T, B = 2540, 11, 2
+    rng = np.random.default_rng(12)
+    m = orc.init_weights(E, H, H, V, seed=42)
+    tokens = rng.integers(3, V, size=(T, B)).astype(np.int32)
+    fn = (ref / ref.sum(axis=1, keepdims=True)).astype(np.float32)  # the reference trains on sum-normalised features
+    ref_loss, ref_g = orc.loss(m, fn, tokens, want_grad=True)
+    ctx = L.Context(E, H, H, V, max_B=B, max_T=T, vgg_dtype=lrcn_amd.LRCN_F32, max_images=B)
+    L.vgg_load(ctx, *w)
+    feats = L.from_jl(L.convnet_u8(ctx, torch.as_tensor(img).cuda()))
+    feats = (feats / feats.sum(axis=1, keepdims=True)).astype(np.float32)
+    grads, val = L.lossgradient(ctx, L.model_from_arrays(m.p), L.to_jl(feats), tokens)
+    assert abs(val - ref_loss) <= 1e-4 * abs(ref_loss), (val, ref_loss)
+    for n, g in zip(orc.PARAM_NAMES, grads):
+        a, b = L.from_jl(g).ravel().astype(np.float64), ref_g.p[n].ravel().astype(np.float64)
+        assert np.linalg.norm(a - b) <= 2e-3 * np.linalg.norm(b) + 1e-9, n
+    ctx.close()
