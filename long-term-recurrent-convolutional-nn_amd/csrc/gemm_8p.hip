@@ -72,10 +72,8 @@ __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float 
 // multiplies by g.scale[col] before the bias and writes e4m3.
 template <int WM, int WN, int MT, int NT, int AMODE, bool SWAP, bool F8>
 __device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *smem, const int tile, const int ntiles_xy) {
-    using elem_t = std::conditional_t<F8, unsigned char, bf16_t>;
     constexpr int ES = F8 ? 1 : 2;       // bytes per element
     constexpr int KE = 128 / ES;         // elements per K-tile
-    constexpr int CE = 16 / ES;          // elements per 16-byte chunk
     static_assert(WM * WN == 8, "8 waves");
     constexpr int QM = MT * 16, QN = NT * 16;   // quadrant = QM x QN of a wave's (2 QM) x (2 QN) output tile
     constexpr int WTM = 2 * QM, WTN = 2 * QN;
@@ -100,9 +98,19 @@ __device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *sm
     const int nt = bid % tiles_n, mt = bid / tiles_n;
     const int m0 = mt * BM, n0 = nt * BN;
 
-    const elem_t *Ab = reinterpret_cast<const elem_t *>(g.A);
-    const elem_t *Bb = reinterpret_cast<const elem_t *>(g.B);
-    const elem_t *Zp = reinterpret_cast<const elem_t *>(g.zero_page) + (lane & 7) * CE;
+    // Operands are addressed through buffer descriptors (buffer_load_dwordx4 ... lds): the per-lane byte offset of a piece is
+    // loop-invariant, the K-step offset rides in the scalar soffset, and a lane whose row / tap falls outside the matrix /
+    // image uses offset 0xFFFFFFFF >= num_records, for which the hardware writes zeros to LDS -- no 64-bit address arithmetic
+    // and no zero-page pointers in the load segment (measured on gfx950: out-of-range lanes store 0, soffset is not part of
+    // the range check).  The 3x3 taps reach (W + 1) pixels BEHIND a pixel, so the convolution's descriptor starts that far
+    // before the tensor and soffset carries the difference.
+    constexpr unsigned OOB = 0xFFFFFFFFu, NREC = 0xFFFFFF00u;
+    const unsigned conv_back = (AMODE == GEMM_A_CONV3) ? (unsigned)((g.W + 1) * g.Cin * ES) : 0u;
+    const unsigned char *Abase = reinterpret_cast<const unsigned char *>(g.A) - conv_back;
+    const unsigned char *Bbase = reinterpret_cast<const unsigned char *>(g.B);
+    auto rsrc_of = [](const unsigned char *base, bool live) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(base), 0, live ? NREC : 0u, 0x00020000);
+    };
 
     const int kpt = (AMODE == GEMM_A_CONV3) ? g.Cin / KE : g.K / KE;
     const int KT_all = (AMODE == GEMM_A_CONV3) ? 9 * kpt : kpt;
@@ -118,10 +126,9 @@ __device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *sm
         const int hr = (wave * BPW + j) * 8;
         return (hr / QN) * WTN + hf * QN + (hr % QN);
     };
-    int a_off[2][APW];
-    unsigned a_mask[2][APW];
-    int b_off[2][BPW];
-    bool b_ok[2][BPW];
+    unsigned a_voff[2][APW];  // byte offset of this lane's 16-byte chunk of the piece (OOB: row >= M)
+    unsigned a_mask[2][APW];  // conv: bit t = tap t reads inside the image
+    unsigned b_voff[2][BPW];
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
 #pragma unroll
@@ -129,12 +136,12 @@ __device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *sm
             const int row = a_piece_row(hf, j) + (lane >> 3);
             const int m = m0 + row;
             const int src_chunk = (lane & 7) ^ ((row >> 1) & 7);
-            a_off[hf][j] = 0;
+            a_voff[hf][j] = OOB;
             a_mask[hf][j] = 0;
             if (m < M) {
                 if (AMODE == GEMM_A_CONV3) {
                     const PixDecode p = decode_pixel(m, g.H, g.W);
-                    a_off[hf][j] = ((p.n * g.H + p.y) * g.W + p.x) * g.Cin + src_chunk * CE;
+                    a_voff[hf][j] = (unsigned)((((p.n * g.H + p.y) * g.W + p.x) * g.Cin) * ES + src_chunk * 16);
                     unsigned mk = 0;
 #pragma unroll
                     for (int t = 0; t < 9; ++t) {
@@ -143,8 +150,7 @@ __device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *sm
                     }
                     a_mask[hf][j] = mk;
                 } else {
-                    a_off[hf][j] = m * (int)g.lda + src_chunk * CE;
-                    a_mask[hf][j] = 1;
+                    a_voff[hf][j] = (unsigned)(m * (int)g.lda * ES + src_chunk * 16);
                 }
             }
         }
@@ -153,8 +159,7 @@ __device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *sm
             const int row = b_piece_row(hf, j) + (lane >> 3);
             const int n = n0 + row;
             const int src_chunk = (lane & 7) ^ ((row >> 1) & 7);
-            b_ok[hf][j] = n < N;
-            b_off[hf][j] = b_ok[hf][j] ? n * (int)g.ldb + src_chunk * CE : 0;
+            b_voff[hf][j] = n < N ? (unsigned)(n * (int)g.ldb * ES + src_chunk * 16) : OOB;
         }
     }
 
@@ -173,21 +178,44 @@ __device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *sm
         }
         return k;
     };
+    // PLAIN operands keep flat 64-bit addresses (global_load_lds_dwordx4, zero page for rows past the edge): with no tap
+    // masks there was little arithmetic to save and the descriptor form measured 5 % slower at 4096^3.
+    const unsigned char *Aflat = reinterpret_cast<const unsigned char *>(g.A);
+    const unsigned char *Zp = reinterpret_cast<const unsigned char *>(g.zero_page) + (lane & 7) * 16;
     auto stage_a = [&](int buf, int hf, const KStep &k, bool live) {
-        const unsigned tapbit = live ? (1u << k.tap) : 0u;  // wave-uniform
+        if constexpr (AMODE == GEMM_A_CONV3) {
+            const __amdgpu_buffer_rsrc_t rs = rsrc_of(Abase, live);  // a dead K-tile (past the end) loads zeros: keeps the vmcnt bookkeeping uniform
+            const int soff = (int)(conv_back + (unsigned)(k.koff * ES));
+            const unsigned tapbit = 1u << k.tap;  // wave-uniform
 #pragma unroll
-        for (int j = 0; j < APW; ++j) {
-            const bool ok = (a_mask[hf][j] & tapbit) != 0;
-            const elem_t *src = ok ? Ab + (a_off[hf][j] + k.koff) : Zp;
-            __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(smem + buf * BUF + a_piece_row(hf, j) * 128), 16, 0, 0);
+            for (int j = 0; j < APW; ++j) {
+                const unsigned vo = (a_mask[hf][j] & tapbit) ? a_voff[hf][j] : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(smem + buf * BUF + a_piece_row(hf, j) * 128), 16, (int)vo, soff, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < APW; ++j) {
+                const bool ok = live && a_voff[hf][j] != OOB;
+                const unsigned char *src = ok ? Aflat + ((int64_t)a_voff[hf][j] + (int64_t)k.koff * ES) : Zp;
+                __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(smem + buf * BUF + a_piece_row(hf, j) * 128), 16, 0, 0);
+            }
         }
     };
     auto stage_b = [&](int buf, int hf, const KStep &k, bool live) {
+        if constexpr (AMODE == GEMM_A_CONV3) {
+            const __amdgpu_buffer_rsrc_t rs = rsrc_of(Bbase, live);
+            const int soff = k.kb * ES;
 #pragma unroll
-        for (int j = 0; j < BPW; ++j) {
-            const elem_t *src = (b_ok[hf][j] & live) ? Bb + (b_off[hf][j] + k.kb) : Zp;
-            __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(smem + buf * BUF + A_BYTES + b_piece_row(hf, j) * 128), 16, 0,
-                                             0);
+            for (int j = 0; j < BPW; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(smem + buf * BUF + A_BYTES + b_piece_row(hf, j) * 128), 16,
+                                                         (int)b_voff[hf][j], soff, 0, 0);
+        } else {
+#pragma unroll
+            for (int j = 0; j < BPW; ++j) {
+                const bool ok = live && b_voff[hf][j] != OOB;
+                const unsigned char *src = ok ? Bbase + ((int64_t)b_voff[hf][j] + (int64_t)k.kb * ES) : Zp;
+                __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(smem + buf * BUF + A_BYTES + b_piece_row(hf, j) * 128), 16, 0, 0);
+            }
         }
     };
 
