@@ -315,8 +315,10 @@ __device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *sm
     //   [read A1         | stage A1 of tile t+1         | retire A0, B0, B1 of t+1]   32 MFMAs: quadrants (1,1), (1,0)
     // (four barrier pairs of 16 MFMAs per K-tile ran the matrix pipe 59 % of a resident workgroup's cycles: the barrier /
     // wait overhead per pair is about constant, so two pairs of 32 are +6-8 % on every conv layer.)
-    for (int t = 0; t < KT; ++t) {
-        const int cur = t & 1, nxt = cur ^ 1;
+    // the K loop is unrolled by two so that the ring buffer of a K-tile is a compile-time constant (LDS addresses of the
+    // fragment reads and DMA destinations need no per-tile VALU arithmetic in the load segment)
+    auto k_tile = [&](int t, auto curc) {
+        constexpr int cur = decltype(curc)::value, nxt = cur ^ 1;
         const bool live1 = t + 1 < KT;
         read_a(cur, I0);
         read_b(cur, I0, bf0);
@@ -331,6 +333,10 @@ __device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *sm
         wait_vmcnt<APW>();            // A0, B0, B1 of tile t+1
         MFMA_PAIR(1, 1, bf1, 1, 0, bf0, 0);
         kn = kstep_of(kbeg + (t + 2 < KT ? t + 2 : 0));
+    };
+    for (int t = 0; t < KT; t += 2) {
+        k_tile(t, I0);
+        if (t + 1 < KT) k_tile(t + 1, I1);
     }
 #undef MFMA_PAIR
 #undef MFMA_BODY
