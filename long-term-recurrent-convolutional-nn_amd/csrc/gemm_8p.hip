@@ -127,7 +127,7 @@ __device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *sm
         return (hr / QN) * WTN + hf * QN + (hr % QN);
     };
     unsigned a_voff[2][APW];  // byte offset of this lane's 16-byte chunk of the piece (OOB: row >= M)
-    unsigned a_mask[2][APW];  // conv: bit t = tap t reads inside the image
+    unsigned a_mask[2][APW];  // conv: bit t CLEAR = tap t reads inside the image
     unsigned b_voff[2][BPW];
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
@@ -137,7 +137,7 @@ __device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *sm
             const int m = m0 + row;
             const int src_chunk = (lane & 7) ^ ((row >> 1) & 7);
             a_voff[hf][j] = OOB;
-            a_mask[hf][j] = 0;
+            a_mask[hf][j] = ~0u;
             if (m < M) {
                 if (AMODE == GEMM_A_CONV3) {
                     const PixDecode p = decode_pixel(m, g.H, g.W);
@@ -148,7 +148,7 @@ __device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *sm
                         const int y = p.y + t / 3 - 1, x = p.x + t % 3 - 1;
                         if ((unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W) mk |= 1u << t;
                     }
-                    a_mask[hf][j] = mk;
+                    a_mask[hf][j] = ~mk;  // stored inverted: see stage_a
                 } else {
                     a_voff[hf][j] = (unsigned)(m * (int)g.lda * ES + src_chunk * 16);
                 }
@@ -186,10 +186,10 @@ __device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *sm
         if constexpr (AMODE == GEMM_A_CONV3) {
             const __amdgpu_buffer_rsrc_t rs = rsrc_of(Abase, live);  // a dead K-tile (past the end) loads zeros: keeps the vmcnt bookkeeping uniform
             const int soff = (int)(conv_back + (unsigned)(k.koff * ES));
-            const unsigned tapbit = 1u << k.tap;  // wave-uniform
 #pragma unroll
             for (int j = 0; j < APW; ++j) {
-                const unsigned vo = (a_mask[hf][j] & tapbit) ? a_voff[hf][j] : OOB;
+                // bit `tap` of the INVERTED mask, sign-extended (v_bfe_i32): 0 for a tap inside the image, all ones (= OOB) outside
+                const unsigned vo = a_voff[hf][j] | (unsigned)__builtin_amdgcn_sbfe((int)a_mask[hf][j], k.tap, 1);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(smem + buf * BUF + a_piece_row(hf, j) * 128), 16, (int)vo, soff, 0, 0);
             }
         } else {
