@@ -141,7 +141,7 @@ __device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *sm
             if (m < M) {
                 if (AMODE == GEMM_A_CONV3) {
                     const PixDecode p = decode_pixel(m, g.H, g.W);
-                    a_voff[hf][j] = (unsigned)((((p.n * g.H + p.y) * g.W + p.x) * g.Cin) * ES + src_chunk * 16);
+                    a_voff[hf][j] = (unsigned)((uint64_t)((p.n * g.H + p.y) * g.W + p.x) * (uint64_t)(g.Cin * ES) + src_chunk * 16);  // < NREC: launch check
                     unsigned mk = 0;
 #pragma unroll
                     for (int t = 0; t < 9; ++t) {
@@ -150,7 +150,7 @@ __device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *sm
                     }
                     a_mask[hf][j] = ~mk;  // stored inverted: see stage_a
                 } else {
-                    a_voff[hf][j] = (unsigned)(m * (int)g.lda * ES + src_chunk * 16);
+                    a_voff[hf][j] = (unsigned)((uint64_t)m * (uint64_t)(g.lda * ES) + src_chunk * 16);
                 }
             }
         }
@@ -159,7 +159,7 @@ __device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *sm
             const int row = b_piece_row(hf, j) + (lane >> 3);
             const int n = n0 + row;
             const int src_chunk = (lane & 7) ^ ((row >> 1) & 7);
-            b_voff[hf][j] = n < N ? (unsigned)(n * (int)g.ldb * ES + src_chunk * 16) : OOB;
+            b_voff[hf][j] = n < N ? (unsigned)((uint64_t)n * (uint64_t)(g.ldb * ES) + src_chunk * 16) : OOB;
         }
     }
 
@@ -654,6 +654,11 @@ int gemm_8p_config(const GemmArgs &g, int64_t *blocks) {
         if (!gemm_8p_f8_ok(g)) return -1;
     } else if (!gemm_glds_eligible(g)) {
         return -1;
+    }
+    {   // 32-bit byte offsets inside the kernel (buffer descriptors / lane offsets): operands must stay below 4 GiB - margin
+        const int64_t es = g.dtype == GEMM_T_F8 ? 1 : 2;
+        const int64_t a_bytes = (g.a_mode == GEMM_A_CONV3 ? (int64_t)g.M * g.Cin + (int64_t)(g.W + 1) * g.Cin : (int64_t)g.M * g.lda) * es;
+        if (a_bytes >= 0xFFFF0000ll || (int64_t)g.N * g.ldb * es >= 0xFFFF0000ll) return -1;
     }
     if ((g.M < 256 && g.dtype != GEMM_T_F8) || g.N < 128) return -1;  // e4m3 has no other kernel: M tails are masked rows
     const int ke = g.dtype == GEMM_T_F8 ? 128 : 64;
