@@ -41,6 +41,15 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
+// ReLU on two packed bf16 values as ONE v_pk_max_i16: a negative float has the sign bit set, i.e. is a negative int16
+// (-0 = 0x8000 included), and max(., 0) clears it; positive values are positive int16 and pass unchanged.  Half the vector
+// ALU instructions of fmaxf-before-convert -- the epilogue / producer of this kernel run beside the partner wave's MFMAs
+// and compete with them for the SIMD's issue port.
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned relu_bf16x2(unsigned w) {
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, w), s16x2{0, 0}));
+}
+
 constexpr int PATCH_BYTES = 48 * 1024;  // 48 DMA pieces of 1 KiB (41 carry pixels, the rest keep the per-wave count uniform)
 constexpr int NPIECE = 6;               // pieces per wave per patch
 constexpr int BIAS_OFF = 3 * PATCH_BYTES;
@@ -261,10 +270,10 @@ template <bool POOL, bool FUSE> __global__ __launch_bounds__(512) void conv64_ke
                                                                        __builtin_bit_cast(f32x4v, bq[nn]), 0, 0, 0);
                     bf16x4 o;
 #pragma unroll
-                    for (int r2 = 0; r2 < 4; ++r2) o[r2] = (bf16_t)fmaxf(d[r2], 0.0f);
+                    for (int r2 = 0; r2 < 4; ++r2) o[r2] = (bf16_t)d[r2];
                     uint2 ov = __builtin_bit_cast(uint2, o);
-                    ov.x &= pmask;
-                    ov.y &= pmask;
+                    ov.x = relu_bf16x2(ov.x) & pmask;
+                    ov.y = relu_bf16x2(ov.y) & pmask;
                     // channels nn*16 + 4 lq .. + 3 of pixel q: chunk nn*2 + (lq >> 1), 8-byte half lq & 1
                     lds_write8(wdst + (((nn * 2 + (lqv >> 1)) ^ gsw) << 4), ov);
                 });
@@ -399,15 +408,13 @@ template <bool POOL, bool FUSE> __global__ __launch_bounds__(512) void conv64_ke
                     const int oy = ty * 8 + (widx >> 3), ox = tx * 8 + (widx & 7);
                     float v0 = fmaxf(fmaxf(acc[i][0][0], acc[i][0][1]), fmaxf(acc[i][0][2], acc[i][0][3])) + b0v;
                     float v1 = fmaxf(fmaxf(acc[i][1][0], acc[i][1][1]), fmaxf(acc[i][1][2], acc[i][1][3])) + b1v;
-                    if (a.relu) {
-                        v0 = fmaxf(v0, 0.0f);
-                        v1 = fmaxf(v1, 0.0f);
-                    }
                     bf16x2 o;
                     o[0] = (bf16_t)v0;
                     o[1] = (bf16_t)v1;
+                    unsigned ow = __builtin_bit_cast(unsigned, o);
+                    if (a.relu) ow = relu_bf16x2(ow);
                     bf16_t *dst = a.out + ((size_t)(n_img * Ho + oy) * Wo + ox) * a.Cout + cc * 64 + wq * 32 + 2 * l15;
-                    *reinterpret_cast<bf16x2 *>(dst) = o;
+                    *reinterpret_cast<unsigned *>(dst) = ow;
                 }
             } else {
                 // lane: pixel l15 of m-tile 4 wp + i; registers of n-tile n = channels lq*8 + n*4 + (0..3)
@@ -431,13 +438,15 @@ template <bool POOL, bool FUSE> __global__ __launch_bounds__(512) void conv64_ke
                     bf16x8v o;
 #pragma unroll
                     for (int r2 = 0; r2 < 4; ++r2) {
-                        float p0 = u0[r2], p1 = u1[r2];
-                        if (a.relu) {
-                            p0 = fmaxf(p0, 0.0f);
-                            p1 = fmaxf(p1, 0.0f);
-                        }
-                        o[r2] = (bf16_t)p0;
-                        o[4 + r2] = (bf16_t)p1;
+                        o[r2] = (bf16_t)u0[r2];
+                        o[4 + r2] = (bf16_t)u1[r2];
+                    }
+                    if (a.relu) {
+                        typedef unsigned u32x4r __attribute__((ext_vector_type(4)));
+                        u32x4r w = __builtin_bit_cast(u32x4r, o);
+#pragma unroll
+                        for (int r2 = 0; r2 < 4; ++r2) w[r2] = relu_bf16x2(w[r2]);
+                        o = __builtin_bit_cast(bf16x8v, w);
                     }
                     if constexpr (!FUSE) {
                         if (a.f8_inv_scale > 0.0f) {  // wave-uniform: the e4m3 input of the fp8 convolution stack (fp8.hip)
