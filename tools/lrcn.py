@@ -110,7 +110,7 @@ def main(argv=None):
     if len(o.hidden) != 2 or o.hidden[1] % 2:
         raise SystemExit("--hidden takes two sizes, the second even (LRCN-2f, lrcn.jl:496-504)")
     H1, H2 = o.hidden
-    gen_chunk = 64  # images decoded together by the batched beam search
+    gen_chunk = 256  # images decoded together by the batched beam search (1280 hypothesis rows at beam 5: the decode GEMMs fill the chip)
     ctx = L.Context(o.embed, H1, H2, V, max_B=max(o.batchsize, o.beam_width * (gen_chunk if o.generate > 0 else 1), 10), lstm_dtype=dt, vgg_dtype=vdt,
                     max_images=max(o.batchsize, 1) if o.cnn else 0)
     param = L.initweights(ctx, seed=o.seed if o.seed > 0 else 42) if host_model is None else L.model_from_arrays(host_model)
@@ -153,7 +153,7 @@ def main(argv=None):
         os.makedirs(o.out, exist_ok=True)
         suffix = "_flickr" if o.flickr else ".txt"
         with open(os.path.join(o.out, "candidates" + suffix), "w") as out, open(os.path.join(o.out, "candidate_ids" + suffix), "w") as ido:
-            for s0 in range(0, len(ids), gen_chunk):  # the reference decodes image by image; here 64 images x beam_width rows per step
+            for s0 in range(0, len(ids), gen_chunk):  # the reference decodes image by image; here gen_chunk images x beam_width rows per step
                 chunk = ids[s0:s0 + gen_chunk]
                 for i, (toks, _) in zip(chunk, L.beam_search_batch(ctx, param, feature_rows(table, chunk), o.beam_width, o.generate)):
                     ido.write("%d\n" % i)
