@@ -667,6 +667,10 @@ int gemm_8p_config(const GemmArgs &g, int64_t *blocks) {
     const int64_t b0 = (int64_t)cdiv(g.M, 256) * cdiv(g.N, 256), b1 = (int64_t)cdiv(g.M, 256) * cdiv(g.N, 128);
     int cfg = (g.N > 128 && (b0 >= 200 || g.N % 256 == 0 || g.N > 384)) ? 0 : 1;
     if (cfg == 0 && ((b0 < 200 && b1 >= 200) || (b0 < 128 && b1 >= 128))) cfg = 1;  // the narrower tile when only it fills the chip
+    {
+        static const char *fc = getenv("LRCN_8P_CFG");  // kernel-development knob: force the 256 x 256 (0) or 256 x 128 (1) tile
+        if (fc && (fc[0] == '0' || fc[0] == '1') && g.N > 128) cfg = fc[0] - '0';
+    }
     *blocks = cfg == 0 ? b0 : b1;
     const char *t = getenv("LRCN_8P_TALL");  // kernel-development knob: 0 disables the 512 x 128 tile
     if (cfg == 1 && g.N <= 128 && cdiv(g.M, 512) >= 400 && !(t && t[0] == '0')) {
