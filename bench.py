@@ -44,32 +44,56 @@ def pmc_traffic(dtype, per_gpu_batch):
 
 def cpu_baseline(vgg_w, E, H, V, T, rng):
     """The oracle (kind "port": the reference is Julia/GPU-only and cannot run) timed on this box's host cores on a
-    bounded sample of the same workload: VGG forward on 4 images + lossgradient on 16 captions, float accumulation."""
+    bounded sample of the same workload: VGG forward on 4 images + lossgradient on 16 captions, float accumulation.
+    -> (cpu_baseline object, sample): the sample's inputs and the oracle's outputs, which main() pushes through the HIP
+    path afterwards (outside every timed region) for the `parity` spot-check of the same JSON line."""
     import numpy as np
     from oracle import oracle as orc
     conv_w, conv_b, fc6, fc7 = vgg_w
     n_img, n_cap = 4, 16
-    x = orc.preprocess_u8(rng.integers(0, 256, size=(n_img, 224, 224, 3), dtype=np.uint8), (123.68, 116.779, 103.939))
+    img = rng.integers(0, 256, size=(n_img, 224, 224, 3), dtype=np.uint8)
+    x = orc.preprocess_u8(img, (123.68, 116.779, 103.939))
     t0 = time.time()
-    orc.vgg_forward(conv_w, conv_b, fc6, fc7, x, fast=True)
+    ref_feats = orc.vgg_forward(conv_w, conv_b, fc6, fc7, x, fast=True)
     t_vgg = (time.time() - t0) / n_img
     m = orc.init_weights(E, H, H, V, seed=42)
     feats = (rng.standard_normal((n_cap, 4096)) * 0.01).astype(np.float32)
     tokens = rng.integers(3, V, size=(T, n_cap)).astype(np.int32)
     t0 = time.time()
-    orc.loss(m, feats, tokens, want_grad=True, fast=True)
+    ref_loss, ref_g = orc.loss(m, feats, tokens, want_grad=True, fast=True)
     t_lstm = (time.time() - t0) / n_cap
-    return {"value": 1.0 / (t_vgg + t_lstm), "unit": "images/sec", "cores": orc.num_threads(), "kind": "port",
+    base = {"value": 1.0 / (t_vgg + t_lstm), "unit": "images/sec", "cores": orc.num_threads(), "kind": "port",
             "sample": "oracle/lrcn_oracle.c (float accumulate, OpenMP): VGG-16 fwd on %d images (%.2f s/img) + LSTM "
                       "lossgradient on %d captions of T=%d (%.3f s/caption); Adam excluded (<1%%)"
                       % (n_img, t_vgg, n_cap, T, t_lstm)}
+    return base, {"img": img, "ref_feats": ref_feats, "model": m, "feats": feats, "tokens": tokens, "ref_loss": ref_loss,
+                  "ref_grads": ref_g}
+
+
+def parity_spot_check(ctx, L, sample):
+    """The cpu_baseline sample through the HIP path of THIS context (the benchmark's kernels, dtype and routes): fc7
+    features of the 4 crops and loss + gradients of the 16 captions against the oracle's.  Not timed."""
+    import numpy as np
+    import torch
+    got = L.from_jl(L.convnet_u8(ctx, torch.as_tensor(sample["img"]).cuda()))
+    ref = sample["ref_feats"]
+    vgg_err = float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30))
+    m = sample["model"]
+    grads, val = L.lossgradient(ctx, L.model_from_arrays(m.p), L.to_jl(sample["feats"]), sample["tokens"])
+    cos = []
+    for n, g in zip(L.PARAM_NAMES, grads):
+        a, b = L.from_jl(g).ravel().astype(np.float64), sample["ref_grads"].p[n].ravel().astype(np.float64)
+        cos.append(float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-300)))
+    return {"vgg_rel_max_err": vgg_err, "n_images": int(ref.shape[0]), "vgg_routes": L.debug_route(ctx, 1),
+            "loss_rel_err": float(abs(val - sample["ref_loss"]) / abs(sample["ref_loss"])), "n_captions": int(sample["tokens"].shape[1]),
+            "grad_cos_min": min(cos), "checker": "oracle/lrcn_oracle.c on the cpu_baseline sample"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)    # SURVEY 8(d): >= 50 timed steps after >= 10 warm-up
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--global-batch", type=int, default=256)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--hidden", type=int, default=1000)
@@ -123,13 +147,19 @@ def main():
     toks_all = [torch.as_tensor((rng.choice(V - 3, size=(T, Bg), p=pz) + 3).astype(np.int32)[:, rows.start:rows.stop]
                                 .copy()).cuda() for _ in range(n_sets)]
 
-    def run(nsteps):
+    step_ev = []
+
+    def run(nsteps, events=False):
         # steady-state pipeline: EVERY step (the last one too) issues the VGG forward of the batch after it, so a run of K steps
         # holds exactly K VGG forwards + K LSTM steps; the features a run's first step consumes were produced by the previous
         # run's last step (the warm-up's, for the timed region), or in order if there is none.
         for _ in range(nsteps):
             k = trainer.step_no  # global step index: batch k uses image/token set k mod n_sets, also across warm-up -> timed region
             trainer.step(imgs_all[k % n_sets], toks_all[k % n_sets], next_img_u8=imgs_all[(k + 1) % n_sets])
+            if events:  # one event per step on the main stream (no host sync): per-step intervals -> the median SURVEY 8(d) asks for
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                step_ev.append(e)
 
     def barrier():
         torch.cuda.synchronize()
@@ -141,10 +171,15 @@ def main():
     barrier()
     _lib = lrcn_amd._lib
     _lib.check(ctx._h, _lib.lib().lrcn_profile(ctx._h, 1))
+    e0 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    step_ev.append(e0)
     t0 = time.perf_counter()
-    run(a.steps)
+    run(a.steps, events=True)
     barrier()
     dt_s = time.perf_counter() - t0
+    step_ms = sorted(step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(len(step_ev) - 1))
+    median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     import ctypes as C
     conv_ms, conv_n = C.c_double(), C.c_int64()
     _lib.check(ctx._h, _lib.lib().lrcn_profile_get(ctx._h, C.byref(conv_ms), C.byref(conv_n)))
@@ -168,7 +203,7 @@ def main():
         out = {
             "metric": "training images/sec (VGG16+LSTM, COCO, batch 256) at 1/2/4/8 MI355X",
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "ms_per_step": ms_step, "ms_per_step_median": median_ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[3] (C4): MS-COCO-shaped VGG-16 -> fc7 fwd + LRCN-2f LSTM "
                                    "E=H=%d V=%d T=%d fwd/bwd + Adam, global batch %d, dp%d, dropout %.1f; synthetic uint8 "
@@ -184,7 +219,8 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             host_w = ([L.from_jl(w) for w in vgg_w[0]], [b.cpu().numpy() for b in vgg_w[1]],
                       (L.from_jl(vgg_w[2][0]), vgg_w[2][1].cpu().numpy()), (L.from_jl(vgg_w[3][0]), vgg_w[3][1].cpu().numpy()))
-            out["cpu_baseline"] = cpu_baseline(host_w, E, H, V, T, np.random.default_rng(3))
+            out["cpu_baseline"], sample = cpu_baseline(host_w, E, H, V, T, np.random.default_rng(3))
+            out["parity"] = parity_spot_check(ctx, L, sample)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -191,8 +191,8 @@ int lrcn_conv3x3_fp8(lrcn_ctx *ctx, const float *x, int W, int H, int Cin, int N
                      int relu, int pool, float sa_in, float sa_out, float *y, float *sw_out);
 
 /* ---- measurement (bench.py "roofline") ----
- * While enabled, every VGG forward brackets its 12 implicit-GEMM convolution launches (conv1_2..conv5_3: one kernel,
- * gemm_nt_kernel<.,128,128,CONV3>, back to back on the context's stream) with a pair of HIP events.
+ * While enabled, every VGG forward brackets its 12 convolution launches (bf16: conv1_1+conv1_2 fused and conv2_1 on
+ * conv64_kernel, conv2_2..conv5_3 on gemm8p_kernel<..,CONV3,..>; back to back on the context's stream) with a pair of HIP events.
  * lrcn_profile_get synchronises and returns the accumulated milliseconds and launch count since lrcn_profile(ctx,1). */
 int lrcn_profile(lrcn_ctx *ctx, int enable);
 int lrcn_profile_get(lrcn_ctx *ctx, double *conv_ms, int64_t *conv_launches);
@@ -201,6 +201,12 @@ int lrcn_profile_get(lrcn_ctx *ctx, double *conv_ms, int64_t *conv_launches);
 int lrcn_bench_conv(lrcn_ctx *ctx, int N, int S, int Cin, int Cout, int pool, int iters, double *ms_out);
 /* Same for one bf16 NT contraction C[M][N] = A[M][K] B[N][K]^T (K a multiple of 64, N of 8) through the library's dispatch. */
 int lrcn_bench_gemm(lrcn_ctx *ctx, int M, int N, int K, int iters, double *ms_out);
+
+/* Test / development aid: which kernel family did the work?  which = 0: the most recent contraction / convolution launched by
+ * the calling thread ("8p:0" = phase-interleaved 256x256 tile, "8p:1" = 256x128, "8p:2" = 512x128, "8p-splitk:<slices>", "glds",
+ * "skinny", "gemm_nt", "conv64", "conv64-fused11", ...); which = 1: the comma-separated routes of the layers of ctx's most recent
+ * VGG forward (conv1_1 [+conv1_2], ..., conv5_3, fc6, fc7).  The string is valid until the next call that launches work. */
+const char *lrcn_debug_route(lrcn_ctx *ctx, int which);
 
 #ifdef __cplusplus
 }

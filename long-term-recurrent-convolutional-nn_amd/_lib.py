@@ -82,6 +82,7 @@ SIGNATURES = {
                                C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "lrcn_vgg_set_wg_cap": (C.c_int, [C.c_void_p, C.c_int]),
     "lrcn_vgg_calibrate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_float]),
+    "lrcn_debug_route": (C.c_char_p, [C.c_void_p, C.c_int]),
     "lrcn_conv3x3_fp8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                    C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
 }

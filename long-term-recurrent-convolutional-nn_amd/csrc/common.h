@@ -20,6 +20,21 @@ template <typename T> __device__ __forceinline__ T from_f32(float x);
 template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { return (bf16_t)x; }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute: remember it per (kernel instantiation, device).
+// `done` is one function-local static per kernel instantiation; bit d = set on device ordinal d (ordinals >= 64 just re-set it).
+#include <atomic>
+typedef std::atomic<uint64_t> LdsAttrMask;
+static inline hipError_t set_max_lds(const void *kern, int lds, LdsAttrMask &done) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint64_t bit = dev < 64 ? (1ull << dev) : 0ull;
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+    return e;
+}
+
 static inline int64_t round_up64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

@@ -509,13 +509,10 @@ hipError_t launch_conv64(hipStream_t stream, const void *in, const void *w, cons
     int gx = (wg_cap >= 8 ? wg_cap : 256) / chunks;  // one workgroup per CU (all of LDS); capped: leaves CUs to the other stream
     if (gx < 1) gx = 1;
     if (gx > a.ntiles) gx = a.ntiles;
-    static bool attr_done[2] = {false, false};
+    static LdsAttrMask attr_done[2] = {{0}, {0}};
     auto kern = pool ? conv64_kernel<true, false> : conv64_kernel<false, false>;
-    if (!attr_done[pool ? 1 : 0]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr_done[pool ? 1 : 0] = true;
-    }
+    if (hipError_t e = set_max_lds(reinterpret_cast<const void *>(kern), LDS_BYTES, attr_done[pool ? 1 : 0]); e != hipSuccess) return e;
+    gemm_debug_note_route("conv64", -1);
     hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)chunks), dim3(512), LDS_BYTES, stream, a);
     return hipGetLastError();
 }
@@ -539,13 +536,10 @@ hipError_t launch_conv64_fused11(hipStream_t stream, const void *img16, const vo
     a.b11 = b11;
     int gx = wg_cap >= 8 ? wg_cap : 256;
     if (gx > a.ntiles) gx = a.ntiles;
-    static bool attr_done = false;
+    static LdsAttrMask attr_done{0};
     auto kern = conv64_kernel<true, true>;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    if (hipError_t e = set_max_lds(reinterpret_cast<const void *>(kern), F_LDS_BYTES, attr_done); e != hipSuccess) return e;
+    gemm_debug_note_route("conv64-fused11", -1);
     hipLaunchKernelGGL(kern, dim3((unsigned)gx, 1), dim3(512), F_LDS_BYTES, stream, a);
     return hipGetLastError();
 }

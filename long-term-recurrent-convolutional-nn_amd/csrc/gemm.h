@@ -36,6 +36,11 @@ struct GemmArgs {
 // CONV3: Cin a multiple of 32 (f32) / 64 (bf16).  Returns hipSuccess or an error; never faults on bad shapes.
 hipError_t launch_gemm(hipStream_t stream, const GemmArgs &g);
 
+// Test / development aid: the kernel family the most recent launch on this thread took ("8p:0" = 256x256 tile, "8p:1" = 256x128,
+// "8p:2" = 512x128, "8p-splitk:N", "glds", "skinny", "gemm_nt", "conv64", "conv64-fused11", ...).  lrcn_debug_last_route() returns it.
+void gemm_debug_note_route(const char *route, int cfg);
+const char *gemm_debug_last_route();
+
 // bf16 direct-to-LDS variant (gemm_glds.hip): 256-row tiles, global_load_lds staging, XOR-swizzled LDS.
 // launch_gemm routes to it when gemm_glds_eligible(g) and the grid is large enough to fill the chip.
 bool gemm_glds_eligible(const GemmArgs &g);

@@ -246,14 +246,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
 
 template <typename T, int BM, int BN, int AMODE> hipError_t launch_one(hipStream_t s, const GemmArgs &g) {
     constexpr int lds = 2 * (BM + BN) * ROWB;
-    static bool attr_done = false;
+    static LdsAttrMask attr_done{0};
     auto kern = gemm_nt_kernel<T, BM, BN, AMODE>;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    if (hipError_t e = set_max_lds(reinterpret_cast<const void *>(kern), lds, attr_done); e != hipSuccess) return e;
     const int64_t blocks = (int64_t)cdiv(g.M, BM) * cdiv(g.N, BN);
     if (blocks <= 0 || blocks > 0x7FFFFFFF) return hipErrorInvalidValue;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, s, g);
@@ -270,11 +265,25 @@ template <typename T> hipError_t dispatch(hipStream_t s, const GemmArgs &g) {
 
 }  // namespace
 
+static thread_local char g_route[48] = "";
+static thread_local int g_route_cfg = -1;
+void gemm_debug_note_route(const char *route, int cfg) {
+    if (route) {
+        if (cfg >= 0) snprintf(g_route, sizeof(g_route), "%s:%d", route, cfg);
+        else snprintf(g_route, sizeof(g_route), "%s", route);
+    } else {
+        g_route_cfg = cfg;  // tile config / slice count of the launch in flight (composed into the string by launch_gemm)
+    }
+}
+const char *gemm_debug_last_route() { return g_route; }
+
 static hipError_t launch_gemm_routed(hipStream_t stream, const GemmArgs &g, const char **route);
 hipError_t launch_gemm(hipStream_t stream, const GemmArgs &g) {
     static const bool trace = getenv("LRCN_GEMM_TRACE") != nullptr;  // development: print the kernel family every GEMM takes
     const char *route = "?";
+    g_route_cfg = -1;
     const hipError_t e = launch_gemm_routed(stream, g, &route);
+    gemm_debug_note_route(route, g_route_cfg);
     if (trace) fprintf(stderr, "[gemm] M=%d N=%d K=%d lda=%ld ldb=%ld amode=%d out=%d beta=%d -> %s\n", g.M, g.N, g.K, (long)g.lda, (long)g.ldb, g.a_mode, g.out_mode, (int)g.beta, route);
     return e;
 }

@@ -607,13 +607,9 @@ template <int WM, int WN, int MT, int NT, int AMODE, bool SWAP, bool F8 = false>
     constexpr int ring = 2 * (BM + BN) * 128, ctile = BM * BN * 2;
     constexpr int lds = ring > ctile ? ring : ctile;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    static bool attr_done = false;
+    static LdsAttrMask attr_done{0};
     auto kern = gemm8p_kernel<WM, WN, MT, NT, AMODE, SWAP, F8>;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    if (hipError_t e = set_max_lds(reinterpret_cast<const void *>(kern), lds, attr_done); e != hipSuccess) return e;
     const int64_t blocks = (int64_t)cdiv(g.M, BM) * cdiv(g.N, BN);
     if (blocks <= 0 || blocks > 0x7FFFFFFF) return hipErrorInvalidValue;
     int64_t grid = blocks;
@@ -743,6 +739,7 @@ hipError_t launch_gemm_8p(hipStream_t stream, const GemmArgs &g0, int splitk) {
     int64_t blocks = 0;
     int cfg = gemm_8p_config(g, &blocks);
     if (cfg < 0) return hipErrorInvalidValue;
+    gemm_debug_note_route(nullptr, splitk > 1 ? splitk : cfg);
     if (splitk > 1) {
         if (gemm_8p_splitk(g, &blocks) != splitk) return hipErrorInvalidValue;
         hipError_t e = dispatch<GEMM_A_PLAIN, true>(stream, g, 1, splitk);

@@ -339,13 +339,9 @@ template <int WM, int WN, int TM, int TN, int AMODE, int NBUF> hipError_t launch
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int lds = NBUF * (BM + BN) * 128;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    static bool attr_done = false;
+    static LdsAttrMask attr_done{0};
     auto kern = gemm_glds_kernel<WM, WN, TM, TN, AMODE, NBUF>;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    if (hipError_t e = set_max_lds(reinterpret_cast<const void *>(kern), lds, attr_done); e != hipSuccess) return e;
     const int64_t blocks = (int64_t)cdiv(g.M, BM) * cdiv(g.N, BN);
     if (blocks <= 0 || blocks > 0x7FFFFFFF) return hipErrorInvalidValue;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)splitk), dim3(WM * WN * 64), lds, s, g);

@@ -184,13 +184,9 @@ template <int MT, int PF> __global__ __launch_bounds__(256) void gemm_skinny_ker
 
 template <int MT, int PF> hipError_t launch_one(hipStream_t s, const GemmArgs &g, int splitk) {
     constexpr int lds = (PF + 1) * (MT * 16 + 64) * 128;
-    static bool attr_done = false;
+    static LdsAttrMask attr_done{0};
     auto kern = gemm_skinny_kernel<MT, PF>;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    if (hipError_t e = set_max_lds(reinterpret_cast<const void *>(kern), lds, attr_done); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)cdiv(g.N, 64), (unsigned)splitk), dim3(256), lds, s, g);
     return hipGetLastError();
 }

@@ -47,9 +47,14 @@ __global__ void build_tokens_kernel(const int32_t *tokens, int T, int B, int V, 
     const int s = i / B, b = i - s * B;
     int in = (s == 0) ? 1 : tokens[(s - 1) * B + b];
     int tg = (s < T) ? tokens[s * B + b] : 0;
-    // out-of-range ids would fault the gather: clamp to unk (the reference would raise BoundsError)
-    if ((unsigned)in >= (unsigned)V) in = 2;
-    if ((unsigned)tg >= (unsigned)V) tg = 2;
+    // out-of-range ids would fault the gather (the reference raises BoundsError, lrcn.jl:556/569): clamp to unk so that nothing
+    // faults, and raise the sticky flag zero_acc[1] -- the next synchronising call (lrcn_last_loss / loss_host / lrcn_sync)
+    // reports LRCN_EINVAL
+    if ((unsigned)in >= (unsigned)V || (unsigned)tg >= (unsigned)V) {
+        if (zero_acc) zero_acc[1] = 1.0;
+        if ((unsigned)in >= (unsigned)V) in = 2;
+        if ((unsigned)tg >= (unsigned)V) tg = 2;
+    }
     tok_in[i] = in;
     tok_tgt[i] = tg;
 }
@@ -797,8 +802,8 @@ __global__ __launch_bounds__(256) void softmax_topk_rows_kernel(const float *log
     __shared__ float sh[8];
     __shared__ float sv[4];
     __shared__ int si[4];
-    __shared__ float wv[32];
-    __shared__ int wi[32];
+    __shared__ float wv[64];
+    __shared__ int wi[64];
     const int r = blockIdx.x;
     const float *row = logits + (int64_t)r * ld;  // ld % 4 == 0, 16-byte aligned rows: columns [V, ld) may be read, never used
     float x[Q][4];
@@ -836,7 +841,13 @@ __global__ __launch_bounds__(256) void softmax_topk_rows_kernel(const float *log
         for (int j = 0; j < 4; ++j) se += __expf(x[q][j] - mx);  // exp(-inf) = 0 for the padding
     se = block_sum(se, sh);
     const float lse = mx + logf(se);
-    for (int k = 0; k < K; ++k) {
+    // Rounds 0 .. K-1 take the K largest logits.  The reference ranks the float32 PROBABILITIES with a stable sort (lrcn.jl:652-656),
+    // and distinct logits can round to one float probability: if candidates beyond the K-th still share the K-th winner's
+    // probability they belong to the same tie group, whose lowest INDICES win.  So the rounds go on (at most to 64 entries)
+    // until the next candidate's probability differs; all of this is block-uniform.
+    float pK = -1.0f;
+    int n = 0;
+    for (int k = 0; k < 64; ++k) {
         float bv = lv;
         int bi = li;
 #pragma unroll
@@ -862,10 +873,14 @@ __global__ __launch_bounds__(256) void softmax_topk_rows_kernel(const float *log
                 bv = sv[w];
                 bi = si[w];
             }
+        const float pv = expf(bv - lse);
+        if (k >= K && (pv != pK || bi == 0x7FFFFFFF)) break;  // uniform: every thread holds the same (bv, bi)
         if (threadIdx.x == 0) {
             wi[k] = bi;
-            wv[k] = expf(bv - lse);
+            wv[k] = pv;
         }
+        n = k + 1;
+        if (k == K - 1) pK = pv;
         if (((bi >> 2) & 255) == (int)threadIdx.x) {  // the owner retires the winner and finds its next candidate
             const int slot = bi >> 10, j0 = bi & 3;
 #pragma unroll
@@ -877,7 +892,7 @@ __global__ __launch_bounds__(256) void softmax_topk_rows_kernel(const float *log
         }
     }
     if (threadIdx.x == 0) {
-        for (int k = 1; k < K; ++k) {  // equal probabilities (distinct logits, same float): ascending index
+        for (int k = 1; k < n; ++k) {  // equal probabilities (distinct logits, same float): ascending index
             const float v = wv[k];
             const int ix = wi[k];
             int q = k;

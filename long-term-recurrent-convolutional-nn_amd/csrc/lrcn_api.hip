@@ -99,6 +99,7 @@ struct lrcn_ctx {
     size_t prof_used = 0;
     double prof_ms = 0.0;
     int64_t prof_launches = 0;
+    std::string vgg_routes;  // kernel family per layer of the most recent VGG forward (lrcn_debug_route)
 };
 
 #define FAIL(ctx, code, ...)                          \
@@ -120,6 +121,22 @@ struct lrcn_ctx {
     } while (0)
 
 namespace {
+
+// Every entry point that takes a context runs on the context's device, whatever device the calling thread had selected,
+// and restores the caller's selection on return (allocations, null-stream work and hipFuncSetAttribute are per device).
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(const lrcn_ctx *c) {
+        if (!c) return;
+        if (hipGetDevice(&prev) == hipSuccess && prev != c->cfg.device) switched = hipSetDevice(c->cfg.device) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
 
 template <class P> int dalloc(lrcn_ctx *c, P *&p, size_t bytes) {
     void *q = nullptr;
@@ -410,11 +427,16 @@ int loss_impl(lrcn_ctx *c, const float *const p[9], const float *feats, const in
     return LRCN_OK;
 }
 
+// logp[0] = running sum of log p(target); logp[1] = sticky "token id outside [0, V)" flag raised by build_tokens_kernel
 int fetch_loss(lrcn_ctx *c, double *out) {
-    double s = 0.0;
-    HIPCHK(c, hipMemcpyAsync(&s, c->logp, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    double s[2] = {0.0, 0.0};
+    HIPCHK(c, hipMemcpyAsync(s, c->logp, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    *out = -s / ((double)c->last_norm * (double)c->last_S);
+    if (s[1] != 0.0) {
+        HIPCHK(c, hipMemsetAsync(c->logp + 1, 0, sizeof(double), c->stream));
+        FAIL(c, LRCN_EINVAL, "a token id was outside [0, V=%d) (ids are 0-based at the ABI: eos=0, bos=1, unk=2; the reference raises BoundsError, lrcn.jl:556/569)", c->V);
+    }
+    if (out) *out = -s[0] / ((double)c->last_norm * (double)c->last_S);
     return LRCN_OK;
 }
 
@@ -489,7 +511,7 @@ int lrcn_memcpy_d2h(void *d, const void *s, size_t n) { return hipMemcpy(d, s, n
 
 void lrcn_destroy(lrcn_ctx *c) {
     if (!c) return;
-    (void)hipSetDevice(c->cfg.device);
+    DeviceGuard dg(c);
     (void)hipDeviceSynchronize();
     for (void *p : c->allocs) (void)hipFree(p);
     for (auto &e : c->grad_ev)
@@ -519,12 +541,17 @@ int lrcn_create(const lrcn_config *cfg, lrcn_ctx **out) {
         g_create_err = "no such HIP device (is a GPU visible?)";
         return LRCN_EHIP;
     }
-    if (hipSetDevice(cfg->device) != hipSuccess) {
-        g_create_err = "hipSetDevice failed";
-        return LRCN_EHIP;
-    }
     lrcn_ctx *c = new lrcn_ctx();
     c->cfg = *cfg;
+    DeviceGuard dg(c);  // allocate on cfg->device, then restore the caller's selection
+    {
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess || cur != cfg->device) {
+            g_create_err = "hipSetDevice failed";
+            delete c;
+            return LRCN_EHIP;
+        }
+    }
     c->dt = cfg->lstm_dtype == LRCN_BF16 ? GEMM_T_BF16 : GEMM_T_F32;
     c->vdt = cfg->vgg_dtype == LRCN_F32 ? GEMM_T_F32 : GEMM_T_BF16;  // LRCN_FP8: bf16 everywhere outside conv2_2..conv5_3
     c->vgg_fp8 = cfg->vgg_dtype == LRCN_FP8;
@@ -619,6 +646,7 @@ int lrcn_create(const lrcn_config *cfg, lrcn_ctx **out) {
 }
 
 int lrcn_vgg_set_wg_cap(lrcn_ctx *c, int cap) {
+    DeviceGuard dg(c);
     if (!c) return LRCN_EINVAL;
     if (cap < 0 || (cap > 0 && cap < 8)) FAIL(c, LRCN_EINVAL, "wg_cap=%d must be 0 (off) or >= 8", cap);
     c->vgg_wg_cap = cap;
@@ -626,17 +654,19 @@ int lrcn_vgg_set_wg_cap(lrcn_ctx *c, int cap) {
 }
 
 int lrcn_set_stream(lrcn_ctx *c, void *s) {
+    DeviceGuard dg(c);
     if (!c) return LRCN_EINVAL;
     c->stream = reinterpret_cast<hipStream_t>(s);
     return LRCN_OK;
 }
 int lrcn_sync(lrcn_ctx *c) {
     if (!c) return LRCN_EINVAL;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return LRCN_OK;
+    DeviceGuard dg(c);
+    return fetch_loss(c, nullptr);  // synchronises, and reports a pending out-of-range-token error
 }
 
 int lrcn_init_weights(lrcn_ctx *c, float *const p[9], uint64_t seed) {
+    DeviceGuard dg(c);
     if (!c || !p) return LRCN_EINVAL;
     int64_t sz[9];
     lrcn_param_sizes(c->E, c->H1, c->H2, c->V, sz);
@@ -657,6 +687,7 @@ int lrcn_init_weights(lrcn_ctx *c, float *const p[9], uint64_t seed) {
 
 int lrcn_loss(lrcn_ctx *c, const float *const p[9], const float *feats, const int32_t *tokens, int T, int B, int norm_B,
               const lrcn_dropout *drop, double *loss_host) {
+    DeviceGuard dg(c);
     if (!c || !p || !feats || (!tokens && T > 0)) return LRCN_EINVAL;
     int r = loss_impl(c, p, feats, tokens, T, B, norm_B, drop, nullptr, nullptr);
     if (r) return r;
@@ -665,6 +696,7 @@ int lrcn_loss(lrcn_ctx *c, const float *const p[9], const float *feats, const in
 
 int lrcn_loss_grad(lrcn_ctx *c, const float *const p[9], const float *feats, const int32_t *tokens, int T, int B, int norm_B,
                    const lrcn_dropout *drop, float *const grads[9], double *loss_host) {
+    DeviceGuard dg(c);
     if (!c || !p || !feats || (!tokens && T > 0) || !grads) return LRCN_EINVAL;
     int r = loss_impl(c, p, feats, tokens, T, B, norm_B, drop, grads, nullptr);
     if (r) return r;
@@ -672,24 +704,28 @@ int lrcn_loss_grad(lrcn_ctx *c, const float *const p[9], const float *feats, con
 }
 
 int lrcn_grad_group_wait(lrcn_ctx *c, int group, void *stream) {
+    DeviceGuard dg(c);
     if (!c || group < 0 || group >= LRCN_GRAD_GROUPS) return LRCN_EINVAL;
     HIPCHK(c, hipStreamWaitEvent(reinterpret_cast<hipStream_t>(stream), c->grad_ev[group], 0));
     return LRCN_OK;
 }
 
 int lrcn_last_loss(lrcn_ctx *c, double *loss_host) {
+    DeviceGuard dg(c);
     if (!c || !loss_host) return LRCN_EINVAL;
     return fetch_loss(c, loss_host);
 }
 
 int lrcn_forward_logits(lrcn_ctx *c, const float *const p[9], const float *feats, const int32_t *tokens, int T, int B,
                         float *logits_out) {
+    DeviceGuard dg(c);
     if (!c || !p || !feats || (!tokens && T > 0) || !logits_out) return LRCN_EINVAL;
     return loss_impl(c, p, feats, tokens, T, B, B, nullptr, nullptr, logits_out);
 }
 
 int lrcn_adam_update(lrcn_ctx *c, float *const p[9], const float *const g[9], float *const m[9], float *const v[9], int step,
                      float lr, float b1, float b2, float eps) {
+    DeviceGuard dg(c);
     if (!c || !p || !g || !m || !v || step < 1) return LRCN_EINVAL;
     AdamTensors t;
     int64_t sz[9];
@@ -708,6 +744,7 @@ int lrcn_adam_update(lrcn_ctx *c, float *const p[9], const float *const g[9], fl
 
 int lrcn_adam_update_group(lrcn_ctx *c, float *const p[9], const float *const g[9], float *const m[9], float *const v[9], int group,
                            int step, float lr, float b1, float b2, float eps, void *stream) {
+    DeviceGuard dg(c);
     if (!c || !p || !g || !m || !v || step < 1) return LRCN_EINVAL;
     if (group < 0 || group >= LRCN_GRAD_GROUPS) FAIL(c, LRCN_EINVAL, "group=%d outside [0,%d)", group, LRCN_GRAD_GROUPS);
     static const int kGroup[LRCN_GRAD_GROUPS][2] = {{7, 8}, {2, 3}, {4, 5}, {0, 1}, {6, 6}};  // order of the grad_ev records
@@ -730,6 +767,7 @@ int lrcn_adam_update_group(lrcn_ctx *c, float *const p[9], const float *const g[
 int lrcn_train_step(lrcn_ctx *c, float *const p[9], float *const g[9], float *const m[9], float *const v[9], const float *feats,
                     const int32_t *tokens, int T, int B, int norm_B, const lrcn_dropout *drop, int step, float lr, float b1,
                     float b2, float eps, double *loss_host) {
+    DeviceGuard dg(c);
     if (!c || !p || !g || !m || !v) return LRCN_EINVAL;
     int r = lrcn_loss_grad(c, p, feats, tokens, T, B, norm_B, drop, g, nullptr);
     if (r) return r;
@@ -740,6 +778,7 @@ int lrcn_train_step(lrcn_ctx *c, float *const p[9], float *const g[9], float *co
 
 int lrcn_lstm(lrcn_ctx *c, const float *W, const float *b, int X, int H, int B, const float *x, const float *h, const float *cc,
               float *h_out, float *c_out) {
+    DeviceGuard dg(c);
     if (!c || !W || !b || !x || !h || !cc || !h_out || !c_out) return LRCN_EINVAL;
     void *Wx, *Wh, *xb, *hb;
     if (X == c->E && H == c->H1) {
@@ -772,6 +811,7 @@ int lrcn_lstm(lrcn_ctx *c, const float *W, const float *b, int X, int H, int B, 
 
 int lrcn_step(lrcn_ctx *c, const float *const p[9], float *const state[4], int B, const float *x_cnn, const float *x_lstm,
               const float *mask1, const float *mask2, float *logits) {
+    DeviceGuard dg(c);
     if (!c || !p || !state || !x_cnn || !x_lstm || !logits) return LRCN_EINVAL;
     if (B < 1 || B > c->maxB) FAIL(c, LRCN_EINVAL, "B=%d outside [1,%d]", B, c->maxB);
     const int dt = c->dt, E = c->E, H1 = c->H1, H2 = c->H2, h = c->h, V = c->V;
@@ -801,8 +841,9 @@ int lrcn_step(lrcn_ctx *c, const float *const p[9], float *const state[4], int B
 
 int lrcn_beam_search(lrcn_ctx *c, const float *const p[9], const float *feat, int K, int nword, int32_t *out_tokens, int *out_len,
                      float *out_prob) {
+    DeviceGuard dg(c);
     if (!c || !p || !feat || !out_tokens || !out_len) return LRCN_EINVAL;
-    if (K < 1 || K > 32 || K > c->maxB) FAIL(c, LRCN_EINVAL, "beam width K=%d must be in [1, min(32, max_B=%d)]", K, c->maxB);
+    if (K < 1 || K > 32 || K > c->maxB || K > c->V) FAIL(c, LRCN_EINVAL, "beam width K=%d must be in [1, min(32, max_B=%d, V=%d)]", K, c->maxB, c->V);
     if (nword < 1 || nword > 256) FAIL(c, LRCN_EINVAL, "nword=%d outside [1,256]", nword);
     const int dt = c->dt, E = c->E, H1 = c->H1, H2 = c->H2, h = c->h, V = c->V;
     hipStream_t st = c->stream;
@@ -888,8 +929,9 @@ int lrcn_beam_search(lrcn_ctx *c, const float *const p[9], const float *feat, in
 // (bos first), out_len[N], out_prob[N] (may be NULL) on the HOST.
 int lrcn_beam_search_batch(lrcn_ctx *c, const float *const p[9], const float *feats, int N, int K, int nword, int32_t *out_tokens,
                            int *out_len, float *out_prob) {
+    DeviceGuard dg(c);
     if (!c || !p || !feats || !out_tokens || !out_len) return LRCN_EINVAL;
-    if (K < 1 || K > 32) FAIL(c, LRCN_EINVAL, "beam width K=%d must be in [1, 32]", K);
+    if (K < 1 || K > 32 || K > c->V) FAIL(c, LRCN_EINVAL, "beam width K=%d must be in [1, min(32, V=%d)]", K, c->V);
     if (N < 1 || (int64_t)N * K > c->maxB) FAIL(c, LRCN_EINVAL, "N*K = %d*%d exceeds max_B = %d", N, K, c->maxB);
     if (nword < 1 || nword + 2 > LRCN_BEAM_MAXLEN) FAIL(c, LRCN_EINVAL, "nword=%d outside [1,%d]", nword, LRCN_BEAM_MAXLEN - 2);
     const int dt = c->dt, E = c->E, H1 = c->H1, H2 = c->H2, h = c->h, V = c->V;
@@ -963,6 +1005,7 @@ static const int kVggPool[13] = {0, 1, 0, 1, 0, 0, 1, 0, 0, 1, 0, 0, 1};
 
 int lrcn_vgg_load(lrcn_ctx *c, const float *const cw[13], const float *const cb[13], const float *fc6_w, const float *fc6_b,
                   const float *fc7_w, const float *fc7_b) {
+    DeviceGuard dg(c);
     if (!c || !cw || !cb || !fc6_w || !fc6_b || !fc7_w || !fc7_b) return LRCN_EINVAL;
     if (c->cfg.max_images < 1) FAIL(c, LRCN_ESTATE, "context was created with max_images = 0");
     if (c->vgg_loaded) FAIL(c, LRCN_ESTATE, "VGG weights already loaded");
@@ -1045,8 +1088,8 @@ int conv_layer(lrcn_ctx *c, int dtype, const void *in, const VggLayer &L, int N,
     g.H = g.W = L.S;
     g.Cin = L.Cin;
     g.zero_page = c->zero_page;
-    g.ws = c->gemm_ws;
-    g.ws_bytes = c->gemm_ws_bytes;
+    g.ws = c->vgg_ws;  // one split-K workspace per stream: the VGG forward may run beside the LSTM step (gemm_ws)
+    g.ws_bytes = c->vgg_ws ? c->gemm_ws_bytes : 0;
     g.wg_cap = c->vgg_wg_cap;
     hipError_t e = launch_gemm(c->stream, g);
     if (e != hipSuccess) FAIL(c, LRCN_EHIP, "conv layer S=%d Cin=%d Cout=%d: %s", L.S, L.Cin, L.Cout, hipGetErrorString(e));
@@ -1088,6 +1131,11 @@ int vgg_body(lrcn_ctx *c, int N, const void *src, bool src_u8, const float *mean
     const float m0 = mean ? mean[0] : 0.f, m1 = mean ? mean[1] : 0.f, m2 = mean ? mean[2] : 0.f;
     const char *kf = getenv("LRCN_FUSE11");  // LRCN_FUSE11=0: conv1_1 and conv1_2 as two launches
     const bool fuse11 = vdt == GEMM_T_BF16 && src_u8 && c->conv[0].w_fused && conv64_enabled() && !(kf && kf[0] == '0');
+    c->vgg_routes.clear();
+    auto note = [&](const char *r) {
+        if (!c->vgg_routes.empty()) c->vgg_routes += ',';
+        c->vgg_routes += r;
+    };
     if (fuse11) {
         // read_image_data's arithmetic as an elementwise pass (38 MB -> 77 MB at N = 256); conv1_1 itself runs inside conv1_2's launch
         k_img_u8_to_bf16(c->stream, reinterpret_cast<const uint8_t *>(src), (int64_t)N * 224 * 224 * 3, m0, m1, m2, c->img16);
@@ -1120,6 +1168,7 @@ int vgg_body(lrcn_ctx *c, int N, const void *src, bool src_u8, const float *mean
         hipError_t e = launch_gemm(c->stream, g);
         if (e != hipSuccess) FAIL(c, LRCN_EHIP, "conv1_1: %s", hipGetErrorString(e));
     }
+    if (!fuse11) note(vdt == GEMM_T_BF16 ? "conv11" : gemm_debug_last_route());
     void *cur = c->actA, *nxt = c->actB;
     std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
     if (c->prof) {
@@ -1137,6 +1186,7 @@ int vgg_body(lrcn_ctx *c, int N, const void *src, bool src_u8, const float *mean
         hipError_t e = launch_conv64_fused11(c->stream, c->img16, c->conv[0].w_fused, c->conv[0].b, c->conv[1].w, c->conv[1].b, nxt, N, 224,
                                              c->zero_page, c->vgg_wg_cap);
         if (e != hipSuccess) FAIL(c, LRCN_EHIP, "fused conv1_1+conv1_2: %s", hipGetErrorString(e));
+        note(gemm_debug_last_route());
         std::swap(cur, nxt);
         l0 = 2;
     }
@@ -1157,6 +1207,7 @@ int vgg_body(lrcn_ctx *c, int N, const void *src, bool src_u8, const float *mean
         else  // conv2_1 writes the e4m3 input of conv2_2 directly when it runs on conv64.hip
             r = conv_layer(c, vdt, cur, c->conv[l], N, nxt, (fp8 && l == kFp8First - 1) ? 1.0f / c->act_scale[l] : 0.0f, &in_is_f8);
         if (r) return r;
+        note(gemm_debug_last_route());
         std::swap(cur, nxt);
         if (calibrate && l >= kFp8First - 1) k_amax(c->stream, 0, cur, out_count(l), c->amax_dev + l);
     }
@@ -1184,6 +1235,7 @@ int vgg_body(lrcn_ctx *c, int N, const void *src, bool src_u8, const float *mean
     g.relu = 1;
     hipError_t e = launch_gemm(c->stream, g);  // N = 256 images: 205 MB of weights through 32 tiles -> gemm_8p's split-K form
     if (e != hipSuccess) FAIL(c, LRCN_EHIP, "fc6: %s", hipGetErrorString(e));
+    note(gemm_debug_last_route());
     g.A = c->f6;
     g.lda = 4096;
     g.B = c->fc7w;
@@ -1195,6 +1247,7 @@ int vgg_body(lrcn_ctx *c, int N, const void *src, bool src_u8, const float *mean
     g.c_f32 = 1;
     e = launch_gemm(c->stream, g);
     if (e != hipSuccess) FAIL(c, LRCN_EHIP, "fc7: %s", hipGetErrorString(e));
+    note(gemm_debug_last_route());
     return LRCN_OK;
 }
 int vgg_check(lrcn_ctx *c, int N) {
@@ -1204,7 +1257,13 @@ int vgg_check(lrcn_ctx *c, int N) {
 }
 }  // namespace
 
+const char *lrcn_debug_route(lrcn_ctx *c, int which) {
+    if (which == 1) return c ? c->vgg_routes.c_str() : "";
+    return gemm_debug_last_route();
+}
+
 int lrcn_profile(lrcn_ctx *c, int enable) {
+    DeviceGuard dg(c);
     if (!c) return LRCN_EINVAL;
     c->prof = enable != 0;
     c->prof_used = 0;
@@ -1214,6 +1273,7 @@ int lrcn_profile(lrcn_ctx *c, int enable) {
 }
 
 int lrcn_profile_get(lrcn_ctx *c, double *conv_ms, int64_t *conv_launches) {
+    DeviceGuard dg(c);
     if (!c || !conv_ms || !conv_launches) return LRCN_EINVAL;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (size_t i = 0; i < c->prof_used; ++i) {
@@ -1230,6 +1290,7 @@ int lrcn_profile_get(lrcn_ctx *c, double *conv_ms, int64_t *conv_launches) {
 
 // Diagnostic: time one bf16 implicit-GEMM convolution layer (random data) in isolation: avg ms over `iters` launches.
 int lrcn_bench_conv(lrcn_ctx *c, int N, int S, int Cin, int Cout, int pool, int iters, double *ms_out) {
+    DeviceGuard dg(c);
     if (!c || !ms_out || N < 1 || S < 2 || (S & 1) || Cin % 64 || Cout < 1 || iters < 1) return LRCN_EINVAL;
     const size_t in_e = (size_t)N * S * S * Cin, w_e = (size_t)Cout * 9 * Cin, out_e = (size_t)N * S * S * Cout;
     void *in = nullptr, *w = nullptr, *out = nullptr;
@@ -1271,6 +1332,7 @@ int lrcn_bench_conv(lrcn_ctx *c, int N, int S, int Cin, int Cout, int pool, int 
 
 // Diagnostic: time one bf16 NT GEMM C[M][N] = A[M][K] B[N][K]^T (random data, bf16 output) through launch_gemm.
 int lrcn_bench_gemm(lrcn_ctx *c, int M, int N, int K, int iters, double *ms_out) {
+    DeviceGuard dg(c);
     if (!c || !ms_out || M < 1 || N < 8 || K < 64 || (K % 64) || (N % 8) || iters < 1) return LRCN_EINVAL;
     void *A = nullptr, *B = nullptr, *C = nullptr;
     float *tmp = nullptr;
@@ -1307,6 +1369,7 @@ int lrcn_bench_gemm(lrcn_ctx *c, int M, int N, int K, int iters, double *ms_out)
 }
 
 int lrcn_vgg_forward(lrcn_ctx *c, const float *x, int N, float *feats) {
+    DeviceGuard dg(c);
     if (!c || !x || !feats) return LRCN_EINVAL;
     int r = vgg_check(c, N);
     if (r) return r;
@@ -1318,6 +1381,7 @@ int lrcn_vgg_forward(lrcn_ctx *c, const float *x, int N, float *feats) {
 }
 
 int lrcn_vgg_forward_u8(lrcn_ctx *c, const uint8_t *img, int N, const float mean[3], float *feats) {
+    DeviceGuard dg(c);
     if (!c || !img || !feats || !mean) return LRCN_EINVAL;
     int r = vgg_check(c, N);
     if (r) return r;
@@ -1329,6 +1393,7 @@ int lrcn_vgg_forward_u8(lrcn_ctx *c, const uint8_t *img, int N, const float mean
 }
 
 int lrcn_preprocess_u8(lrcn_ctx *c, const uint8_t *img, int N, const float mean[3], float *out) {
+    DeviceGuard dg(c);
     if (!c || !img || !out || !mean || N < 1) return LRCN_EINVAL;
     k_preprocess_u8(c->stream, img, N, 224, mean[0], mean[1], mean[2], out);
     KCHK(c, "preprocess_u8");
@@ -1337,6 +1402,7 @@ int lrcn_preprocess_u8(lrcn_ctx *c, const uint8_t *img, int N, const float mean[
 
 int lrcn_conv3x3(lrcn_ctx *c, const float *x, int W, int H, int Cin, int N, const float *w, const float *b, int Cout, int relu,
                  int pool, float *y) {
+    DeviceGuard dg(c);
     if (!c || !x || !w || !b || !y) return LRCN_EINVAL;
     if (W < 2 || H < 2 || (W & 1) || (H & 1) || Cin < 1 || Cout < 1 || N < 1) FAIL(c, LRCN_EINVAL, "conv3x3: W,H must be even, sizes positive");
     const int vdt = c->vdt;
@@ -1402,6 +1468,7 @@ int lrcn_conv3x3(lrcn_ctx *c, const float *x, int W, int H, int Cin, int N, cons
 }
 
 int lrcn_vgg_calibrate(lrcn_ctx *c, const uint8_t *img, int N, const float mean[3], float margin) {
+    DeviceGuard dg(c);
     if (!c || !img || !mean) return LRCN_EINVAL;
     if (!c->vgg_fp8) FAIL(c, LRCN_ESTATE, "lrcn_vgg_calibrate needs a context created with vgg_dtype = LRCN_FP8");
     if (!(margin >= 1.0f) || margin > 16.0f) FAIL(c, LRCN_EINVAL, "margin=%g outside [1,16]", margin);
@@ -1429,6 +1496,7 @@ int lrcn_vgg_calibrate(lrcn_ctx *c, const uint8_t *img, int N, const float mean[
 
 int lrcn_conv3x3_fp8(lrcn_ctx *c, const float *x, int W, int H, int Cin, int N, const float *w, const float *b, int Cout, int relu,
                      int pool, float sa_in, float sa_out, float *y, float *sw_out) {
+    DeviceGuard dg(c);
     if (!c || !x || !w || !b || !y) return LRCN_EINVAL;
     if (W < 2 || H < 2 || (W & 1) || (H & 1) || Cin < 128 || (Cin % 128) || Cout < 128 || (Cout % 16) || N < 1 || (int64_t)N * W * H < 256 ||
         !(sa_in > 0.0f) || !(sa_out > 0.0f))

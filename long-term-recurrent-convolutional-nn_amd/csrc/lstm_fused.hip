@@ -238,12 +238,7 @@ template <int MT> __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(con
     }
 }
 
-template <class K> hipError_t set_lds(K kern, int lds, bool &done) {
-    if (done) return hipSuccess;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e == hipSuccess) done = true;
-    return e;
-}
+template <class K> hipError_t set_lds(K kern, int lds, LdsAttrMask &done) { return set_max_lds(reinterpret_cast<const void *>(kern), lds, done); }
 
 }  // namespace
 
@@ -259,7 +254,7 @@ hipError_t launch_lstm_rec_fwd(hipStream_t st, const void *h_prev, int64_t ldh, 
     a.acts = (bf16_t *)acts; a.c_new = c_new; a.h_new = (bf16_t *)h_new; a.zero_page = zero_page;
     a.ldh = ldh; a.ld_a = ld_a; a.B = B; a.H = H;
     const dim3 grid((H + 15) / 16, B <= 32 ? 1 : (B + 63) / 64);
-    static bool d2 = false, d4 = false;
+    static LdsAttrMask d2{0}, d4{0};
     hipError_t e;
     if (B <= 32) {
         if ((e = set_lds(lstm_rec_fwd_kernel<2>, FusedGeom<2>::LDS, d2)) != hipSuccess) return e;
@@ -278,7 +273,7 @@ hipError_t launch_lstm_rec_bwd(hipStream_t st, const void *dz_s, int64_t ld4, co
     a.dh_ext = dh_ext; a.dc = dc; a.dz_out = (bf16_t *)dz_out; a.zero_page = zero_page;
     a.ld4 = ld4; a.B = B; a.H = H;
     const dim3 grid((H + 15) / 16, B <= 32 ? 1 : (B + 63) / 64);
-    static bool d2 = false, d4 = false;
+    static LdsAttrMask d2{0}, d4{0};
     hipError_t e;
     if (B <= 32) {
         if ((e = set_lds(lstm_rec_bwd_kernel<2>, FusedGeom<2>::LDS, d2)) != hipSuccess) return e;

@@ -156,13 +156,18 @@ class DataParallelTrainer:
             feats = self.ops.vgg(img_u8, feats=self._feats_buf[k])
         finally:
             self.ctx.use_stream(main)
+        if torch.is_tensor(img_u8) and img_u8.is_cuda:
+            # the crops were allocated on the main stream but are read by the side stream: tell the caching allocator, so a
+            # caller that drops them right after step() cannot have the block recycled under the running convolution
+            img_u8.record_stream(self._side)
         self._vgg_done = torch.cuda.Event()
         self._vgg_done.record(self._side)
         return feats
 
     def step(self, img_u8, tokens, next_img_u8=None, feats=None):
         """One synchronous-SGD step on this rank's shard.  img_u8: this rank's uint8 crops (or feats given);
-        next_img_u8: the NEXT step's crops, whose VGG forward runs beside this step's LSTM work and all-reduce."""
+        next_img_u8: the NEXT step's crops, whose VGG forward runs beside this step's LSTM work and all-reduce.
+        img_u8 is IGNORED when the previous step() prefetched this batch's features through its next_img_u8."""
         if feats is None:
             if self._feats_next is not None:
                 feats = self._feats_next

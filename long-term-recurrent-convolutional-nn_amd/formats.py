@@ -24,7 +24,8 @@ def save_checkpoint(path, model, vocab, adam=None, meta=None):
     """model: 9 arrays in reference shapes (host, float32); vocab: word -> 1-based id; adam: optional
     dict(m=[9 arrays], v=[9 arrays], step=int)."""
     d = {"param_%d_%s" % (i, n): np.asarray(a, dtype=np.float32) for i, (n, a) in enumerate(zip(PARAM_NAMES, model))}
-    d["vocab_words"] = np.array(sorted(vocab, key=vocab.get), dtype=object)
+    # the words as ONE JSON string (like `meta`): no dtype=object array, so loading never needs pickle
+    d["vocab_json"] = np.array(json.dumps(sorted(vocab, key=vocab.get), ensure_ascii=False))
     d["vocab_ids"] = np.array([vocab[w] for w in sorted(vocab, key=vocab.get)], dtype=np.int64)
     if adam is not None:
         for i, (m, v) in enumerate(zip(adam["m"], adam["v"])):
@@ -39,9 +40,14 @@ def save_checkpoint(path, model, vocab, adam=None, meta=None):
 
 def load_checkpoint(path):
     """-> (model list of 9 float32 arrays, vocab dict, adam dict or None, meta dict)."""
-    z = np.load(path, allow_pickle=True)
+    z = np.load(path, allow_pickle=False)  # a checkpoint is data: nothing in it may execute on load
     model = [z["param_%d_%s" % (i, n)] for i, n in enumerate(PARAM_NAMES)]
-    vocab = {str(w): int(i) for w, i in zip(z["vocab_words"], z["vocab_ids"])}
+    if "vocab_json" in z.files:
+        words = json.loads(str(z["vocab_json"]))
+    else:  # round-1 files stored the words as a pickled object array
+        raise ValueError("%s holds a pickled vocabulary (pre-round-2 checkpoint); re-save it with save_checkpoint -- "
+                         "pickled checkpoints are not loaded" % path)
+    vocab = {str(w): int(i) for w, i in zip(words, z["vocab_ids"])}
     adam = None
     if "adam_step" in z.files:
         adam = {"m": [z["adam_m_%d" % i] for i in range(9)], "v": [z["adam_v_%d" % i] for i in range(9)],

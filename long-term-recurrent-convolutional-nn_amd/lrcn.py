@@ -394,8 +394,15 @@ def conv3x3_fp8(ctx, x, w, b, sa_in, sa_out, relu=True, pool=False):
     return y, sw
 
 
-def synthetic_vgg_weights(seed=1, device="cuda"):
-    """He-normal(fan_in) VGG-16 weights, zero biases (no pretrained file offline)."""
+def debug_route(ctx, which=0):
+    """Kernel family of the last contraction (which=0) / per layer of the last VGG forward (which=1): lrcn_debug_route."""
+    r = _lib.lib().lrcn_debug_route(ctx._h, int(which))
+    return r.decode() if r else ""
+
+
+def synthetic_vgg_weights(seed=1, device="cuda", bias_std=0.0):
+    """He-normal(fan_in) VGG-16 weights (no pretrained file offline); biases zero, or N(0, bias_std)
+    so that every bias path of the kernels sees non-zero values (parity tests)."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     conv_w, conv_b = [], []
@@ -404,10 +411,12 @@ def synthetic_vgg_weights(seed=1, device="cuda"):
         w = jl_empty(3, 3, cin, cout, device=device)
         w.copy_(torch.randn((3, 3, cin, cout), generator=g, device=device) * float(np.sqrt(2.0 / (9 * cin))))
         conv_w.append(w)
-        conv_b.append(torch.zeros(cout, device=device))
+        conv_b.append(torch.randn(cout, generator=g, device=device) * bias_std if bias_std else torch.zeros(cout, device=device))
         cin = cout
     fc6 = jl_empty(4096, 25088, device=device)
     fc6.copy_(torch.randn((4096, 25088), generator=g, device=device) * float(np.sqrt(2.0 / 25088)))
     fc7 = jl_empty(4096, 4096, device=device)
     fc7.copy_(torch.randn((4096, 4096), generator=g, device=device) * float(np.sqrt(2.0 / 4096)))
-    return conv_w, conv_b, (fc6, torch.zeros(4096, device=device)), (fc7, torch.zeros(4096, device=device))
+    b6 = torch.randn(4096, generator=g, device=device) * bias_std if bias_std else torch.zeros(4096, device=device)
+    b7 = torch.randn(4096, generator=g, device=device) * bias_std if bias_std else torch.zeros(4096, device=device)
+    return conv_w, conv_b, (fc6, b6), (fc7, b7)

@@ -125,6 +125,18 @@ def test_checkpoint_and_feature_round_trip(tmp_path):
         np.testing.assert_array_equal(x, y)
     fmt.save_checkpoint(p, model, vocab)
     assert fmt.load_checkpoint(p)[2] is None  # the reference's payload: no optimizer state
+    # a checkpoint is plain data: no object arrays inside (np.load(allow_pickle=False) reads every member), unicode words survive
+    z = np.load(p, allow_pickle=False)
+    assert all(z[k].dtype != object for k in z.files)
+    uni = {"~~": 1, "caf\u00e9": 2, "\u72ac": 3}
+    fmt.save_checkpoint(p, model, uni)
+    assert fmt.load_checkpoint(p)[1] == uni
+    # and a file that does carry a pickled object array (the round-1 layout) is refused, never unpickled
+    legacy = str(tmp_path / "legacy.npz")
+    d = {"param_%d_%s" % (i, n): a for i, (n, a) in enumerate(zip(fmt.PARAM_NAMES, model))}
+    np.savez(legacy, vocab_words=np.array(list(vocab), dtype=object), vocab_ids=np.arange(4), meta=np.array("{}"), **d)
+    with pytest.raises(ValueError):
+        fmt.load_checkpoint(legacy)
     feats = {42: np.arange(4096, dtype=np.float32) + 1, 7: np.ones(4096, np.float32)}
     fp = str(tmp_path / "f.npz")
     fmt.save_features(fp, feats)

@@ -163,3 +163,15 @@ def test_preprocess_u8_layout():
     # out(i,j,c,n) = pixel(row=i, col=j, c) - mean[c]  (lrcn.jl:766-772)
     ref = np.transpose(img.astype(np.float32), (1, 2, 3, 0)) - mean[None, None, :, None]
     np.testing.assert_array_equal(out, ref)
+
+
+def test_oracle_sanitizer_build_runs_clean():
+    # AddressSanitizer + UBSan pass over every oracle entry point (oracle/selftest.c); CPU only by necessity
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    r = subprocess.run(["make", "-s", "-C", here, "-f", os.path.join(here, "Makefile"), "asan"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "oracle selftest ok" in r.stdout
