@@ -70,13 +70,17 @@ def cpu_baseline(vgg_w, E, H, V, T, rng):
                   "ref_grads": ref_g}
 
 
-def parity_spot_check(ctx, L, sample):
-    """The cpu_baseline sample through the HIP path of THIS context (the benchmark's kernels, dtype and routes): fc7
-    features of the 4 crops and loss + gradients of the 16 captions against the oracle's.  Not timed."""
+def parity_spot_check(ctx, L, sample, batch_imgs):
+    """The cpu_baseline sample through the HIP path of THIS context: the 4 crops replace the first rows of one of the
+    benchmark's own image batches, so the VGG forward runs at the benchmark's batch size with the benchmark's kernels and
+    routes (reported); loss + gradients of the 16 captions against the oracle's.  Not timed."""
     import numpy as np
     import torch
-    got = L.from_jl(L.convnet_u8(ctx, torch.as_tensor(sample["img"]).cuda()))
-    ref = sample["ref_feats"]
+    imgs = batch_imgs.clone()
+    n = min(sample["img"].shape[0], imgs.shape[0])
+    imgs[:n] = torch.as_tensor(sample["img"][:n]).cuda()
+    got = L.from_jl(L.convnet_u8(ctx, imgs))[:n]
+    ref = sample["ref_feats"][:n]
     vgg_err = float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30))
     m = sample["model"]
     grads, val = L.lossgradient(ctx, L.model_from_arrays(m.p), L.to_jl(sample["feats"]), sample["tokens"])
@@ -220,7 +224,7 @@ def main():
             host_w = ([L.from_jl(w) for w in vgg_w[0]], [b.cpu().numpy() for b in vgg_w[1]],
                       (L.from_jl(vgg_w[2][0]), vgg_w[2][1].cpu().numpy()), (L.from_jl(vgg_w[3][0]), vgg_w[3][1].cpu().numpy()))
             out["cpu_baseline"], sample = cpu_baseline(host_w, E, H, V, T, np.random.default_rng(3))
-            out["parity"] = parity_spot_check(ctx, L, sample)
+            out["parity"] = parity_spot_check(ctx, L, sample, imgs_all[0])
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -104,7 +104,7 @@ def test_beam5_large_vocab_topk_instantiations_vs_oracle(V):
     # softmax_topk_rows_kernel<Q>: V = 7730 -> <8>, 10640 -> <12>, 16001 -> <16>, 4097 -> <8> (first float4 past 4096);
     # small E = H = 64 model so the oracle's K sequential decodes stay cheap; fp32 so candidates order identically
     E = H = 64
-    K, nword = 5, 12
+    K, nword = 5, 6   # 7 steps: the float32 product of probabilities stays far above the denormal range
     rng = np.random.default_rng(V)
     m = orc.init_weights(E, H, H, V, seed=V)
     m.p["Wout"] *= 8.0   # spread the distribution: top-5 gaps far above fp32 noise
@@ -116,7 +116,7 @@ def test_beam5_large_vocab_topk_instantiations_vs_oracle(V):
     for i in range(3):
         seq, p = L.beam_search(ctx, param, L.to_jl(feats[i:i + 1]), K, nword)
         assert seq == list(refs[i][0]), (V, i)
-        assert abs(p - refs[i][1]) <= 1e-4 * refs[i][1]
+        assert refs[i][1] > 1e-30 and abs(p - refs[i][1]) <= 1e-4 * refs[i][1]
     batch = L.beam_search_batch(ctx, param, L.to_jl(feats), K, nword)
     for i in range(3):
         assert batch[i][0] == list(refs[i][0]) and abs(batch[i][1] - refs[i][1]) <= 1e-4 * refs[i][1]
