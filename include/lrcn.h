@@ -56,6 +56,11 @@ typedef struct {
     int lstm_dtype; /* LRCN_F32 | LRCN_BF16 */
     int vgg_dtype;  /* LRCN_F32 | LRCN_BF16 | LRCN_FP8 (conv2_2..conv5_3 in OCP e4m3 after lrcn_vgg_calibrate; the rest bf16) */
     int max_images; /* VGG batch capacity; 0 = no VGG in this context */
+    int n_layers;   /* 0 or 2: the reference's two-layer LRCN-2f (lrcn.jl:540-551).  1: LRCN-1f (BASELINE configs[1] "1-layer
+                     * LSTM", SURVEY 8d -- this repo's definition, the reference hard-wires two layers): LSTM-1 and Wproj are
+                     * dropped and ONE LSTM of width H1 == H2 reads dropout(hcat(embedding, x_cnn)) at every step.  Its model
+                     * keeps the 9-slot order with W1 (E+h+H) x 4H in slot 0, b1 in slot 1, slots 2..4 (W2, b2, Wproj) unused
+                     * (NULL / size 0); state = {h, c}; lrcn_dropout.mask1 holds (T+1) blocks of B x (E+h), mask2 is unused. */
 } lrcn_config;
 
 /* ---- lifetime / plumbing ---- */
@@ -75,8 +80,9 @@ int lrcn_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
 const char *lrcn_version(void);
 
 /* ---- model ---- */
-/* Element counts of the 9 tensors. */
+/* Element counts of the 9 tensors (two-layer model), and for a given lrcn_config.n_layers (0 for the slots a model lacks). */
 int lrcn_param_sizes(int E, int H1, int H2, int V, int64_t sizes[9]);
+int lrcn_param_sizes_n(int n_layers, int E, int H1, int H2, int V, int64_t sizes[9]);
 /* initweights (lrcn.jl:489-510): xavier-uniform +-sqrt(2/(fanin+fanout)), zero biases, forget-gate bias 1.
  * Julia's RNG stream is not reproducible; the generator is a counter-based hash keyed by (seed, tensor, index). */
 int lrcn_init_weights(lrcn_ctx *ctx, float *const params[9], uint64_t seed);

@@ -25,7 +25,7 @@ class LrcnError(RuntimeError):
 class Config(C.Structure):
     _fields_ = [("device", C.c_int), ("E", C.c_int), ("H1", C.c_int), ("H2", C.c_int), ("V", C.c_int),
                 ("max_B", C.c_int), ("max_T", C.c_int), ("lstm_dtype", C.c_int), ("vgg_dtype", C.c_int),
-                ("max_images", C.c_int)]
+                ("max_images", C.c_int), ("n_layers", C.c_int)]
 
 
 class Dropout(C.Structure):
@@ -49,6 +49,7 @@ SIGNATURES = {
     "lrcn_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "lrcn_version": (C.c_char_p, []),
     "lrcn_param_sizes": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
+    "lrcn_param_sizes_n": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
     "lrcn_init_weights": (C.c_int, [C.c_void_p, P9, C.c_uint64]),
     "lrcn_lstm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                             C.c_void_p, C.c_void_p, C.c_void_p]),

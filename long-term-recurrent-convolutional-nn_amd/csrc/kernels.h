@@ -39,11 +39,12 @@ hipError_t launch_lstm_rec_fwd(hipStream_t st, const void *h_prev, int64_t ldh, 
 hipError_t launch_lstm_rec_bwd(hipStream_t st, const void *dz_s, int64_t ld4, const void *WhT, const void *acts, const float *c_prev,
                                const float *c_new, const float *dh_ext, float *dc, int B, int H, void *dz_out, const void *zero_page);
 
-// X2[m][j<h] *= mask ; X2[m][h+j] = xcnn[b][j] * mask      (lrcn.jl:546-547)
+// X2[m][j<nl] *= mask ; X2[m][nl+j] = xcnn[b][j] * mask (j < nr); mask over nl+nr columns      (lrcn.jl:546-547: nl = nr = h;
+// LRCN-1f: nl = E, nr = h)
 void k_concat_x2(hipStream_t st, int dtype, void *x2, int64_t ld_x2, const float *xcnn, int64_t ld_xc, int S, int B,
-                 int h, DropSpec d);
-// dX2[m][j] *= mask (all 2h columns, in place);  dxcnn[b][j] = sum_s dX2[s*B+b][h+j]
-void k_dx2_mask_reduce(hipStream_t st, int dtype, void *dx2, int64_t ld, int S, int B, int h, DropSpec d,
+                 int nl, int nr, DropSpec d);
+// dX2[m][j] *= mask (all nl+nr columns, in place);  dxcnn[b][j] = sum_s dX2[s*B+b][nl+j]
+void k_dx2_mask_reduce(hipStream_t st, int dtype, void *dx2, int64_t ld, int S, int B, int nl, int nr, DropSpec d,
                        float *dxcnn, int64_t ld_dxc);
 
 // Row-wise log-softmax + target pick + (optional) dlogits = (softmax - onehot) * scale   (lrcn.jl:562-567 and dual).

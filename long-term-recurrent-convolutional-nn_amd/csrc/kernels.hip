@@ -126,28 +126,28 @@ __global__ void lstm_bwd_kernel(const T *acts, int64_t ld_a, const float *c_prev
 }
 
 template <typename T>
-__global__ void concat_x2_kernel(T *x2, int64_t ld_x2, const float *xcnn, int64_t ld_xc, int S, int B, int h, DropSpec d) {
+__global__ void concat_x2_kernel(T *x2, int64_t ld_x2, const float *xcnn, int64_t ld_xc, int S, int B, int nl, int nr, DropSpec d) {
     const int m = blockIdx.x;
     const int s = m / B, b = m - s * B;
     T *row = x2 + (int64_t)m * ld_x2;
-    for (int j = threadIdx.x; j < 2 * h; j += blockDim.x) {
-        const float v = (j < h) ? to_f32(row[j]) : xcnn[(int64_t)b * ld_xc + (j - h)];
-        row[j] = from_f32<T>(v * drop_mult(d, s, b, j, B, 2 * h));
+    for (int j = threadIdx.x; j < nl + nr; j += blockDim.x) {
+        const float v = (j < nl) ? to_f32(row[j]) : xcnn[(int64_t)b * ld_xc + (j - nl)];
+        row[j] = from_f32<T>(v * drop_mult(d, s, b, j, B, nl + nr));
     }
 }
 
 template <typename T>
-__global__ void dx2_mask_reduce_kernel(T *dx2, int64_t ld, int S, int B, int h, DropSpec d, float *dxcnn, int64_t ld_dxc) {
+__global__ void dx2_mask_reduce_kernel(T *dx2, int64_t ld, int S, int B, int nl, int nr, DropSpec d, float *dxcnn, int64_t ld_dxc) {
     const int b = blockIdx.x, j = blockIdx.y * blockDim.x + threadIdx.x;
-    if (j >= 2 * h) return;
+    if (j >= nl + nr) return;
     float acc = 0.0f;
     for (int s = 0; s < S; ++s) {
         T *p = dx2 + (int64_t)(s * B + b) * ld + j;
-        const float v = to_f32(*p) * drop_mult(d, s, b, j, B, 2 * h);
+        const float v = to_f32(*p) * drop_mult(d, s, b, j, B, nl + nr);
         *p = from_f32<T>(v);
         acc += v;
     }
-    if (j >= h) dxcnn[(int64_t)b * ld_dxc + (j - h)] = acc;
+    if (j >= nl) dxcnn[(int64_t)b * ld_dxc + (j - nl)] = acc;
 }
 
 __device__ __forceinline__ float wave_max(float v) {
@@ -976,15 +976,15 @@ void k_lstm_bwd(hipStream_t st, int dtype, const void *acts, int64_t ld_a, const
     DISPATCH_T(dtype, hipLaunchKernelGGL(lstm_bwd_kernel<T>, dim3(cdiv(H, 256), B), dim3(256), 0, st, (const T *)acts, ld_a,
                                          c_prev, c_new, dh_a, ld_dha, dh_b, dh_b_read, dc, dc_zero, B, H, (T *)dz, ld_dz));
 }
-void k_concat_x2(hipStream_t st, int dtype, void *x2, int64_t ld_x2, const float *xcnn, int64_t ld_xc, int S, int B, int h,
+void k_concat_x2(hipStream_t st, int dtype, void *x2, int64_t ld_x2, const float *xcnn, int64_t ld_xc, int S, int B, int nl, int nr,
                  DropSpec d) {
     DISPATCH_T(dtype, hipLaunchKernelGGL(concat_x2_kernel<T>, dim3(S * B), dim3(256), 0, st, (T *)x2, ld_x2, xcnn, ld_xc, S,
-                                         B, h, d));
+                                         B, nl, nr, d));
 }
-void k_dx2_mask_reduce(hipStream_t st, int dtype, void *dx2, int64_t ld, int S, int B, int h, DropSpec d, float *dxcnn,
+void k_dx2_mask_reduce(hipStream_t st, int dtype, void *dx2, int64_t ld, int S, int B, int nl, int nr, DropSpec d, float *dxcnn,
                        int64_t ld_dxc) {
-    DISPATCH_T(dtype, hipLaunchKernelGGL(dx2_mask_reduce_kernel<T>, dim3(B, cdiv(2 * h, 256)), dim3(256), 0, st, (T *)dx2, ld, S, B, h, d,
-                                         dxcnn, ld_dxc));
+    DISPATCH_T(dtype, hipLaunchKernelGGL(dx2_mask_reduce_kernel<T>, dim3(B, cdiv(nl + nr, 256)), dim3(256), 0, st, (T *)dx2, ld, S, B, nl,
+                                         nr, d, dxcnn, ld_dxc));
 }
 void k_softmax_xent(hipStream_t st, int dtype, const float *logits, int64_t ld_l, const int32_t *tgt, int M, int V,
                     float scale, double *logp_sum, void *dlog, int64_t ld_d) {

@@ -47,6 +47,9 @@ struct lrcn_ctx {
     int dt = 0, vdt = 0;
     size_t esz = 4, vesz = 4;
     int E = 0, H1 = 0, H2 = 0, h = 0, V = 0, maxB = 0, maxS = 0;
+    int nl = 2;             // LSTM layers: 2 = the reference's LRCN-2f (lrcn.jl:540-551), 1 = LRCN-1f (BASELINE configs[1])
+    int X1 = 0;             // input width of LSTM-1: E (2 layers) or E + h = [embedding | x_cnn] (1 layer)
+    int64_t ldX1 = 0;
     int64_t ldE = 0, ldH1 = 0, ldH2 = 0, ldh = 0, ld4H1 = 0, ld4H2 = 0, ldV = 0, ldM = 0, ldB = 0;
     // shadow weights (T)
     void *W1x = nullptr, *W1h = nullptr, *W1xT = nullptr, *W1hT = nullptr;
@@ -218,6 +221,7 @@ DropSpec make_drop(const lrcn_dropout *d, int which) {
 // f32 column-major params -> K-contiguous shadows in T (direct and transposed).  See DESIGN.md "shadow weights".
 int prepare_weights(lrcn_ctx *c, const float *const p[9], bool need_bwd, bool cat = false) {
     const int dt = c->dt, E = c->E, H1 = c->H1, H2 = c->H2, h = c->h, V = c->V;
+    if (!p[0] || !p[1] || !p[5] || !p[6] || !p[7] || !p[8] || (c->nl == 2 && (!p[2] || !p[3] || !p[4]))) FAIL(c, LRCN_EINVAL, "null parameter tensor");
     hipStream_t st = c->stream;
     PrepPlan plan{};
     auto add = [&](const float *src, int R, int C, int cs, void *dA, int64_t ldA, void *dB, int64_t ldB, void *tA, int64_t ldtA, void *tB,
@@ -227,17 +231,20 @@ int prepare_weights(lrcn_ctx *c, const float *const p[9], bool need_bwd, bool ca
         d.dA = dA; d.ldA = ldA; d.dB = dB; d.ldB = ldB;
         d.tA = tA; d.ldtA = ldtA; d.tB = tB; d.ldtB = ldtB;
     };
-    const bool b = need_bwd;
-    // W1: memory [4H1][E + H1] -> W1x | W1h (and their transposes [E][ld4H1] | [H1][ld4H1] for the backward dX GEMMs)
-    add(p[0], 4 * H1, E + H1, E, c->W1x, c->ldE, c->W1h, c->ldH1, b ? c->W1xT : nullptr, c->ld4H1, b ? c->W1hT : nullptr, c->ld4H1);
-    add(p[2], 4 * H2, 2 * H2, H2, c->W2x, c->ldH2, c->W2h, c->ldH2, b ? c->W2xT : nullptr, c->ld4H2, b ? c->W2hT : nullptr, c->ld4H2);
-    add(p[4], h, H1, H1, c->Wpd, c->ldH1, nullptr, 0, b ? c->WpT : nullptr, c->ldh, nullptr, 0);  // Wproj (H1 x h): memory [h][H1]
+    const bool b = need_bwd, two = c->nl == 2;
+    const int X1 = c->X1;
+    // W1: memory [4H1][X1 + H1] -> W1x | W1h (and their transposes [X1][ld4H1] | [H1][ld4H1] for the backward dX GEMMs)
+    add(p[0], 4 * H1, X1 + H1, X1, c->W1x, c->ldX1, c->W1h, c->ldH1, b ? c->W1xT : nullptr, c->ld4H1, b ? c->W1hT : nullptr, c->ld4H1);
+    if (two) {
+        add(p[2], 4 * H2, 2 * H2, H2, c->W2x, c->ldH2, c->W2h, c->ldH2, b ? c->W2xT : nullptr, c->ld4H2, b ? c->W2hT : nullptr, c->ld4H2);
+        add(p[4], h, H1, H1, c->Wpd, c->ldH1, nullptr, 0, b ? c->WpT : nullptr, c->ldh, nullptr, 0);  // Wproj (H1 x h): memory [h][H1]
+    }
     add(p[5], h, LRCN_CNNOUT, LRCN_CNNOUT, c->Wcd, LRCN_CNNOUT, nullptr, 0, nullptr, 0, nullptr, 0);   // Wcnn: memory [h][4096]
     add(p[6], E, V, V, nullptr, 0, nullptr, 0, c->WeT, c->ldE, nullptr, 0);                          // Wembed (V x E): memory [E][V] -> [V][ldE]
     add(p[7], V, H2, H2, c->Wod, c->ldH2, nullptr, 0, b ? c->WoT : nullptr, c->ldV, nullptr, 0);   // Wout (H2 x V): memory [V][H2]
     if (cat) {  // batched decode: W1 / W2 with the x and h column blocks each padded to whole K-steps, side by side
-        add(p[0], 4 * H1, E + H1, E, c->W1cat, c->ldXH1, boff(c->W1cat, c->ldE, c->esz), c->ldXH1, nullptr, 0, nullptr, 0);
-        add(p[2], 4 * H2, 2 * H2, H2, c->W2cat, c->ldXH2, boff(c->W2cat, c->ldH2, c->esz), c->ldXH2, nullptr, 0, nullptr, 0);
+        add(p[0], 4 * H1, X1 + H1, X1, c->W1cat, c->ldXH1, boff(c->W1cat, c->ldX1, c->esz), c->ldXH1, nullptr, 0, nullptr, 0);
+        if (two) add(p[2], 4 * H2, 2 * H2, H2, c->W2cat, c->ldXH2, boff(c->W2cat, c->ldH2, c->esz), c->ldXH2, nullptr, 0, nullptr, 0);
     }
     k_prepare_weights(st, dt, plan);
     KCHK(c, "prepare_weights");
@@ -318,13 +325,16 @@ int loss_impl(lrcn_ctx *c, const float *const p[9], const float *feats, const in
     int r = check_shapes(c, T, B, norm_B);
     if (r) return r;
     if (drop && (drop->pdrop < 0.0f || drop->pdrop >= 1.0f)) FAIL(c, LRCN_EINVAL, "pdrop=%g outside [0,1)", drop->pdrop);
-    if (drop && ((drop->mask1 == nullptr) != (drop->mask2 == nullptr))) FAIL(c, LRCN_EINVAL, "mask1/mask2 must both be set");
-    const int dt = c->dt, E = c->E, H1 = c->H1, H2 = c->H2, h = c->h, V = c->V;
+    if (drop && c->nl == 2 && ((drop->mask1 == nullptr) != (drop->mask2 == nullptr))) FAIL(c, LRCN_EINVAL, "mask1/mask2 must both be set");
+    const int dt = c->dt, E = c->E, H1 = c->H1, H2 = c->H2, h = c->h, V = c->V, X1 = c->X1;
     const int S = T + 1, M = S * B;
     const size_t es = c->esz;
     hipStream_t st = c->stream;
-    const bool bwd = grads != nullptr;
+    const bool bwd = grads != nullptr, two = c->nl == 2;
+    if (bwd && (!grads[0] || !grads[1] || !grads[5] || !grads[6] || !grads[7] || !grads[8] || (two && (!grads[2] || !grads[3] || !grads[4]))))
+        FAIL(c, LRCN_EINVAL, "null gradient tensor");
     const DropSpec d1 = make_drop(drop, 1), d2 = make_drop(drop, 2);
+    const DropSpec none{};
 
     r = prepare_weights(c, p, bwd);
     if (r) return r;
@@ -333,21 +343,27 @@ int loss_impl(lrcn_ctx *c, const float *const p[9], const float *feats, const in
     k_transpose(st, dt, 1, feats, B, LRCN_CNNOUT, B, c->F, LRCN_CNNOUT, 0);
     // input = input * param[end-3]   lrcn.jl:558
     GEMM(c, dt, c->F, LRCN_CNNOUT, c->Wcd, LRCN_CNNOUT, c->xcnn, c->ldh, B, h, LRCN_CNNOUT, nullptr, true);
-    // embeddings of [bos, tokens...] with the :542 dropout
-    k_embed_gather(st, dt, c->WeT, c->ldE, c->tok_in, S, B, E, d1, c->Xemb, c->ldE);
+    // embeddings of [bos, tokens...] with the :542 dropout.  LRCN-1f: the LSTM input is dropout(hcat(embedding, x_cnn)) -- the
+    // gather fills columns [0, E), the concat kernel appends x_cnn and applies the one mask over all E + h columns
+    k_embed_gather(st, dt, c->WeT, c->ldE, c->tok_in, S, B, E, two ? d1 : none, c->Xemb, c->ldX1);
+    if (!two) k_concat_x2(st, dt, c->Xemb, c->ldX1, c->xcnn, c->ldh, S, B, E, h, d1);
     // LSTM 1
-    GEMM(c, dt, c->Xemb, c->ldE, c->W1x, c->ldE, c->G1, 4 * H1, M, 4 * H1, E, p[1], true);
+    GEMM(c, dt, c->Xemb, c->ldX1, c->W1x, c->ldX1, c->G1, 4 * H1, M, 4 * H1, X1, p[1], true);
     r = lstm_layer_fwd(c, S, B, H1, c->ldH1, c->ld4H1, c->G1, c->W1h, c->A1, c->C1, c->H1all);
     if (r) return r;
-    // x = s[1]*w[end-4]; x = hcat(x, x_cnn); x = dropout(x)    lrcn.jl:544-547
-    GEMM(c, dt, c->H1all, c->ldH1, c->Wpd, c->ldH1, c->X2, c->ldH2, M, h, H1, nullptr, false);
-    k_concat_x2(st, dt, c->X2, c->ldH2, c->xcnn, c->ldh, S, B, h, d2);
-    // LSTM 2
-    GEMM(c, dt, c->X2, c->ldH2, c->W2x, c->ldH2, c->G2, 4 * H2, M, 4 * H2, H2, p[3], true);
-    r = lstm_layer_fwd(c, S, B, H2, c->ldH2, c->ld4H2, c->G2, c->W2h, c->A2, c->C2, c->H2all);
-    if (r) return r;
+    const void *Htop = c->H1all;  // the hidden states the logits are computed from
+    if (two) {
+        // x = s[1]*w[end-4]; x = hcat(x, x_cnn); x = dropout(x)    lrcn.jl:544-547
+        GEMM(c, dt, c->H1all, c->ldH1, c->Wpd, c->ldH1, c->X2, c->ldH2, M, h, H1, nullptr, false);
+        k_concat_x2(st, dt, c->X2, c->ldH2, c->xcnn, c->ldh, S, B, h, h, d2);
+        // LSTM 2
+        GEMM(c, dt, c->X2, c->ldH2, c->W2x, c->ldH2, c->G2, 4 * H2, M, 4 * H2, H2, p[3], true);
+        r = lstm_layer_fwd(c, S, B, H2, c->ldH2, c->ld4H2, c->G2, c->W2h, c->A2, c->C2, c->H2all);
+        if (r) return r;
+        Htop = c->H2all;
+    }
     // logits for all steps: x * w[end-1] .+ w[end]   lrcn.jl:550
-    GEMM(c, dt, c->H2all, c->ldH2, c->Wod, c->ldH2, c->Logits, c->ldV, M, V, H2, p[8], true);
+    GEMM(c, dt, Htop, c->ldH2, c->Wod, c->ldH2, c->Logits, c->ldV, M, V, H2, p[8], true);
     if (logits_out) {  // (T+1) blocks of B x V column-major: block s memory [V][B]
         for (int s = 0; s < S; ++s)
             k_transpose_f32(st, c->Logits + (int64_t)s * B * c->ldV, c->ldV, B, V, logits_out + (int64_t)s * B * V, B);
@@ -371,57 +387,70 @@ int loss_impl(lrcn_ctx *c, const float *const p[9], const float *feats, const in
     {
         TrPlan pl{};
         tr(pl, c->dLog, c->ldV, M, V, c->TA, 0);      // dLog^T [V][ldM]
-        tr(pl, c->H2all, c->ldH2, M, H2, c->TB, 0);   // H2all^T [H2][ldM]
+        tr(pl, Htop, c->ldH2, M, H2, c->TB, 0);       // H2all^T [H2][ldM]
         k_transpose_multi(st, dt, pl);
     }
     GEMM(c, dt, c->TA, ldM, c->TB, ldM, grads[7], H2, V, H2, M, nullptr, true);
     k_colsum(st, dt, c->dLog, c->ldV, M, V, grads[8]);
     HIPCHK(c, hipEventRecord(c->grad_ev[0], st));  // group 0: Wout, bout
-    GEMM(c, dt, c->dLog, c->ldV, c->WoT, c->ldV, c->dH2all, H2, M, H2, V, nullptr, true);
-    // ---- LSTM 2 ----
-    r = lstm_layer_bwd(c, S, B, H2, c->ld4H2, c->A2, c->C2, c->dH2all, c->W2hT, c->dZ2);
-    if (r) return r;
-    {
-        TrPlan pl{};
-        tr(pl, c->dZ2, c->ld4H2, M, 4 * H2, c->TA, 0);                              // dZ2^T [4H2][ldM]
-        tr(pl, c->X2, c->ldH2, M, H2, c->TB, 0);                                     // X2^T [2h][ldM]
-        tr(pl, c->H2all, c->ldH2, M - B, H2, boff(c->TB, (int64_t)H2 * ldM, es), M > B ? B : 0);  // h2_prev^T (one step later)
-        k_transpose_multi(st, dt, pl);
+    GEMM(c, dt, c->dLog, c->ldV, c->WoT, c->ldV, two ? c->dH2all : c->dH1all, H2, M, H2, V, nullptr, true);
+    if (two) {
+        // ---- LSTM 2 ----
+        r = lstm_layer_bwd(c, S, B, H2, c->ld4H2, c->A2, c->C2, c->dH2all, c->W2hT, c->dZ2);
+        if (r) return r;
+        {
+            TrPlan pl{};
+            tr(pl, c->dZ2, c->ld4H2, M, 4 * H2, c->TA, 0);                              // dZ2^T [4H2][ldM]
+            tr(pl, c->X2, c->ldH2, M, H2, c->TB, 0);                                     // X2^T [2h][ldM]
+            tr(pl, c->H2all, c->ldH2, M - B, H2, boff(c->TB, (int64_t)H2 * ldM, es), M > B ? B : 0);  // h2_prev^T (one step later)
+            k_transpose_multi(st, dt, pl);
+        }
+        GEMM(c, dt, c->TA, ldM, c->TB, ldM, grads[2], 2 * H2, 4 * H2, 2 * H2, M, nullptr, true);
+        k_colsum(st, dt, c->dZ2, c->ld4H2, M, 4 * H2, grads[3]);
     }
-    GEMM(c, dt, c->TA, ldM, c->TB, ldM, grads[2], 2 * H2, 4 * H2, 2 * H2, M, nullptr, true);
-    k_colsum(st, dt, c->dZ2, c->ld4H2, M, 4 * H2, grads[3]);
     HIPCHK(c, hipEventRecord(c->grad_ev[1], st));  // group 1: W2, b2
-    GEMM(c, dt, c->dZ2, c->ld4H2, c->W2xT, c->ld4H2, c->dX2, c->ldH2, M, H2, 4 * H2, nullptr, false);
-    k_dx2_mask_reduce(st, dt, c->dX2, c->ldH2, S, B, h, d2, c->dxcnn, c->ldh);
-    // ---- projection and image embedding ----
-    {
-        TrPlan pl{};
-        tr(pl, c->dX2, c->ldH2, M, h, c->TA, 0);      // dP^T [h][ldM]
-        tr(pl, c->H1all, c->ldH1, M, H1, c->TB, 0);   // H1all^T [H1][ldM]
-        k_transpose_multi(st, dt, pl);
+    if (two) {
+        GEMM(c, dt, c->dZ2, c->ld4H2, c->W2xT, c->ld4H2, c->dX2, c->ldH2, M, H2, 4 * H2, nullptr, false);
+        k_dx2_mask_reduce(st, dt, c->dX2, c->ldH2, S, B, h, h, d2, c->dxcnn, c->ldh);
+        // ---- projection and image embedding ----
+        {
+            TrPlan pl{};
+            tr(pl, c->dX2, c->ldH2, M, h, c->TA, 0);      // dP^T [h][ldM]
+            tr(pl, c->H1all, c->ldH1, M, H1, c->TB, 0);   // H1all^T [H1][ldM]
+            k_transpose_multi(st, dt, pl);
+        }
+        GEMM(c, dt, c->TA, ldM, c->TB, ldM, grads[4], H1, h, H1, M, nullptr, true);
+        GEMM(c, dt, c->dX2, c->ldH2, c->WpT, c->ldh, c->dH1all, H1, M, H1, h, nullptr, true);
+        k_transpose(st, dt, 1, c->dxcnn, c->ldh, B, h, c->dxcT, ldB, 0);     // dxcnn^T [h][ldB]
+        k_cast_rows(st, dt, feats, B, LRCN_CNNOUT, B, c->FT, ldB);           // feats^T [4096][ldB] (it already is, in memory)
+        GEMM(c, dt, c->dxcT, ldB, c->FT, ldB, grads[5], LRCN_CNNOUT, h, LRCN_CNNOUT, B, nullptr, true);
+        HIPCHK(c, hipEventRecord(c->grad_ev[2], st));  // group 2: Wproj, Wcnn
     }
-    GEMM(c, dt, c->TA, ldM, c->TB, ldM, grads[4], H1, h, H1, M, nullptr, true);
-    GEMM(c, dt, c->dX2, c->ldH2, c->WpT, c->ldh, c->dH1all, H1, M, H1, h, nullptr, true);
-    k_transpose(st, dt, 1, c->dxcnn, c->ldh, B, h, c->dxcT, ldB, 0);     // dxcnn^T [h][ldB]
-    k_cast_rows(st, dt, feats, B, LRCN_CNNOUT, B, c->FT, ldB);           // feats^T [4096][ldB] (it already is, in memory)
-    GEMM(c, dt, c->dxcT, ldB, c->FT, ldB, grads[5], LRCN_CNNOUT, h, LRCN_CNNOUT, B, nullptr, true);
-    HIPCHK(c, hipEventRecord(c->grad_ev[2], st));  // group 2: Wproj, Wcnn
     // ---- LSTM 1 ----
     r = lstm_layer_bwd(c, S, B, H1, c->ld4H1, c->A1, c->C1, c->dH1all, c->W1hT, c->dZ1);
     if (r) return r;
     {
         TrPlan pl{};
         tr(pl, c->dZ1, c->ld4H1, M, 4 * H1, c->TA, 0);
-        tr(pl, c->Xemb, c->ldE, M, E, c->TB, 0);
-        tr(pl, c->H1all, c->ldH1, M - B, H1, boff(c->TB, (int64_t)E * ldM, es), M > B ? B : 0);
+        tr(pl, c->Xemb, c->ldX1, M, X1, c->TB, 0);
+        tr(pl, c->H1all, c->ldH1, M - B, H1, boff(c->TB, (int64_t)X1 * ldM, es), M > B ? B : 0);
         k_transpose_multi(st, dt, pl);
     }
-    GEMM(c, dt, c->TA, ldM, c->TB, ldM, grads[0], E + H1, 4 * H1, E + H1, M, nullptr, true);
+    GEMM(c, dt, c->TA, ldM, c->TB, ldM, grads[0], X1 + H1, 4 * H1, X1 + H1, M, nullptr, true);
     k_colsum(st, dt, c->dZ1, c->ld4H1, M, 4 * H1, grads[1]);
     HIPCHK(c, hipEventRecord(c->grad_ev[3], st));  // group 3: W1, b1
-    GEMM(c, dt, c->dZ1, c->ld4H1, c->W1xT, c->ld4H1, c->dXemb, c->ldE, M, E, 4 * H1, nullptr, true);
+    GEMM(c, dt, c->dZ1, c->ld4H1, c->W1xT, c->ld4H1, c->dXemb, c->ldX1, M, X1, 4 * H1, nullptr, true);
+    if (!two) {
+        // LRCN-1f: d[embedding | x_cnn] -- mask all E + h columns in place, sum the right h columns over the steps -> d x_cnn,
+        // then the image-embedding gradient exactly as in the two-layer model
+        k_dx2_mask_reduce(st, GEMM_T_F32, c->dXemb, c->ldX1, S, B, E, h, d1, c->dxcnn, c->ldh);
+        k_transpose(st, dt, 1, c->dxcnn, c->ldh, B, h, c->dxcT, ldB, 0);
+        k_cast_rows(st, dt, feats, B, LRCN_CNNOUT, B, c->FT, ldB);
+        GEMM(c, dt, c->dxcT, ldB, c->FT, ldB, grads[5], LRCN_CNNOUT, h, LRCN_CNNOUT, B, nullptr, true);
+        HIPCHK(c, hipEventRecord(c->grad_ev[2], st));  // group 2: Wcnn
+    }
     HIPCHK(c, hipMemsetAsync(grads[6], 0, sizeof(float) * (size_t)V * E, st));
-    k_embed_scatter(st, c->dXemb, c->ldE, c->tok_in, S, B, E, V, d1, grads[6]);
+    k_embed_scatter(st, c->dXemb, c->ldX1, c->tok_in, S, B, E, V, two ? d1 : none, grads[6]);
     HIPCHK(c, hipEventRecord(c->grad_ev[4], st));  // group 4: Wembed
     KCHK(c, "backward");
     return LRCN_OK;
@@ -440,19 +469,27 @@ int fetch_loss(lrcn_ctx *c, double *out) {
     return LRCN_OK;
 }
 
-// lrcn() on internal single-step buffers: state st_f32 (f32 row-major), inputs st_x (T [B][ldE]) and xcnn (f32 [B][ldh]).
-// m2: dropout for the concatenated LSTM-2 input. Leaves logits in st_logits [B][ldV].
+// lrcn() on internal single-step buffers: state st_f32 (f32 row-major), inputs st_x (T [B][ldX1]: the embedding in columns
+// [0, E); LRCN-1f appends x_cnn here) and xcnn (f32 [B][ldh]).
+// d2: dropout of the concatenated input (LSTM-2's in the two-layer model, LSTM-1's in LRCN-1f). Leaves logits in st_logits [B][ldV].
 int step_internal(lrcn_ctx *c, const float *const p[9], int B, const DropSpec &d2, bool h_ready = false) {
-    const int dt = c->dt, E = c->E, H1 = c->H1, H2 = c->H2, h = c->h, V = c->V;
+    const int dt = c->dt, E = c->E, H1 = c->H1, H2 = c->H2, h = c->h, V = c->V, X1 = c->X1;
     hipStream_t st = c->stream;
+    const bool two = c->nl == 2;
+    if (!two) k_concat_x2(st, dt, c->st_x, c->ldX1, c->xcnn, c->ldh, 1, B, E, h, d2);  // x = dropout(hcat(x_lstm, x_cnn))
     // LSTM 1: gates = x*W1x' + h1*W1h' + b1
     if (!h_ready) k_cast_rows(st, dt, c->st_f32[0], H1, B, H1, c->st_h1, c->ldH1);  // h_ready: st_h1 / st_h2 already hold T(h)
-    GEMM(c, dt, c->st_x, c->ldE, c->W1x, c->ldE, c->st_g, 4 * H1, B, 4 * H1, E, p[1], true);
+    GEMM(c, dt, c->st_x, c->ldX1, c->W1x, c->ldX1, c->st_g, 4 * H1, B, 4 * H1, X1, p[1], true);
     GEMM(c, dt, c->st_h1, c->ldH1, c->W1h, c->ldH1, c->st_g, 4 * H1, B, 4 * H1, H1, nullptr, true, true);
     k_lstm_fwd(st, dt, c->st_g, 4 * H1, c->st_f32[1], B, H1, c->st_a, c->ld4H1, c->st_f32[1], c->st_h1, c->ldH1, c->st_f32[0]);
+    if (!two) {
+        GEMM(c, dt, c->st_h1, c->ldH1, c->Wod, c->ldH2, c->st_logits, c->ldV, B, V, H2, p[8], true);
+        KCHK(c, "step (1 layer)");
+        return LRCN_OK;
+    }
     // projection + concat + dropout
     GEMM(c, dt, c->st_h1, c->ldH1, c->Wpd, c->ldH1, c->st_x2, c->ldH2, B, h, H1, nullptr, false);
-    k_concat_x2(st, dt, c->st_x2, c->ldH2, c->xcnn, c->ldh, 1, B, h, d2);
+    k_concat_x2(st, dt, c->st_x2, c->ldH2, c->xcnn, c->ldh, 1, B, h, h, d2);
     // LSTM 2
     if (!h_ready) k_cast_rows(st, dt, c->st_f32[2], H2, B, H2, c->st_h2, c->ldH2);
     GEMM(c, dt, c->st_x2, c->ldH2, c->W2x, c->ldH2, c->st_g, 4 * H2, B, 4 * H2, H2, p[3], true);
@@ -464,21 +501,30 @@ int step_internal(lrcn_ctx *c, const float *const p[9], int B, const DropSpec &d
 }
 
 // The same step for the batched beam decode, on the concatenated buffers: st_xh1 = [x | h1], st_xh2 = [x2 | h2] (T, the
-// h blocks already hold this step's input states), one GEMM per LSTM against W1cat / W2cat.
+// h blocks already hold this step's input states), one GEMM per LSTM against W1cat / W2cat.  LRCN-1f: st_xh1 = [emb | x_cnn | h1]
+// (the caller wrote the x_cnn columns once: they do not change during a decode).
 int step_decode(lrcn_ctx *c, const float *const p[9], int B, const DropSpec &d2) {
     const int dt = c->dt, H1 = c->H1, H2 = c->H2, h = c->h, V = c->V;
     hipStream_t st = c->stream;
-    void *h1T = boff(c->st_xh1, c->ldE, c->esz), *h2T = boff(c->st_xh2, c->ldH2, c->esz);
-    GEMM(c, dt, c->st_xh1, c->ldXH1, c->W1cat, c->ldXH1, c->st_g, 4 * H1, B, 4 * H1, (int)c->ldE + H1, p[1], true);
+    void *h1T = boff(c->st_xh1, c->ldX1, c->esz), *h2T = boff(c->st_xh2, c->ldH2, c->esz);
+    GEMM(c, dt, c->st_xh1, c->ldXH1, c->W1cat, c->ldXH1, c->st_g, 4 * H1, B, 4 * H1, (int)c->ldX1 + H1, p[1], true);
     k_lstm_fwd(st, dt, c->st_g, 4 * H1, c->st_f32[1], B, H1, c->st_a, c->ld4H1, c->st_f32[1], h1T, c->ldXH1, c->st_f32[0]);
+    if (c->nl == 1) {
+        GEMM(c, dt, h1T, c->ldXH1, c->Wod, c->ldH2, c->st_logits, c->ldV, B, V, H2, p[8], true);
+        KCHK(c, "step_decode (1 layer)");
+        return LRCN_OK;
+    }
     GEMM(c, dt, h1T, c->ldXH1, c->Wpd, c->ldH1, c->st_xh2, c->ldXH2, B, h, H1, nullptr, false);
-    k_concat_x2(st, dt, c->st_xh2, c->ldXH2, c->xcnn, c->ldh, 1, B, h, d2);
+    k_concat_x2(st, dt, c->st_xh2, c->ldXH2, c->xcnn, c->ldh, 1, B, h, h, d2);
     GEMM(c, dt, c->st_xh2, c->ldXH2, c->W2cat, c->ldXH2, c->st_g, 4 * H2, B, 4 * H2, (int)c->ldH2 + H2, p[3], true);
     k_lstm_fwd(st, dt, c->st_g, 4 * H2, c->st_f32[3], B, H2, c->st_a, c->ld4H2, c->st_f32[3], h2T, c->ldXH2, c->st_f32[2]);
     GEMM(c, dt, h2T, c->ldXH2, c->Wod, c->ldH2, c->st_logits, c->ldV, B, V, H2, p[8], true);
     KCHK(c, "step_decode");
     return LRCN_OK;
 }
+
+// element counts of the context's 9 tensors (0 for the slots its model does not have)
+void ctx_sizes(const lrcn_ctx *c, int64_t sz[9]) { lrcn_param_sizes_n(c->nl, c->E, c->H1, c->H2, c->V, sz); }
 
 }  // namespace
 
@@ -489,20 +535,28 @@ const char *lrcn_version(void) { return "lrcn-hip 0.1 (gfx950)"; }
 
 const char *lrcn_last_error(const lrcn_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
-int lrcn_param_sizes(int E, int H1, int H2, int V, int64_t s[9]) {
+int lrcn_param_sizes_n(int n_layers, int E, int H1, int H2, int V, int64_t s[9]) {
     if (E < 1 || H1 < 1 || H2 < 2 || (H2 & 1) || V < 3 || !s) return LRCN_EINVAL;
+    if (n_layers != 0 && n_layers != 1 && n_layers != 2) return LRCN_EINVAL;
     const int h = H2 / 2;
-    s[0] = (int64_t)(E + H1) * 4 * H1;
+    if (n_layers == 1) {  // LRCN-1f: one LSTM over [embedding | x_cnn]; W2, b2, Wproj do not exist
+        if (H1 != H2) return LRCN_EINVAL;
+        s[0] = (int64_t)(E + h + H1) * 4 * H1;
+        s[2] = s[3] = s[4] = 0;
+    } else {
+        s[0] = (int64_t)(E + H1) * 4 * H1;
+        s[2] = (int64_t)(2 * H2) * 4 * H2;
+        s[3] = 4 * H2;
+        s[4] = (int64_t)H1 * h;
+    }
     s[1] = 4 * H1;
-    s[2] = (int64_t)(2 * H2) * 4 * H2;
-    s[3] = 4 * H2;
-    s[4] = (int64_t)H1 * h;
     s[5] = (int64_t)LRCN_CNNOUT * h;
     s[6] = (int64_t)V * E;
     s[7] = (int64_t)H2 * V;
     s[8] = V;
     return LRCN_OK;
 }
+int lrcn_param_sizes(int E, int H1, int H2, int V, int64_t s[9]) { return lrcn_param_sizes_n(2, E, H1, H2, V, s); }
 
 int lrcn_malloc(void **p, size_t bytes) { return hipMalloc(p, bytes ? bytes : 16) == hipSuccess ? LRCN_OK : LRCN_ENOMEM; }
 int lrcn_free(void *p) { return hipFree(p) == hipSuccess ? LRCN_OK : LRCN_EHIP; }
@@ -530,10 +584,10 @@ int lrcn_create(const lrcn_config *cfg, lrcn_ctx **out) {
     }
     *out = nullptr;
     int64_t sz[9];
-    if (lrcn_param_sizes(cfg->E, cfg->H1, cfg->H2, cfg->V, sz) != LRCN_OK || cfg->max_B < 1 || cfg->max_T < 0 ||
+    if (lrcn_param_sizes_n(cfg->n_layers, cfg->E, cfg->H1, cfg->H2, cfg->V, sz) != LRCN_OK || cfg->max_B < 1 || cfg->max_T < 0 ||
         cfg->max_T > LRCN_MAX_T || (cfg->lstm_dtype != LRCN_F32 && cfg->lstm_dtype != LRCN_BF16) ||
         (cfg->vgg_dtype != LRCN_F32 && cfg->vgg_dtype != LRCN_BF16 && cfg->vgg_dtype != LRCN_FP8) || cfg->max_images < 0) {
-        g_create_err = "invalid lrcn_config (need E,H1>=1, even H2>=2, V>=3, max_B>=1, 0<=max_T<=28, lstm_dtype in {F32,BF16}, vgg_dtype in {F32,BF16,FP8})";
+        g_create_err = "invalid lrcn_config (need E,H1>=1, even H2>=2, V>=3, max_B>=1, 0<=max_T<=28, lstm_dtype in {F32,BF16}, vgg_dtype in {F32,BF16,FP8}, n_layers in {0,1,2} with H1 == H2 when n_layers == 1)";
         return LRCN_EINVAL;
     }
     int ndev = 0;
@@ -558,18 +612,22 @@ int lrcn_create(const lrcn_config *cfg, lrcn_ctx **out) {
     c->esz = c->dt == GEMM_T_BF16 ? 2 : 4;
     c->vesz = c->vdt == GEMM_T_BF16 ? 2 : 4;
     c->E = cfg->E; c->H1 = cfg->H1; c->H2 = cfg->H2; c->h = cfg->H2 / 2; c->V = cfg->V;
+    c->nl = cfg->n_layers == 1 ? 1 : 2;
+    c->X1 = c->nl == 1 ? c->E + c->h : c->E;
     c->maxB = cfg->max_B; c->maxS = cfg->max_T + 1;
     const int E = c->E, H1 = c->H1, H2 = c->H2, h = c->h, V = c->V, B = c->maxB, S = c->maxS;
     const int64_t M = (int64_t)S * B;
+    const int X1 = c->X1;
+    c->ldX1 = ld8(X1);
     c->ldE = ld8(E); c->ldH1 = ld8(H1); c->ldH2 = ld8(H2); c->ldh = ld8(h); c->ld4H1 = ld8(4 * H1); c->ld4H2 = ld8(4 * H2);
     c->ldV = ld8(V); c->ldM = ld8(M); c->ldB = ld8(B);
     const size_t es = c->esz;
     int rc = [&]() -> int {
-        c->ldXH1 = c->ldE + c->ldH1; c->ldXH2 = 2 * c->ldH2;
+        c->ldXH1 = c->ldX1 + c->ldH1; c->ldXH2 = 2 * c->ldH2;
         DALLOC(c, c->W1cat, es * 4 * H1 * c->ldXH1); DALLOC(c, c->W2cat, es * 4 * H2 * c->ldXH2);
         DALLOC(c, c->st_xh1, es * B * c->ldXH1);     DALLOC(c, c->st_xh2, es * B * c->ldXH2);
-        DALLOC(c, c->W1x, es * 4 * H1 * c->ldE);   DALLOC(c, c->W1h, es * 4 * H1 * c->ldH1);
-        DALLOC(c, c->W1xT, es * E * c->ld4H1);     DALLOC(c, c->W1hT, es * H1 * c->ld4H1);
+        DALLOC(c, c->W1x, es * 4 * H1 * c->ldX1);  DALLOC(c, c->W1h, es * 4 * H1 * c->ldH1);
+        DALLOC(c, c->W1xT, es * X1 * c->ld4H1);    DALLOC(c, c->W1hT, es * H1 * c->ld4H1);
         DALLOC(c, c->W2x, es * 4 * H2 * c->ldH2);  DALLOC(c, c->W2h, es * 4 * H2 * c->ldH2);
         DALLOC(c, c->W2xT, es * H2 * c->ld4H2);    DALLOC(c, c->W2hT, es * H2 * c->ld4H2);
         DALLOC(c, c->Wpd, es * h * c->ldH1);       DALLOC(c, c->WpT, es * H1 * c->ldh);
@@ -579,7 +637,7 @@ int lrcn_create(const lrcn_config *cfg, lrcn_ctx **out) {
         DALLOC(c, c->tok_tgt, sizeof(int32_t) * M);
         DALLOC(c, c->F, es * B * LRCN_CNNOUT);     DALLOC(c, c->FT, es * LRCN_CNNOUT * c->ldB);
         DALLOC(c, c->xcnn, sizeof(float) * B * c->ldh);
-        DALLOC(c, c->Xemb, es * M * c->ldE);
+        DALLOC(c, c->Xemb, es * M * c->ldX1);
         DALLOC(c, c->G1, sizeof(float) * M * 4 * H1); DALLOC(c, c->A1, es * M * c->ld4H1);
         DALLOC(c, c->C1, sizeof(float) * M * H1);     DALLOC(c, c->H1all, es * M * c->ldH1);
         DALLOC(c, c->X2, es * M * c->ldH2);
@@ -590,12 +648,12 @@ int lrcn_create(const lrcn_config *cfg, lrcn_ctx **out) {
         DALLOC(c, c->dZ1, es * M * c->ld4H1);      DALLOC(c, c->dZ2, es * M * c->ld4H2);
         DALLOC(c, c->dX2, es * M * c->ldH2);
         DALLOC(c, c->dH1all, sizeof(float) * M * H1); DALLOC(c, c->dH2all, sizeof(float) * M * H2);
-        DALLOC(c, c->dXemb, sizeof(float) * M * c->ldE);
+        DALLOC(c, c->dXemb, sizeof(float) * M * c->ldX1);
         const int Hm = H1 > H2 ? H1 : H2;
         DALLOC(c, c->dhrec, sizeof(float) * B * Hm); DALLOC(c, c->dc, sizeof(float) * B * Hm);
         DALLOC(c, c->dxcnn, sizeof(float) * B * c->ldh); DALLOC(c, c->dxcT, es * h * c->ldB);
         int64_t ra = 4 * Hm; if (V > ra) ra = V;
-        int64_t rb = 2 * H2; if (E + H1 > rb) rb = E + H1;  // stacked [x | h_prev]^T of one LSTM
+        int64_t rb = 2 * H2; if (X1 + H1 > rb) rb = X1 + H1;  // stacked [x | h_prev]^T of one LSTM
         DALLOC(c, c->TA, es * ra * c->ldM);        DALLOC(c, c->TB, es * rb * c->ldM);
         DALLOC(c, c->logp, sizeof(double) * 2);
         DALLOC(c, c->zero_page, 256);
@@ -610,11 +668,11 @@ int lrcn_create(const lrcn_config *cfg, lrcn_ctx **out) {
             DALLOC(c, c->st2_f32[i], sizeof(float) * B * Hm);
         }
         DALLOC(c, c->st_h1, es * B * c->ldH1);     DALLOC(c, c->st_h2, es * B * c->ldH2);
-        DALLOC(c, c->st_x, es * B * c->ldE);       DALLOC(c, c->st_x2, es * B * c->ldH2);
+        DALLOC(c, c->st_x, es * B * c->ldX1);      DALLOC(c, c->st_x2, es * B * c->ldH2);
         DALLOC(c, c->st_a, es * B * (c->ld4H1 > c->ld4H2 ? c->ld4H1 : c->ld4H2));
         DALLOC(c, c->st_g, sizeof(float) * B * 4 * Hm);
         DALLOC(c, c->st_logits, sizeof(float) * B * c->ldV); DALLOC(c, c->st_prob, sizeof(float) * B * c->ldV);
-        int64_t io = (int64_t)B * (V > 4 * Hm ? V : 4 * Hm); if (io < (int64_t)B * (E + Hm)) io = (int64_t)B * (E + Hm);
+        int64_t io = (int64_t)B * (V > 4 * Hm ? V : 4 * Hm); if (io < (int64_t)B * (X1 + Hm)) io = (int64_t)B * (X1 + Hm);
         DALLOC(c, c->st_io, sizeof(float) * io);
         DALLOC(c, c->st_topi, sizeof(int32_t) * B * 32); DALLOC(c, c->st_topv, sizeof(float) * B * 32);
         DALLOC(c, c->st_parent, sizeof(int32_t) * B);
@@ -669,11 +727,13 @@ int lrcn_init_weights(lrcn_ctx *c, float *const p[9], uint64_t seed) {
     DeviceGuard dg(c);
     if (!c || !p) return LRCN_EINVAL;
     int64_t sz[9];
-    lrcn_param_sizes(c->E, c->H1, c->H2, c->V, sz);
+    ctx_sizes(c, sz);
     const int E = c->E, H1 = c->H1, H2 = c->H2, h = c->h, V = c->V;
-    const int rows[9] = {E + H1, 1, 2 * H2, 1, H1, LRCN_CNNOUT, V, H2, 1};
+    const int rows[9] = {c->X1 + H1, 1, 2 * H2, 1, H1, LRCN_CNNOUT, V, H2, 1};
     const int cols[9] = {4 * H1, 4 * H1, 4 * H2, 4 * H2, h, h, E, V, V};
     for (int k = 0; k < 9; ++k) {
+        if (sz[k] == 0) continue;  // LRCN-1f has no W2 / b2 / Wproj
+        if (!p[k]) FAIL(c, LRCN_EINVAL, "null parameter tensor %d", k);
         if (k == 1 || k == 3 || k == 8) {
             k_fill(c->stream, p[k], sz[k], 0.0f);
             if (k != 8) k_fill(c->stream, p[k], k == 1 ? H1 : H2, 1.0f);  // forget-gate bias = 1 (lrcn.jl:501)
@@ -729,7 +789,7 @@ int lrcn_adam_update(lrcn_ctx *c, float *const p[9], const float *const g[9], fl
     if (!c || !p || !g || !m || !v || step < 1) return LRCN_EINVAL;
     AdamTensors t;
     int64_t sz[9];
-    lrcn_param_sizes(c->E, c->H1, c->H2, c->V, sz);
+    ctx_sizes(c, sz);
     for (int k = 0; k < 9; ++k) {
         t.w[k] = p[k];
         t.g[k] = g[k];
@@ -750,7 +810,7 @@ int lrcn_adam_update_group(lrcn_ctx *c, float *const p[9], const float *const g[
     static const int kGroup[LRCN_GRAD_GROUPS][2] = {{7, 8}, {2, 3}, {4, 5}, {0, 1}, {6, 6}};  // order of the grad_ev records
     AdamTensors t;
     int64_t sz[9];
-    lrcn_param_sizes(c->E, c->H1, c->H2, c->V, sz);
+    ctx_sizes(c, sz);
     for (int k = 0; k < 9; ++k) {
         const bool in = k == kGroup[group][0] || k == kGroup[group][1];
         t.w[k] = p[k];
@@ -781,12 +841,12 @@ int lrcn_lstm(lrcn_ctx *c, const float *W, const float *b, int X, int H, int B, 
     DeviceGuard dg(c);
     if (!c || !W || !b || !x || !h || !cc || !h_out || !c_out) return LRCN_EINVAL;
     void *Wx, *Wh, *xb, *hb;
-    if (X == c->E && H == c->H1) {
+    if (X == c->X1 && H == c->H1) {
         Wx = c->W1x; Wh = c->W1h; xb = c->st_x; hb = c->st_h1;
-    } else if (X == c->H2 && H == c->H2) {
+    } else if (c->nl == 2 && X == c->H2 && H == c->H2) {
         Wx = c->W2x; Wh = c->W2h; xb = c->st_x2; hb = c->st_h2;
     } else {
-        FAIL(c, LRCN_EINVAL, "lrcn_lstm: (X=%d,H=%d) must be the context's (E,H1)=(%d,%d) or (H2,H2)=(%d,%d)", X, H, c->E, c->H1,
+        FAIL(c, LRCN_EINVAL, "lrcn_lstm: (X=%d,H=%d) must be the context's LSTM-1 (%d,%d) or (two layers) LSTM-2 (%d,%d)", X, H, c->X1, c->H1,
              c->H2, c->H2);
     }
     if (B < 1 || B > c->maxB) FAIL(c, LRCN_EINVAL, "B=%d outside [1,%d]", B, c->maxB);
@@ -819,21 +879,26 @@ int lrcn_step(lrcn_ctx *c, const float *const p[9], float *const state[4], int B
     int r = prepare_weights(c, p, false);
     if (r) return r;
     const int Hs[4] = {H1, H1, H2, H2};
-    for (int i = 0; i < 4; ++i) k_transpose_f32(st, state[i], B, Hs[i], B, c->st_f32[i], Hs[i]);
+    const int ns = c->nl == 1 ? 2 : 4;  // LRCN-1f: state = {h, c}
+    for (int i = 0; i < ns; ++i) {
+        if (!state[i]) FAIL(c, LRCN_EINVAL, "null state tensor %d", i);
+        k_transpose_f32(st, state[i], B, Hs[i], B, c->st_f32[i], Hs[i]);
+    }
     k_transpose_f32(st, x_cnn, B, h, B, c->xcnn, c->ldh);
-    // x = dropout(x_lstm)  (lrcn.jl:542): both arrays are B x E column-major, multiply first, then lay out [B][ldE] (T)
+    // two layers: x = dropout(x_lstm)  (lrcn.jl:542): both arrays are B x E column-major, multiply first, then lay out [B][ldE] (T);
+    // mask2 (B x H2) multiplies the concatenated LSTM-2 input (:547).  LRCN-1f: mask1 (B x (E+h)) multiplies hcat(x_lstm, x_cnn).
     DropSpec d2{};
-    d2.which = 2;
-    d2.mask = mask2;
+    d2.which = c->nl == 1 ? 1 : 2;
+    d2.mask = c->nl == 1 ? mask1 : mask2;
     const float *xsrc = x_lstm;
-    if (mask1) {
+    if (mask1 && c->nl == 2) {
         k_mul_f32(st, x_lstm, mask1, (int64_t)B * E, c->st_io);
         xsrc = c->st_io;
     }
-    k_transpose(st, dt, 1, xsrc, B, E, B, c->st_x, c->ldE, 0);
+    k_transpose(st, dt, 1, xsrc, B, E, B, c->st_x, c->ldX1, 0);
     r = step_internal(c, p, B, d2);
     if (r) return r;
-    for (int i = 0; i < 4; ++i) k_transpose_f32(st, c->st_f32[i], Hs[i], B, Hs[i], state[i], B);
+    for (int i = 0; i < ns; ++i) k_transpose_f32(st, c->st_f32[i], Hs[i], B, Hs[i], state[i], B);
     k_transpose_f32(st, c->st_logits, c->ldV, B, V, logits, B);
     KCHK(c, "lrcn_step");
     return LRCN_OK;
@@ -871,7 +936,7 @@ int lrcn_beam_search(lrcn_ctx *c, const float *const p[9], const float *feat, in
     for (int current = 1;; ++current) {
         for (int i = 0; i < K; ++i) last[i] = x[i].seq.back();
         HIPCHK(c, hipMemcpyAsync(c->st_parent, last.data(), sizeof(int32_t) * K, hipMemcpyHostToDevice, st));
-        k_embed_gather(st, dt, c->WeT, c->ldE, c->st_parent, 1, K, E, none, c->st_x, c->ldE);  // lrcn.jl:650
+        k_embed_gather(st, dt, c->WeT, c->ldE, c->st_parent, 1, K, E, none, c->st_x, c->ldX1);  // lrcn.jl:650
         r = step_internal(c, p, K, none);                                                    // lrcn.jl:651 (K hypotheses batched)
         if (r) return r;
         if (!k_softmax_topk_rows(st, c->st_logits, c->ldV, K, V, K, c->st_topi, c->st_topv)) {  // :652, :655-656 on device
@@ -947,6 +1012,10 @@ int lrcn_beam_search_batch(lrcn_ctx *c, const float *const p[9], const float *fe
     for (int i = 0; i < 4; ++i) HIPCHK(c, hipMemsetAsync(c->st_f32[i], 0, sizeof(float) * (size_t)R * Hs[i], st));
     HIPCHK(c, hipMemsetAsync(c->st_xh1, 0, c->esz * (size_t)R * c->ldXH1, st));  // zero initial h1 / h2 (T copies) and K padding
     HIPCHK(c, hipMemsetAsync(c->st_xh2, 0, c->esz * (size_t)R * c->ldXH2, st));
+    if (c->nl == 1) {  // LRCN-1f: the x_cnn columns of [emb | x_cnn | h1] are constant over the decode (a hypothesis never changes image)
+        DropSpec nd{};
+        k_concat_x2(st, dt, c->st_xh1, c->ldXH1, c->xcnn, c->ldh, 1, R, E, h, nd);
+    }
     HIPCHK(c, hipMemsetAsync(c->bs_done, 0, sizeof(int32_t) * N, st));
     HIPCHK(c, hipMemsetAsync(c->bs_ndone, 0, sizeof(int32_t), st));
     {   // histories = [bos], probabilities 1, next input = bos
@@ -972,7 +1041,7 @@ int lrcn_beam_search_batch(lrcn_ctx *c, const float *const p[9], const float *fe
                       c->bs_ndone, c->bs_res_tok, c->bs_res_len, c->bs_res_p, N, K, Lh, current, nword, LRCN_EOS);
         cur ^= 1;
         {   // :673-676: the four states follow their parents; the T copies of h1 / h2 for the next step's GEMMs ride along
-            void *const hT[4] = {boff(c->st_xh1, c->ldE, c->esz), nullptr, boff(c->st_xh2, c->ldH2, c->esz), nullptr};
+            void *const hT[4] = {boff(c->st_xh1, c->ldX1, c->esz), nullptr, boff(c->st_xh2, c->ldH2, c->esz), nullptr};
             const int64_t ldT[4] = {c->ldXH1, 0, c->ldXH2, 0};
             k_gather_state(st, dt, c->st_f32, c->st2_f32, hT, ldT, Hs, c->st_parent, R);
             for (int i = 0; i < 4; ++i) std::swap(c->st_f32[i], c->st2_f32[i]);

@@ -130,6 +130,8 @@ class DataParallelTrainer:
         if gpu and self._bucket_streams is None:
             self._bucket_streams = [torch.cuda.Stream(device=self.flat_grads.device) for _ in GRAD_GROUPS]
         for k, (a, b) in enumerate(self._group_slices()):
+            if a == b:
+                continue  # LRCN-1f has no W2 / b2: nothing to exchange for that group
             chunk = self.flat_grads[a:b]
             if gpu:
                 s = self._bucket_streams[k]
@@ -219,7 +221,7 @@ class DataParallelTrainer:
             s = self._bucket_streams[k]
             self.ops.grad_group_wait(k, s)  # s waits for the group's event recorded inside lossgradient
             with torch.cuda.stream(s):
-                if self.world > 1:
+                if self.world > 1 and b > a:
                     dist.all_reduce(self.flat_grads[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True).wait()  # s waits for RCCL
                 self.ops.update_group(self.param, self.grads, self.optim, k, s)
         for s in self._bucket_streams:

@@ -76,8 +76,10 @@ def _p9(ts):
     return _lib.P9(*[_ptr(t).value for t in ts])
 
 
-def param_shapes(E, H1, H2, V):
+def param_shapes(E, H1, H2, V, n_layers=2):
     h = (H2 + 1) // 2
+    if n_layers == 1:  # LRCN-1f (include/lrcn.h, lrcn_config.n_layers): no W2 / b2 / Wproj
+        return [(E + h + H1, 4 * H1), (1, 4 * H1), (0, 0), (0, 0), (0, 0), (CNNOUT, h), (V, E), (H2, V), (1, V)]
     return [(E + H1, 4 * H1), (1, 4 * H1), (H2 + H2, 4 * H2), (1, 4 * H2), (H1, h), (CNNOUT, h), (V, E), (H2, V), (1, V)]
 
 
@@ -86,7 +88,7 @@ class Context:
     """One lrcn_ctx (one device). Owns scratch only; the caller owns models, gradients, optimizer state."""
 
     def __init__(self, E, H1, H2, V, max_B, max_T=_lib.MAX_T, lstm_dtype=LRCN_F32, vgg_dtype=LRCN_F32, max_images=0,
-                 device=None):
+                 device=None, n_layers=2):
         if not torch.cuda.is_available():
             raise LrcnError("no MI355X visible: liblrcn_hip has no CPU path")
         self.device = torch.cuda.current_device() if device is None else int(device)
@@ -94,7 +96,8 @@ class Context:
         self.h = H2 // 2
         self.max_B, self.max_T = max_B, max_T
         self.lstm_dtype, self.vgg_dtype = lstm_dtype, vgg_dtype
-        cfg = _lib.Config(self.device, E, H1, H2, V, max_B, max_T, lstm_dtype, vgg_dtype, max_images)
+        self.n_layers = n_layers
+        cfg = _lib.Config(self.device, E, H1, H2, V, max_B, max_T, lstm_dtype, vgg_dtype, max_images, n_layers)
         h = C.c_void_p()
         rc = _lib.lib().lrcn_create(C.byref(cfg), C.byref(h))
         _lib.check(None, rc)
@@ -130,11 +133,14 @@ def _dropout(pdrop, seed, mask1, mask2):
     d = _lib.Dropout(float(pdrop or 0.0), int(seed or 0), None, None)
     keep = None
     if mask1 is not None:
-        # masks: (T+1, B, E) / (T+1, B, H2) logical arrays; the ABI wants (T+1) column-major blocks
+        # masks: (T+1, B, E) / (T+1, B, H2) logical arrays; the ABI wants (T+1) column-major blocks (LRCN-1f: mask1 only, (T+1, B, E+h))
         m1 = torch.as_tensor(np.ascontiguousarray(np.transpose(np.asarray(mask1, np.float32), (0, 2, 1)))).cuda()
-        m2 = torch.as_tensor(np.ascontiguousarray(np.transpose(np.asarray(mask2, np.float32), (0, 2, 1)))).cuda()
-        d.mask1, d.mask2 = m1.data_ptr(), m2.data_ptr()
-        keep = (m1, m2)
+        d.mask1 = m1.data_ptr()
+        keep = [m1]
+        if mask2 is not None:
+            m2 = torch.as_tensor(np.ascontiguousarray(np.transpose(np.asarray(mask2, np.float32), (0, 2, 1)))).cuda()
+            d.mask2 = m2.data_ptr()
+            keep.append(m2)
     return d, keep
 
 
@@ -148,7 +154,7 @@ def _tokens(tokens, device):
 # ------------------------------------------------------------------------------------------------ model
 def initweights(ctx, seed=42):
     """initweights(atype, hidden, vocab, embed) (lrcn.jl:489-510) -> list of 9 column-major tensors."""
-    model = [jl_empty(*s) for s in param_shapes(ctx.E, ctx.H1, ctx.H2, ctx.V)]
+    model = [jl_empty(*s) for s in param_shapes(ctx.E, ctx.H1, ctx.H2, ctx.V, ctx.n_layers)]
     ctx._call("lrcn_init_weights", _p9(model), C.c_uint64(seed))
     return model
 
@@ -172,6 +178,8 @@ def zeros_like_model(model):
 def initstate(ctx, batch):
     """initstate(model, batch) (lrcn.jl:512-526): zero (B x H) hidden/cell per layer -- without the reference's
     spurious third layer and without aliasing all entries to one array."""
+    if ctx.n_layers == 1:
+        return [jl_zeros(batch, ctx.H1), jl_zeros(batch, ctx.H1)]
     return [jl_zeros(batch, ctx.H1), jl_zeros(batch, ctx.H1), jl_zeros(batch, ctx.H2), jl_zeros(batch, ctx.H2)]
 
 
@@ -189,7 +197,7 @@ def lrcn(ctx, w, s, x_cnn, x_lstm, mask1=None, mask2=None):
     Dropout enters as explicit multiplier arrays (B x E, B x H2) so a step is reproducible."""
     B = x_lstm.shape[0]
     logits = jl_empty(B, ctx.V)
-    st = _lib.P4(*[_ptr(t).value for t in s])
+    st = _lib.P4(*([_ptr(t).value for t in s] + [None] * (4 - len(s))))
     ctx._call("lrcn_step", _p9(w), st, B, _ptr(x_cnn), _ptr(x_lstm), _ptr(mask1), _ptr(mask2), _ptr(logits))
     return logits
 

@@ -433,6 +433,154 @@ void orc_adam(float *w, const float *g, float *mom, float *var, int64_t n, int t
     }
 }
 
+/* ================================================================================================
+ * LRCN-1f -- BASELINE configs[1] "1-layer LSTM" (SURVEY 8d).  NOT in the reference, which hard-wires two layers
+ * (lrcn.jl:540-551; its initweights would raise BoundsError for length(hidden) == 1, :504): this repo's definition --
+ * drop LSTM-1 and Wproj of lrcn() and feed dropout(hcat(x_lstm, x_cnn)) to ONE lstm (:528-538) of width H = H1 = H2, then the
+ * same output layer (:550).  Everything else (loss :553-581, generate/beam_search :585-678, Adam) is the reference's code
+ * with this step in place of lrcn().  The model uses W1 ((E+h+H) x 4H), b1, Wcnn, Wembed, Wout, bout of orc_model.
+ * ================================================================================================ */
+void orc1_param_sizes(int E, int H, int V, int64_t s[9]) {
+    const int h = (H + 1) / 2;
+    s[0] = (int64_t)(E + h + H) * 4 * H;
+    s[1] = 4 * H;
+    s[2] = s[3] = s[4] = 0;
+    s[5] = (int64_t)ORC_CNNOUT * h;
+    s[6] = (int64_t)V * E;
+    s[7] = (int64_t)H * V;
+    s[8] = V;
+}
+void orc1_init_weights(orc_model *m, uint64_t seed) { /* initweights' rules (lrcn.jl:489-510) on the 1f shapes */
+    uint64_t rng = seed;
+    const int H = m->H1, h = (H + 1) / 2;
+    xavier(m->W1, m->E + h + H, 4 * H, &rng);
+    memset(m->b1, 0, sizeof(float) * 4 * H);
+    for (int i = 0; i < H; ++i) m->b1[i] = 1.0f;
+    xavier(m->Wcnn, ORC_CNNOUT, h, &rng);
+    xavier(m->Wembed, m->V, m->E, &rng);
+    xavier(m->Wout, H, m->V, &rng);
+    memset(m->bout, 0, sizeof(float) * m->V);
+}
+
+typedef struct {
+    float *x;   /* B x (E+h)  dropout(hcat(x_lstm, x_cnn)) */
+    float *xh;  /* B x (E+h+H) */
+    float *g, *cp, *c, *h;
+    float *logits;
+} step1_tape;
+static void tape1_alloc(step1_tape *t, const orc_model *m, int B) {
+    const int H = m->H1, X = m->E + (H + 1) / 2;
+    t->x = fzeros((size_t)B * X);
+    t->xh = fzeros((size_t)B * (X + H));
+    t->g = fzeros((size_t)B * 4 * H);
+    t->cp = fzeros((size_t)B * H);
+    t->c = fzeros((size_t)B * H);
+    t->h = fzeros((size_t)B * H);
+    t->logits = fzeros((size_t)B * m->V);
+}
+static void tape1_free(step1_tape *t) { free(t->x); free(t->xh); free(t->g); free(t->cp); free(t->c); free(t->h); free(t->logits); }
+
+static void lrcn1_fwd(const orc_model *m, int B, const float *h, const float *c, const float *x_cnn, const float *x_lstm,
+                      const float *mask, step1_tape *t) {
+    const int E = m->E, H = m->H1, V = m->V, hh = (H + 1) / 2, X = E + hh;
+    memcpy(t->x, x_lstm, sizeof(float) * (size_t)B * E);                  /* hcat(x_lstm, x_cnn) */
+    memcpy(t->x + (size_t)B * E, x_cnn, sizeof(float) * (size_t)B * hh);
+    if (mask)
+        for (size_t i = 0; i < (size_t)B * X; ++i) t->x[i] *= mask[i];    /* dropout */
+    memcpy(t->cp, c, sizeof(float) * (size_t)B * H);
+    lstm_fwd(m->W1, m->b1, X, H, B, t->x, h, c, t->h, t->c, t->g, t->xh);
+    gemm_cm(0, 0, B, V, H, t->h, B, m->Wout, H, 0.0f, t->logits, B);     /* x * w[end-1] .+ w[end]  :550 */
+    for (int v = 0; v < V; ++v) {
+        const float bv = m->bout[v];
+        float *l = &CM(t->logits, B, 0, v);
+        for (int i = 0; i < B; ++i) l[i] += bv;
+    }
+}
+
+void orc1_step(const orc_model *m, int B, float *h, float *c, const float *x_cnn, const float *x_lstm, const float *mask,
+               float *logits) {
+    step1_tape t;
+    tape1_alloc(&t, m, B);
+    lrcn1_fwd(m, B, h, c, x_cnn, x_lstm, mask, &t);
+    memcpy(h, t.h, sizeof(float) * (size_t)B * m->H1);
+    memcpy(c, t.c, sizeof(float) * (size_t)B * m->H1);
+    memcpy(logits, t.logits, sizeof(float) * (size_t)B * m->V);
+    tape1_free(&t);
+}
+
+static double loss1_impl(const orc_model *m, const float *feats, const int32_t *tokens, int T, int B, int norm_B, const float *mask,
+                         orc_model *G, float *logits_out) {
+    const int E = m->E, H = m->H1, V = m->V, hh = (H + 1) / 2, X = E + hh;
+    const int S = T + 1;
+    step1_tape *tape = (step1_tape *)xmalloc(sizeof(step1_tape) * S);
+    for (int s = 0; s < S; ++s) tape1_alloc(&tape[s], m, B);
+    float *x_cnn = fzeros((size_t)B * hh);
+    gemm_cm(0, 0, B, hh, ORC_CNNOUT, feats, B, m->Wcnn, ORC_CNNOUT, 0.0f, x_cnn, B); /* :558 */
+    float *zeroH = fzeros((size_t)B * H), *x_lstm = fzeros((size_t)B * E);
+    int32_t *inp = (int32_t *)xmalloc(sizeof(int32_t) * B), *tgt = (int32_t *)xmalloc(sizeof(int32_t) * B);
+    double total = 0.0;
+    long count = 0;
+    for (int s = 0; s < S; ++s) {
+        for (int i = 0; i < B; ++i) {
+            inp[i] = (s == 0) ? ORC_BOS : tokens[(size_t)(s - 1) * B + i];
+            tgt[i] = (s < T) ? tokens[(size_t)s * B + i] : ORC_EOS;
+        }
+        embed_rows(m, inp, B, x_lstm);
+        lrcn1_fwd(m, B, s ? tape[s - 1].h : zeroH, s ? tape[s - 1].c : zeroH, x_cnn, x_lstm, mask ? mask + (size_t)s * B * X : NULL, &tape[s]);
+        total += logp_pick(tape[s].logits, B, V, tgt, NULL, 0.0);
+        count += norm_B;
+        if (logits_out) memcpy(logits_out + (size_t)s * B * V, tape[s].logits, sizeof(float) * (size_t)B * V);
+    }
+    const double loss = -total / (double)count;
+    if (G) {
+        int64_t sz[9];
+        orc1_param_sizes(E, H, V, sz);
+        float *gp[9] = {G->W1, G->b1, NULL, NULL, NULL, G->Wcnn, G->Wembed, G->Wout, G->bout};
+        for (int k = 0; k < 9; ++k)
+            if (gp[k]) memset(gp[k], 0, sizeof(float) * (size_t)sz[k]);
+        const double scale = 1.0 / (double)count;
+        float *dlog = fzeros((size_t)B * V), *dh = fzeros((size_t)B * H), *dc = fzeros((size_t)B * H), *dcp = fzeros((size_t)B * H);
+        float *dxh = fzeros((size_t)B * (X + H)), *dz = fzeros((size_t)B * 4 * H), *dxcnn = fzeros((size_t)B * hh);
+        for (int s = S - 1; s >= 0; --s) {
+            step1_tape *t = &tape[s];
+            for (int i = 0; i < B; ++i) {
+                inp[i] = (s == 0) ? ORC_BOS : tokens[(size_t)(s - 1) * B + i];
+                tgt[i] = (s < T) ? tokens[(size_t)s * B + i] : ORC_EOS;
+            }
+            logp_pick(t->logits, B, V, tgt, dlog, scale);
+            gemm_cm(1, 0, H, V, B, t->h, B, dlog, B, 1.0f, G->Wout, H);
+            for (int v = 0; v < V; ++v) {
+                acc_t a = 0;
+                for (int i = 0; i < B; ++i) a += CM(dlog, B, i, v);
+                G->bout[v] += (float)a;
+            }
+            gemm_cm(0, 1, B, H, V, dlog, B, m->Wout, H, 1.0f, dh, B); /* dh holds the recurrent part */
+            lstm_bwd(m->W1, X, H, B, t->xh, t->g, t->cp, t->c, dh, dc, dxh, dcp, G->W1, G->b1, dz);
+            memcpy(dh, dxh + (size_t)B * X, sizeof(float) * (size_t)B * H);
+            memcpy(dc, dcp, sizeof(float) * (size_t)B * H);
+            if (mask) {
+                const float *mk = mask + (size_t)s * B * X;
+                for (size_t i = 0; i < (size_t)B * X; ++i) dxh[i] *= mk[i];
+            }
+            for (int e = 0; e < E; ++e)
+                for (int i = 0; i < B; ++i) CM(G->Wembed, V, inp[i], e) += CM(dxh, B, i, e);
+            for (size_t i = 0; i < (size_t)B * hh; ++i) dxcnn[i] += dxh[(size_t)B * E + i];
+        }
+        gemm_cm(1, 0, ORC_CNNOUT, hh, B, feats, B, dxcnn, B, 0.0f, G->Wcnn, ORC_CNNOUT);
+        free(dlog); free(dh); free(dc); free(dcp); free(dxh); free(dz); free(dxcnn);
+    }
+    for (int s = 0; s < S; ++s) tape1_free(&tape[s]);
+    free(tape); free(x_cnn); free(zeroH); free(x_lstm); free(inp); free(tgt);
+    return loss;
+}
+double orc1_loss(const orc_model *m, const float *feats, const int32_t *tokens, int T, int B, int norm_B, const float *mask,
+                 orc_model *grads) {
+    return loss1_impl(m, feats, tokens, T, B, norm_B, mask, grads, NULL);
+}
+void orc1_forward_logits(const orc_model *m, const float *feats, const int32_t *tokens, int T, int B, float *logits_out) {
+    loss1_impl(m, feats, tokens, T, B, B, NULL, NULL, logits_out);
+}
+
 /* ------------------------------------------------------------------------------------------------
  * beam_search  (lrcn.jl:644-678) driven as generate does (lrcn.jl:609-633)
  * ------------------------------------------------------------------------------------------------ */
@@ -460,8 +608,7 @@ static void argsort_desc(const float *v, int n, int *perm) {
     free(tmp);
 }
 
-int orc_beam_search(const orc_model *m, const float *feat, int K, int nword, int32_t *out_tokens,
-                    float *out_prob) {
+static int beam_impl(const orc_model *m, const float *feat, int K, int nword, int32_t *out_tokens, float *out_prob, int one_layer) {
     const int E = m->E, H1 = m->H1, H2 = m->H2, V = m->V, hh = (H2 + 1) / 2;
     const int maxlen = nword + 3;
     float *x_cnn = fzeros(hh);
@@ -493,7 +640,10 @@ int orc_beam_search(const orc_model *m, const float *feat, int K, int nword, int
             const int32_t last = x[i].seq[x[i].len - 1]; /* :648 */
             for (int e = 0; e < E; ++e) emb[e] = CM(m->Wembed, V, last, e); /* :650 */
             float *s = st[i];
-            orc_lrcn_step(m, 1, s, s + H1, s + 2 * H1, s + 2 * H1 + H2, x_cnn, emb, NULL, NULL, logits); /* :651 */
+            if (one_layer)
+                orc1_step(m, 1, s, s + H1, x_cnn, emb, NULL, logits);
+            else
+                orc_lrcn_step(m, 1, s, s + H1, s + 2 * H1, s + 2 * H1 + H2, x_cnn, emb, NULL, NULL, logits); /* :651 */
             /* ynorm = exp(logp(ypred,2))  :652 */
             float mx = logits[0];
             for (int v = 1; v < V; ++v) mx = fmaxf(mx, logits[v]);
@@ -543,6 +693,12 @@ int orc_beam_search(const orc_model *m, const float *feat, int K, int nword, int
     free(x); free(st); free(nst); free(cand); free(cp); free(corder); free(perm);
     free(logits); free(prob); free(emb); free(x_cnn);
     return len;
+}
+int orc_beam_search(const orc_model *m, const float *feat, int K, int nword, int32_t *out_tokens, float *out_prob) {
+    return beam_impl(m, feat, K, nword, out_tokens, out_prob, 0);
+}
+int orc1_beam_search(const orc_model *m, const float *feat, int K, int nword, int32_t *out_tokens, float *out_prob) {
+    return beam_impl(m, feat, K, nword, out_tokens, out_prob, 1);
 }
 
 /* ------------------------------------------------------------------------------------------------

@@ -94,6 +94,19 @@ void orc_adam(float *w, const float *g, float *mom, float *var, int64_t n, int t
 int orc_beam_search(const orc_model *m, const float *feat, int K, int nword, int32_t *out_tokens,
                     float *out_prob);
 
+/* ---- LRCN-1f: BASELINE configs[1] "1-layer LSTM" (SURVEY 8d).  This repo's definition, NOT reference code (the reference
+ * hard-wires two layers): drop LSTM-1 and Wproj from lrcn() and feed dropout(hcat(x_lstm, x_cnn)) to ONE lstm of width
+ * H = m->H1 = m->H2, then the same output layer.  The model lives in the W1 ((E+h+H) x 4H), b1, Wcnn (4096 x h), Wembed, Wout,
+ * bout members of orc_model (h = ceil(H/2)); W2, b2, Wproj are not touched.  mask: (T+1) blocks of B x (E+h), or NULL. ---- */
+void orc1_param_sizes(int E, int H, int V, int64_t sizes[9]); /* 0 for the absent tensors */
+void orc1_init_weights(orc_model *m, uint64_t seed);
+void orc1_step(const orc_model *m, int B, float *h, float *c, const float *x_cnn, const float *x_lstm, const float *mask,
+               float *logits);
+double orc1_loss(const orc_model *m, const float *feats, const int32_t *tokens, int T, int B, int norm_B, const float *mask,
+                 orc_model *grads);
+void orc1_forward_logits(const orc_model *m, const float *feats, const int32_t *tokens, int T, int B, float *logits_out);
+int orc1_beam_search(const orc_model *m, const float *feat, int K, int nword, int32_t *out_tokens, float *out_prob);
+
 /* ---- VGG-16 to fc7 (lrcn.jl:697-748) ---- */
 /* convx (lrcn.jl:724): 3x3, pad 1, stride 1, cross-correlation (mode=1) + bias.
  * x: (W,H,Cin,N) col-major; w: (3,3,Cin,Cout) col-major; b: Cout; y: (W,H,Cout,N). relu!=0 fuses relux (:725). */

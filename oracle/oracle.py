@@ -79,6 +79,16 @@ def lib(fast=False):
         L.orc_adam.argtypes = [_fp, _fp, _fp, _fp, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]
         L.orc_beam_search.restype = C.c_int
         L.orc_beam_search.argtypes = [C.POINTER(_Model), _fp, C.c_int, C.c_int, _ip, _fp]
+        L.orc1_init_weights.restype = None
+        L.orc1_init_weights.argtypes = [C.POINTER(_Model), C.c_uint64]
+        L.orc1_step.restype = None
+        L.orc1_step.argtypes = [C.POINTER(_Model), C.c_int] + [_fp] * 6
+        L.orc1_loss.restype = C.c_double
+        L.orc1_loss.argtypes = [C.POINTER(_Model), _fp, _ip, C.c_int, C.c_int, C.c_int, _fp, C.POINTER(_Model)]
+        L.orc1_forward_logits.restype = None
+        L.orc1_forward_logits.argtypes = [C.POINTER(_Model), _fp, _ip, C.c_int, C.c_int, _fp]
+        L.orc1_beam_search.restype = C.c_int
+        L.orc1_beam_search.argtypes = [C.POINTER(_Model), _fp, C.c_int, C.c_int, _ip, _fp]
         L.orc_conv3x3.restype = None
         L.orc_conv3x3.argtypes = [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_int, C.c_int, _fp]
         L.orc_pool2.restype = None
@@ -106,19 +116,23 @@ def fa(x, shape=None):
     return a
 
 
-def param_shapes(E, H1, H2, V):
-    """Reference shapes of the 9 tensors (lrcn.jl:489-510)."""
+def param_shapes(E, H1, H2, V, n_layers=2):
+    """Reference shapes of the 9 tensors (lrcn.jl:489-510); n_layers=1: LRCN-1f (lrcn_oracle.h), absent tensors (0, 0)."""
     h = (H2 + 1) // 2
+    if n_layers == 1:
+        assert H1 == H2
+        return {"W1": (E + h + H1, 4 * H1), "b1": (1, 4 * H1), "W2": (0, 0), "b2": (0, 0), "Wproj": (0, 0),
+                "Wcnn": (CNNOUT, h), "Wembed": (V, E), "Wout": (H2, V), "bout": (1, V)}
     return {"W1": (E + H1, 4 * H1), "b1": (1, 4 * H1), "W2": (H2 + H2, 4 * H2), "b2": (1, 4 * H2),
             "Wproj": (H1, h), "Wcnn": (CNNOUT, h), "Wembed": (V, E), "Wout": (H2, V), "bout": (1, V)}
 
 
 class Model:
-    """The reference's `model` vector: 9 Fortran-order float32 arrays with lrcn.jl's shapes."""
+    """The reference's `model` vector: 9 Fortran-order float32 arrays with lrcn.jl's shapes (n_layers=1: LRCN-1f)."""
 
-    def __init__(self, E, H1, H2, V, arrays=None):
-        self.E, self.H1, self.H2, self.V = E, H1, H2, V
-        shp = param_shapes(E, H1, H2, V)
+    def __init__(self, E, H1, H2, V, arrays=None, n_layers=2):
+        self.E, self.H1, self.H2, self.V, self.n_layers = E, H1, H2, V, n_layers
+        shp = param_shapes(E, H1, H2, V, n_layers)
         self.p = {}
         for n in PARAM_NAMES:
             if arrays is not None:
@@ -135,16 +149,16 @@ class Model:
         return m
 
     def zeros_like(self):
-        return Model(self.E, self.H1, self.H2, self.V)
+        return Model(self.E, self.H1, self.H2, self.V, n_layers=self.n_layers)
 
     def arrays(self):
         return [self.p[n] for n in PARAM_NAMES]
 
 
-def init_weights(E, H1, H2, V, seed=42):
-    m = Model(E, H1, H2, V)
+def init_weights(E, H1, H2, V, seed=42, n_layers=2):
+    m = Model(E, H1, H2, V, n_layers=n_layers)
     cs = m.cstruct()
-    lib().orc_init_weights(C.byref(cs), seed)
+    (lib().orc1_init_weights if n_layers == 1 else lib().orc_init_weights)(C.byref(cs), seed)
     return m
 
 
@@ -165,10 +179,15 @@ def loss(model, feats, tokens, norm_B=None, mask1=None, mask2=None, want_grad=Fa
     m1 = m2 = None
     if mask1 is not None:
         m1 = np.ascontiguousarray(np.stack([np.asfortranarray(b).ravel(order="F") for b in mask1]), dtype=np.float32)
+    if mask2 is not None:
         m2 = np.ascontiguousarray(np.stack([np.asfortranarray(b).ravel(order="F") for b in mask2]), dtype=np.float32)
     cs = model.cstruct()
     g = model.zeros_like() if want_grad else None
     gs = g.cstruct() if want_grad else None
+    if model.n_layers == 1:  # LRCN-1f: one mask over the (E + h) columns of hcat(x_lstm, x_cnn)
+        val = lib(fast).orc1_loss(C.byref(cs), _f(feats), tokens.ctypes.data_as(_ip), T, B, norm_B or B, _f(m1),
+                                  C.byref(gs) if want_grad else None)
+        return (val, g) if want_grad else val
     val = lib(fast).orc_loss(C.byref(cs), _f(feats), tokens.ctypes.data_as(_ip), T, B, norm_B or B, _f(m1), _f(m2),
                              C.byref(gs) if want_grad else None)
     return (val, g) if want_grad else val
@@ -180,7 +199,8 @@ def forward_logits(model, feats, tokens):
     feats = fa(feats)
     out = np.zeros((T + 1, model.V, B), dtype=np.float32)  # each block B x V column-major == [V][B] C-order
     cs = model.cstruct()
-    lib().orc_forward_logits(C.byref(cs), _f(feats), tokens.ctypes.data_as(_ip), T, B, _f(out))
+    (lib().orc1_forward_logits if model.n_layers == 1 else lib().orc_forward_logits)(C.byref(cs), _f(feats), tokens.ctypes.data_as(_ip),
+                                                                                      T, B, _f(out))
     return np.transpose(out, (0, 2, 1))  # -> (T+1, B, V)
 
 
@@ -197,10 +217,14 @@ def lstm(W, b, x, h, c):
 def lrcn_step(model, state, x_cnn, x_lstm, mask1=None, mask2=None):
     """lrcn (lrcn.jl:540-551). state = [h1,c1,h2,c2] (updated in place, Fortran arrays). Returns logits B x V."""
     B = x_lstm.shape[0]
-    for i in range(4):
+    for i in range(len(state)):
         state[i] = fa(state[i])
     logits = np.zeros((B, model.V), np.float32, order="F")
     cs = model.cstruct()
+    if model.n_layers == 1:  # state = [h, c]; mask1 = B x (E + h)
+        lib().orc1_step(C.byref(cs), B, _f(state[0]), _f(state[1]), _f(fa(x_cnn)), _f(fa(x_lstm)),
+                        _f(fa(mask1)) if mask1 is not None else None, _f(logits))
+        return logits
     lib().orc_lrcn_step(C.byref(cs), B, _f(state[0]), _f(state[1]), _f(state[2]), _f(state[3]), _f(fa(x_cnn)),
                         _f(fa(x_lstm)), _f(fa(mask1)) if mask1 is not None else None,
                         _f(fa(mask2)) if mask2 is not None else None, _f(logits))
@@ -219,7 +243,8 @@ def beam_search(model, feat, K, nword):
     out = np.zeros(nword + 3, np.int32)
     prob = C.c_float(0)
     cs = model.cstruct()
-    n = lib().orc_beam_search(C.byref(cs), _f(feat), K, nword, out.ctypes.data_as(_ip), C.byref(prob))
+    fn = lib().orc1_beam_search if model.n_layers == 1 else lib().orc_beam_search
+    n = fn(C.byref(cs), _f(feat), K, nword, out.ctypes.data_as(_ip), C.byref(prob))
     return out[:n].copy(), prob.value
 
 

@@ -168,6 +168,124 @@ def make_lstm_case(name, seed, B, E, H1, H2, V, T, pdrop, norm_B=None, nadam=2, 
     print(name, "loss", L.item())
 
 
+# ---- LRCN-1f (BASELINE configs[1] "1-layer LSTM"; this repo's definition, see oracle/lrcn_oracle.h): one lstm() over
+# dropout(hcat(x_lstm, x_cnn)), then the reference's output layer; loss / Adam / beam search are the reference's code around it.
+def init_model1(rng, E, H, V, F=4096):
+    h = (H + 1) // 2
+    b1 = np.zeros((1, 4 * H), np.float32)
+    b1[0, :H] = 1
+    z = np.zeros((0, 0), np.float32)
+    return {"W1": xavier(rng, E + h + H, 4 * H), "b1": b1, "W2": z, "b2": z, "Wproj": z, "Wcnn": xavier(rng, F, h),
+            "Wembed": xavier(rng, V, E), "Wout": xavier(rng, H, V), "bout": (0.1 * rng.standard_normal((1, V))).astype(np.float32)}
+
+
+def lrcn1(p, s, x_cnn, x_lstm, m=None):
+    x = torch.cat([x_lstm, x_cnn], 1)
+    if m is not None:
+        x = x * m
+    s[0], s[1] = lstm(p["W1"], p["b1"], s[0], s[1], x)
+    return s[0] @ p["Wout"] + p["bout"]
+
+
+def loss1(p, feats, tokens, norm_B, mask=None, collect=None):  # lrcn.jl:553-581 around lrcn1
+    T, B = tokens.shape
+    H = p["Wout"].shape[0]
+    s = [torch.zeros(B, H), torch.zeros(B, H)]
+    total = 0.0
+    count = 0
+    x_lstm = p["Wembed"][torch.full((B,), BOS, dtype=torch.long)]
+    x_cnn = feats @ p["Wcnn"]
+    for t in range(T + 1):
+        ypred = lrcn1(p, s, x_cnn, x_lstm, None if mask is None else mask[t])
+        if collect is not None:
+            collect.append(ypred.detach().numpy().astype(np.float32))
+        ynorm = torch.log_softmax(ypred, 1)
+        tgt = torch.as_tensor(tokens[t], dtype=torch.long) if t < T else torch.full((B,), EOS, dtype=torch.long)
+        total = total + ynorm[torch.arange(B), tgt].sum()
+        count += norm_B
+        if t < T:
+            x_lstm = p["Wembed"][tgt]
+    return -total / count
+
+
+def beam_search_ref1(p, feat, K, nword):
+    with torch.no_grad():
+        H = p["Wout"].shape[0]
+        x_cnn = feat @ p["Wcnn"]
+        x = [([BOS], np.float32(1.0)) for _ in range(K)]
+        states = [[torch.zeros(1, H), torch.zeros(1, H)] for _ in range(K)]
+        current = 1
+        while True:
+            new_x = []
+            for i in range(K):
+                last = x[i][0][-1]
+                yp = lrcn1(p, states[i], x_cnn, p["Wembed"][last:last + 1])
+                prob = torch.softmax(yp, 1).numpy().astype(np.float32).reshape(-1)
+                top = np.argsort(-prob, kind="stable")[:K]
+                for j in range(K):
+                    new_x.append((x[i][0] + [int(top[j])], np.float32(prob[top[j]] * x[i][1])))
+                if current == 1:
+                    break
+            order = np.argsort(-np.array([c[1] for c in new_x], np.float32), kind="stable")
+            xs = [new_x[o] for o in order[:K]]
+            if xs[0][0][-1] == EOS or current > nword:
+                return xs
+            states = [[t.clone() for t in states[order[i] // K]] for i in range(K)]
+            x = xs
+            current += 1
+
+
+def make_lstm1_case(name, seed, B, E, H, V, T, pdrop, norm_B=None, nadam=2, beam=None):
+    rng = np.random.default_rng(seed)
+    norm_B = norm_B or B
+    h = (H + 1) // 2
+    P = init_model1(rng, E, H, V)
+    live = [k for k in P if P[k].size]
+    feats = (rng.standard_normal((B, 4096)) * 0.05).astype(np.float32)
+    tokens = rng.integers(0, V, size=(T, B)).astype(np.int32)
+    mask = ((rng.random((T + 1, B, E + h)) > pdrop) / (1 - pdrop)).astype(np.float32) if pdrop > 0 else None
+    tm = None if mask is None else torch.tensor(mask, dtype=torch.float64)
+    p = {k: torch.tensor(P[k], dtype=torch.float64, requires_grad=True) for k in live}
+    logits = []
+    L = loss1(p, torch.tensor(feats, dtype=torch.float64), tokens, norm_B, tm, collect=logits)
+    L.backward()
+    out = {"E": E, "H1": H, "H2": H, "V": V, "T": T, "B": B, "norm_B": norm_B, "pdrop": pdrop, "n_layers": 1,
+           "feats": feats, "tokens": tokens, "loss": np.float64(L.item()), "logits": np.stack(logits)}
+    if mask is not None:
+        out["mask1"] = mask
+    for k in P:
+        out["p_" + k] = P[k]
+        out["g_" + k] = p[k].grad.numpy().astype(np.float32) if k in live else P[k]
+    W = {k: P[k].astype(np.float64) for k in live}
+    M = {k: np.zeros_like(v) for k, v in W.items()}
+    Vv = {k: np.zeros_like(v) for k, v in W.items()}
+    losses = []
+    for t in range(1, nadam + 1):
+        q = {k: torch.tensor(v.astype(np.float32), dtype=torch.float64, requires_grad=True) for k, v in W.items()}
+        Lt = loss1(q, torch.tensor(feats, dtype=torch.float64), tokens, norm_B, tm)
+        Lt.backward()
+        losses.append(Lt.item())
+        for k in W:
+            W[k], M[k], Vv[k] = adam_ref(W[k].astype(np.float32).astype(np.float64), q[k].grad.numpy(), M[k], Vv[k], t)
+    out["adam_losses"] = np.array(losses)
+    for k in P:
+        out["a_" + k] = W[k].astype(np.float32) if k in live else P[k]
+    if beam:
+        K, nword = beam
+        bs = []
+        for i in range(min(B, 4)):
+            xs = beam_search_ref1({k: v.detach() for k, v in p.items()}, torch.tensor(feats[i:i + 1], dtype=torch.float64), K, nword)
+            seq = np.full(nword + 3, -1, np.int32)
+            seq[:len(xs[0][0])] = xs[0][0]
+            bs.append(seq)
+            out.setdefault("beam_prob", []).append(xs[0][1])
+        out["beam_tokens"] = np.stack(bs)
+        out["beam_prob"] = np.array(out["beam_prob"], np.float32)
+        out["beam_K"], out["beam_nword"] = K, nword
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "loss", L.item())
+
+
 def make_cnn_case(name, seed):
     """conv3x3(pad1, cross-correlation)+bias+relu, 2x2 max-pool, fc -- torch.nn.functional as the second statement.
     Julia (W,H,C,N) column-major == torch [N][C][H][W] with Julia dim 1 <-> torch W."""
@@ -195,8 +313,25 @@ def make_cnn_case(name, seed):
 
 
 if __name__ == "__main__":
-    make_lstm_case("lstm_tiny", 1, B=4, E=8, H1=8, H2=8, V=17, T=5, pdrop=0.0, beam=(3, 6))
-    make_lstm_case("lstm_tiny_drop", 2, B=4, E=8, H1=8, H2=8, V=17, T=5, pdrop=0.4)
-    make_lstm_case("lstm_ragged", 3, B=3, E=12, H1=20, H2=10, V=23, T=1, pdrop=0.0, norm_B=6, beam=(4, 5))
-    make_lstm_case("lstm_mid", 4, B=16, E=40, H1=48, H2=56, V=203, T=9, pdrop=0.0, nadam=1, beam=(5, 12))
-    make_cnn_case("cnn_small", 5)
+    import sys
+    only = set(sys.argv[1:])  # e.g. `make_golden.py lstm1_tiny lstm1_drop lstm1_mid` regenerates just those files
+
+    def want(n):
+        return not only or n in only
+
+    if want("lstm_tiny"):
+        make_lstm_case("lstm_tiny", 1, B=4, E=8, H1=8, H2=8, V=17, T=5, pdrop=0.0, beam=(3, 6))
+    if want("lstm_tiny_drop"):
+        make_lstm_case("lstm_tiny_drop", 2, B=4, E=8, H1=8, H2=8, V=17, T=5, pdrop=0.4)
+    if want("lstm_ragged"):
+        make_lstm_case("lstm_ragged", 3, B=3, E=12, H1=20, H2=10, V=23, T=1, pdrop=0.0, norm_B=6, beam=(4, 5))
+    if want("lstm_mid"):
+        make_lstm_case("lstm_mid", 4, B=16, E=40, H1=48, H2=56, V=203, T=9, pdrop=0.0, nadam=1, beam=(5, 12))
+    if want("cnn_small"):
+        make_cnn_case("cnn_small", 5)
+    if want("lstm1_tiny"):
+        make_lstm1_case("lstm1_tiny", 11, B=4, E=8, H=8, V=17, T=5, pdrop=0.0, beam=(3, 6))
+    if want("lstm1_drop"):
+        make_lstm1_case("lstm1_drop", 12, B=3, E=12, H=10, V=23, T=3, pdrop=0.4, norm_B=6)
+    if want("lstm1_mid"):
+        make_lstm1_case("lstm1_mid", 13, B=16, E=40, H=56, V=203, T=9, pdrop=0.0, nadam=1, beam=(5, 12))

@@ -10,14 +10,18 @@ from oracle import oracle as orc
 CASES = ["lstm_tiny", "lstm_tiny_drop", "lstm_ragged", "lstm_mid"]
 
 
+CASES1 = ["lstm1_tiny", "lstm1_drop", "lstm1_mid"]  # LRCN-1f (BASELINE configs[1]; this repo's definition, lrcn_oracle.h)
+
+
 def load_case(golden_dir, name):
     z = np.load(os.path.join(golden_dir, name + ".npz"))
     E, H1, H2, V = (int(z[k]) for k in ("E", "H1", "H2", "V"))
-    model = orc.Model(E, H1, H2, V, {n: z["p_" + n] for n in orc.PARAM_NAMES})
+    nl = int(z["n_layers"]) if "n_layers" in z else 2
+    model = orc.Model(E, H1, H2, V, {n: z["p_" + n] for n in orc.PARAM_NAMES}, n_layers=nl)
     return z, model
 
 
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", CASES + CASES1)
 def test_loss_and_grads_match_golden(golden_dir, name):
     z, model = load_case(golden_dir, name)
     m1 = z["mask1"] if "mask1" in z else None
@@ -29,20 +33,21 @@ def test_loss_and_grads_match_golden(golden_dir, name):
         np.testing.assert_allclose(g.p[n], ref, rtol=1e-4, atol=1e-7, err_msg=n)
 
 
-@pytest.mark.parametrize("name", ["lstm_tiny", "lstm_mid"])
+@pytest.mark.parametrize("name", ["lstm_tiny", "lstm_mid", "lstm1_tiny", "lstm1_mid"])
 def test_logits_match_golden(golden_dir, name):
     z, model = load_case(golden_dir, name)
     got = orc.forward_logits(model, z["feats"], z["tokens"])
     np.testing.assert_allclose(got, z["logits"], rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("name", ["lstm_tiny", "lstm_ragged"])
+@pytest.mark.parametrize("name", ["lstm_tiny", "lstm_ragged", "lstm1_tiny", "lstm1_drop"])
 def test_adam_trajectory_matches_golden(golden_dir, name):
     z, model = load_case(golden_dir, name)
     mom = {n: np.zeros_like(model.p[n]) for n in orc.PARAM_NAMES}
     var = {n: np.zeros_like(model.p[n]) for n in orc.PARAM_NAMES}
     for t, ref_loss in enumerate(z["adam_losses"], start=1):
-        val, g = orc.loss(model, z["feats"], z["tokens"], norm_B=int(z["norm_B"]), want_grad=True)
+        val, g = orc.loss(model, z["feats"], z["tokens"], norm_B=int(z["norm_B"]), mask1=z["mask1"] if "mask1" in z else None,
+                          mask2=z["mask2"] if "mask2" in z else None, want_grad=True)
         assert abs(val - ref_loss) <= 2e-6 * abs(ref_loss)
         for n in orc.PARAM_NAMES:
             orc.adam(model.p[n], g.p[n], mom[n], var[n], t)
@@ -50,7 +55,7 @@ def test_adam_trajectory_matches_golden(golden_dir, name):
         np.testing.assert_allclose(model.p[n], z["a_" + n], rtol=0, atol=2e-6, err_msg=n)
 
 
-@pytest.mark.parametrize("name", ["lstm_tiny", "lstm_ragged", "lstm_mid"])
+@pytest.mark.parametrize("name", ["lstm_tiny", "lstm_ragged", "lstm_mid", "lstm1_tiny", "lstm1_mid"])
 def test_beam_search_matches_golden(golden_dir, name):
     z, model = load_case(golden_dir, name)
     K, nword = int(z["beam_K"]), int(z["beam_nword"])
