@@ -224,7 +224,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": pmc_traffic(a.dtype, B),
                          "kernel": "conv64_kernel (conv1_1+conv1_2 fused, conv2_1) + gemm8p_kernel<*,CONV3,*> (conv2_2..conv5_3): 12 launches/step"
-                                   if a.dtype == "bf16" else "gemm_nt_kernel<float,*,CONV3> (conv1_2..conv5_3)",
+                                   if a.dtype == "bf16" else "gemm_glds_kernel<float,*,CONV3,*> v_mfma_f32_32x32x2_f32 (conv1_2..conv5_3)",
                          "avg_launch_ms": 1e3 * avg_launch_s, "flops_per_launch": flops_per_launch},
         }
         if world == 1 and not a.no_cpu_baseline:

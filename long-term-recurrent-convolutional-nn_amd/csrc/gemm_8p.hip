@@ -648,7 +648,7 @@ static bool gemm_8p_f8_ok(const GemmArgs &g) {  // e4m3 3x3 convolution with an 
 int gemm_8p_config(const GemmArgs &g, int64_t *blocks) {
     if (g.dtype == GEMM_T_F8) {
         if (!gemm_8p_f8_ok(g)) return -1;
-    } else if (!gemm_glds_eligible(g)) {
+    } else if (g.dtype != GEMM_T_BF16 || !gemm_glds_eligible(g)) {
         return -1;
     }
     {   // 32-bit byte offsets inside the kernel (buffer descriptors / lane offsets): operands must stay below 4 GiB - margin

@@ -29,8 +29,14 @@ __device__ __forceinline__ uint4 lds_read16(unsigned addr) {
     return r;
 }
 
-template <int WM, int WN, int TM, int TN, int AMODE, int NBUF>
+// T = bf16_t: v_mfma_f32_32x32x16_bf16 on 64-element K-steps.  T = float (the exact-fp32 VGG path, BASELINE configs[1]):
+// the same staging / ring / swizzle on 32-element K-steps (still 128-byte rows), v_mfma_f32_32x32x2_f32 -- a lane's 16-byte
+// fragment feeds four MFMAs (component c of A with component c of B; lane half hh = k index of the instruction), f32 output.
+template <typename T, int WM, int WN, int TM, int TN, int AMODE, int NBUF>
 __global__ __launch_bounds__(WM *WN * 64) void gemm_glds_kernel(const GemmArgs g) {
+    constexpr bool F32 = sizeof(T) == 4;
+    constexpr int KE = 128 / (int)sizeof(T);  // elements per K-step (one 128-byte LDS row)
+    constexpr int CE = 16 / (int)sizeof(T);   // elements per 16-byte chunk
     constexpr int NW = WM * WN;  // waves per workgroup (4 or 8); each wave stages 32 A rows, so BM = 32 NW
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     static_assert(BM == NW * 32 && (NW == 8 || NW == 4), "each wave stages 32 rows of A");
@@ -56,11 +62,11 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_glds_kernel(const GemmArgs g
     const int nt = bid % tiles_n, mt = bid / tiles_n;
     const int m0 = mt * BM, n0 = nt * BN;
 
-    const bf16_t *Ab = reinterpret_cast<const bf16_t *>(g.A);
-    const bf16_t *Bb = reinterpret_cast<const bf16_t *>(g.B);
-    const bf16_t *Zp = reinterpret_cast<const bf16_t *>(g.zero_page) + (lane & 7) * 8;
+    const T *Ab = reinterpret_cast<const T *>(g.A);
+    const T *Bb = reinterpret_cast<const T *>(g.B);
+    const T *Zp = reinterpret_cast<const T *>(g.zero_page) + (lane & 7) * CE;
 
-    const int kpt = (AMODE == GEMM_A_CONV3) ? g.Cin / 64 : g.K / 64;
+    const int kpt = (AMODE == GEMM_A_CONV3) ? g.Cin / KE : g.K / KE;
     const int KT_all = (AMODE == GEMM_A_CONV3) ? 9 * kpt : kpt;
     // split-K: blockIdx.y owns K-steps [kbeg, kbeg + KT); partial sums are combined by f32 atomics in the epilogue
     const int kbeg = (int)((int64_t)KT_all * blockIdx.y / gridDim.y);
@@ -80,7 +86,7 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_glds_kernel(const GemmArgs g
         if (m < M) {
             if (AMODE == GEMM_A_CONV3) {
                 const PixDecode p = decode_pixel(m, g.H, g.W);
-                a_off[q] = ((p.n * g.H + p.y) * g.W + p.x) * g.Cin + src_chunk * 8;
+                a_off[q] = ((p.n * g.H + p.y) * g.W + p.x) * g.Cin + src_chunk * CE;
                 unsigned mk = 0;
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
@@ -89,7 +95,7 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_glds_kernel(const GemmArgs g
                 }
                 a_mask[q] = mk;
             } else {
-                a_off[q] = m * (int)g.lda + src_chunk * 8;
+                a_off[q] = m * (int)g.lda + src_chunk * CE;
                 a_mask[q] = 1;
             }
         }
@@ -103,7 +109,7 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_glds_kernel(const GemmArgs g
         const int n = n0 + row;
         const int src_chunk = (lane & 7) ^ ((row >> 1) & 7);
         b_ok[i] = n < N;
-        b_off[i] = b_ok[i] ? n * (int)g.ldb + src_chunk * 8 : 0;
+        b_off[i] = b_ok[i] ? n * (int)g.ldb + src_chunk * CE : 0;
     }
 
     // One DMA piece (1 KiB = 8 rows x 128 B) of the K-step `kt` tile into ring slot `buf`: p < 4 -> A piece p of this
@@ -120,11 +126,11 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_glds_kernel(const GemmArgs g
             const int slice = kt / 9;
             k.tap = kt - 9 * slice;
             const int kh = k.tap / 3, kw = k.tap - 3 * kh;
-            k.koff = ((kh - 1) * g.W + (kw - 1)) * g.Cin + slice * 64;
-            k.kb = k.tap * g.Cin + slice * 64;
+            k.koff = ((kh - 1) * g.W + (kw - 1)) * g.Cin + slice * KE;
+            k.kb = k.tap * g.Cin + slice * KE;
         } else {
             k.tap = 0;
-            k.koff = kt * 64;
+            k.koff = kt * KE;
             k.kb = k.koff;
         }
         return k;
@@ -134,11 +140,11 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_glds_kernel(const GemmArgs g
         unsigned char *Bs = As + A_BYTES;
         if (p < 4) {
             const bool ok = live && ((a_mask[p] >> k.tap) & 1u);
-            const bf16_t *src = ok ? Ab + (a_off[p] + k.koff) : Zp;
+            const T *src = ok ? Ab + (a_off[p] + k.koff) : Zp;
             __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(As + (wave * 32 + p * 8) * 128), 16, 0, 0);
         } else {
             const int i = p - 4;
-            const bf16_t *src = (live && b_ok[i]) ? Bb + (b_off[i] + k.kb) : Zp;
+            const T *src = (live && b_ok[i]) ? Bb + (b_off[i] + k.kb) : Zp;
             __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(Bs + (wave + NW * i) * 8 * 128), 16, 0, 0);
         }
     };
@@ -204,9 +210,18 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_glds_kernel(const GemmArgs g
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int n = 0; n < TN; ++n)
-                    acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i & 1][j]),
-                                                                        __builtin_bit_cast(bf16x8, bfr[n][j]), acc[i][n], 0, 0, 0);
+                for (int n = 0; n < TN; ++n) {
+                    if constexpr (F32) {
+                        const uint4 &a4 = af[i & 1][j], &b4 = bfr[n][j];
+                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a4.x), __uint_as_float(b4.x), acc[i][n], 0, 0, 0);
+                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a4.y), __uint_as_float(b4.y), acc[i][n], 0, 0, 0);
+                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a4.z), __uint_as_float(b4.z), acc[i][n], 0, 0, 0);
+                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a4.w), __uint_as_float(b4.w), acc[i][n], 0, 0, 0);
+                    } else {
+                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i & 1][j]),
+                                                                            __builtin_bit_cast(bf16x8, bfr[n][j]), acc[i][n], 0, 0, 0);
+                    }
+                }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -216,8 +231,9 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_glds_kernel(const GemmArgs g
     // free now) -> whole rows written with 16 B per lane (one 2*BN-byte row segment per BN/8 lanes).  The direct
     // per-lane 2-byte stores of epilogue B cost the un-pooled convolution layers 15-45 % (profiles/r01 conv_bench).
     const int hh = lane >> 5;
-    const bool staged = !g.c_f32 && !g.beta && gridDim.y == 1 && (g.ldc % 8) == 0 && ((uintptr_t)g.C & 15) == 0 &&
+    const bool staged = !F32 && !g.c_f32 && !g.beta && gridDim.y == 1 && (g.ldc % 8) == 0 && ((uintptr_t)g.C & 15) == 0 &&
                         (n0 + BN <= N || (N % 8) == 0);
+    const bool c_f32 = F32 || g.c_f32;  // T = float: the output is float whether or not the caller says so
     if (staged) {
         constexpr int CSTR = BN * 2;  // bytes per staged row
         __builtin_amdgcn_s_barrier();  // every wave is done reading the last K-step (and no DMA is in flight)
@@ -294,7 +310,7 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_glds_kernel(const GemmArgs g
                                     fmaxf(acc[i][n][4 * q + 2], acc[i][n][4 * q + 3])) + bias;
                     if (g.relu) v = fmaxf(v, 0.0f);
                     const int64_t off = (int64_t)(row >> 2) * g.ldc + col;
-                    if (g.c_f32)
+                    if (c_f32)
                         reinterpret_cast<float *>(g.C)[off] = v;
                     else
                         reinterpret_cast<bf16_t *>(g.C)[off] = (bf16_t)v;
@@ -318,7 +334,7 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_glds_kernel(const GemmArgs g
                     float v = acc[i][n][4 * q + s] + bias;
                     if (gridDim.y > 1) {  // split-K (launcher guarantees c_f32, PLAIN, no relu, C pre-zeroed unless beta)
                         atomicAdd(reinterpret_cast<float *>(g.C) + off, v);
-                    } else if (g.c_f32) {
+                    } else if (c_f32) {
                         float *c = reinterpret_cast<float *>(g.C) + off;
                         if (g.beta) v += *c;
                         if (g.relu) v = fmaxf(v, 0.0f);
@@ -335,12 +351,12 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_glds_kernel(const GemmArgs g
     }
 }
 
-template <int WM, int WN, int TM, int TN, int AMODE, int NBUF> hipError_t launch_one(hipStream_t s, const GemmArgs &g, int splitk) {
+template <typename T, int WM, int WN, int TM, int TN, int AMODE, int NBUF> hipError_t launch_one(hipStream_t s, const GemmArgs &g, int splitk) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int lds = NBUF * (BM + BN) * 128;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static LdsAttrMask attr_done{0};
-    auto kern = gemm_glds_kernel<WM, WN, TM, TN, AMODE, NBUF>;
+    auto kern = gemm_glds_kernel<T, WM, WN, TM, TN, AMODE, NBUF>;
     if (hipError_t e = set_max_lds(reinterpret_cast<const void *>(kern), lds, attr_done); e != hipSuccess) return e;
     const int64_t blocks = (int64_t)cdiv(g.M, BM) * cdiv(g.N, BN);
     if (blocks <= 0 || blocks > 0x7FFFFFFF) return hipErrorInvalidValue;
@@ -379,6 +395,7 @@ int choose_cfg(const GemmArgs &g, int64_t *blocks_out) {
 int choose_splitk(const GemmArgs &g, int64_t blocks) {
     if (!g.c_f32 || g.out_mode != GEMM_OUT_PLAIN || g.relu || g.a_mode != GEMM_A_PLAIN) return 1;
     if (!g.beta && g.ldc != g.N) return 1;
+    if (g.dtype != GEMM_T_BF16) return 1;
     const int kt = g.K / 64;
     int s = (int)(256 / (blocks > 0 ? blocks : 1));
     if (s > kt / 4) s = kt / 4;
@@ -386,7 +403,7 @@ int choose_splitk(const GemmArgs &g, int64_t blocks) {
     return s < 2 ? 1 : s;
 }
 
-template <int AMODE> hipError_t dispatch(hipStream_t s, const GemmArgs &g) {
+template <typename T, int AMODE> hipError_t dispatch(hipStream_t s, const GemmArgs &g) {
     int64_t blocks = 0;
     const int cfg = choose_cfg(g, &blocks);
     const int sk = (AMODE == GEMM_A_PLAIN) ? choose_splitk(g, blocks) : 1;
@@ -395,10 +412,10 @@ template <int AMODE> hipError_t dispatch(hipStream_t s, const GemmArgs &g) {
         if (e != hipSuccess) return e;
     }
     switch (cfg) {
-        case 0: return launch_one<2, 4, 4, 2, AMODE, 2>(s, g, sk);  // 256 x 256, 2 x 64 KiB
-        case 1: return launch_one<4, 2, 2, 2, AMODE, 3>(s, g, sk);  // 256 x 128, 3 x 48 KiB
-        case 2: return launch_one<4, 2, 2, 1, AMODE, 2>(s, g, sk);  // 256 x 64,  2 x 40 KiB (two workgroups per CU)
-        case 3: return launch_one<2, 2, 2, 1, AMODE, 3>(s, g, sk);  // 128 x 64 (4 waves), 3 x 24 KiB (two per CU)
+        case 0: return launch_one<T, 2, 4, 4, 2, AMODE, 2>(s, g, sk);  // 256 x 256, 2 x 64 KiB
+        case 1: return launch_one<T, 4, 2, 2, 2, AMODE, 3>(s, g, sk);  // 256 x 128, 3 x 48 KiB
+        case 2: return launch_one<T, 4, 2, 2, 1, AMODE, 2>(s, g, sk);  // 256 x 64,  2 x 40 KiB (two workgroups per CU)
+        case 3: return launch_one<T, 2, 2, 2, 1, AMODE, 3>(s, g, sk);  // 128 x 64 (4 waves), 3 x 24 KiB (two per CU)
         default: return hipErrorInvalidValue;
     }
 }
@@ -406,6 +423,14 @@ template <int AMODE> hipError_t dispatch(hipStream_t s, const GemmArgs &g) {
 }  // namespace
 
 bool gemm_glds_eligible(const GemmArgs &g) {
+    if (g.dtype == GEMM_T_F32) {  // exact-fp32 convolutions only (the f32 LSTM GEMMs stay on gemm_nt: the 1e-5 parity path)
+        if (g.a_mode != GEMM_A_CONV3 || !g.zero_page || g.M < 128 || g.beta) return false;
+        if (((uintptr_t)g.A & 15) || ((uintptr_t)g.B & 15) || (g.ldb % 4) || (int64_t)g.N * g.ldb >= (1ll << 31)) return false;
+        if (g.Cin % 32 || g.K != 9 * g.Cin || (g.H & 1) || (g.W & 1) || g.H <= 0 || g.W <= 0 || g.M % (g.H * g.W)) return false;
+        if ((int64_t)g.M * g.Cin >= (1ll << 31) || g.out_mode == GEMM_OUT_PLAIN) return false;
+        if (g.out_mode == GEMM_OUT_POOL && (g.M & 3)) return false;
+        return true;
+    }
     if (g.dtype != GEMM_T_BF16 || !g.zero_page || g.M < 128) return false;
     if (((uintptr_t)g.A & 15) || ((uintptr_t)g.B & 15) || (g.ldb % 8)) return false;
     if ((int64_t)g.N * g.ldb >= (1ll << 31)) return false;
@@ -426,7 +451,8 @@ hipError_t launch_gemm_glds(hipStream_t stream, const GemmArgs &g0) {
     GemmArgs g = g0;
     const char *dbg = getenv("LRCN_DBG");
     g.dbg = dbg ? atoi(dbg) : 0;
-    return g.a_mode == GEMM_A_CONV3 ? dispatch<GEMM_A_CONV3>(stream, g) : dispatch<GEMM_A_PLAIN>(stream, g);
+    if (g.dtype == GEMM_T_F32) return dispatch<float, GEMM_A_CONV3>(stream, g);
+    return g.a_mode == GEMM_A_CONV3 ? dispatch<bf16_t, GEMM_A_CONV3>(stream, g) : dispatch<bf16_t, GEMM_A_PLAIN>(stream, g);
 }
 
 int64_t gemm_glds_blocks(const GemmArgs &g) {

@@ -154,7 +154,7 @@ def test_config2_shape_b32_vs_oracle_fp32_and_bf16():
     # generated dropout: the loss stays finite and differs from the no-dropout loss; same seed -> same loss
     l1 = L.loss(ctx16, param, L.to_jl(feats), tokens, pdrop=0.4, seed=3)
     l2 = L.loss(ctx16, param, L.to_jl(feats), tokens, pdrop=0.4, seed=3)
-    assert np.isfinite(l1) and l1 == l2 and abs(l1 - val16) > 1e-4
+    assert np.isfinite(l1) and l1 == l2 and l1 != val16 and abs(l1 - val16) < 0.5
     ctx16.close()
 
 
