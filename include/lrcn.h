@@ -171,10 +171,25 @@ int lrcn_vgg_load(lrcn_ctx *ctx, const float *const conv_w[13], const float *con
 /* convnet (lrcn.jl:733-748): x (224,224,3,N) preprocessed -> feats N x 4096 (pre-ReLU fc7). */
 int lrcn_vgg_forward(lrcn_ctx *ctx, const float *x, int N, float *feats);
 /* read_image_data's arithmetic (lrcn.jl:766-772) on decoded 224x224 RGB uint8 crops img[n][row][col][c]:
- * out (224,224,3,N), out(i,j,c,n) = pixel(row i, col j, c) - mean[c].  mean: host float[3]. */
+ * out (224,224,3,N), out(i,j,c,n) = pixel(row i, col j, c) - mean[c].  mean: host float[3] (NULL after lrcn_set_average_image). */
 int lrcn_preprocess_u8(lrcn_ctx *ctx, const uint8_t *img, int N, const float mean[3], float *out);
 /* Both of the above fused (no (224,224,3,N) float round trip): the training-path entry. */
 int lrcn_vgg_forward_u8(lrcn_ctx *ctx, const uint8_t *img, int N, const float mean[3], float *feats);
+/* The full VGG averageImage (lrcn.jl:113: vgg["meta"]["normalization"]["averageImage"], (224,224,3) column-major, device pointer;
+ * copied).  Once set, the *_u8 entry points subtract it instead of mean[3] (mean may then be NULL), exactly where the reference does:
+ * before its last H <-> W permutedims (lrcn.jl:770-771), i.e. pixel (row r, col q, c) meets averageImage(q, r, c).  NULL turns it off. */
+int lrcn_set_average_image(lrcn_ctx *ctx, const float *average_image);
+/* read_image_data's geometry on the device for a batch of decoded images of different sizes (lrcn.jl:755-765): resize so that
+ * the shorter side is 224 and the other div(side * 224, shorter), centre crop with div offsets, grey -> 3 channels (alpha dropped).
+ * src: device buffer with the N images back to back, image n at byte offsets[n], row-major [h][w][channels] uint8;
+ * offsets / heights / widths / channels (1, 3 or 4): HOST arrays.  out: device uint8 crops [N][224][224][3] = the input of
+ * lrcn_vgg_forward_u8 / lrcn_preprocess_u8.  Resampling is bilinear between pixel centres in exact integer arithmetic
+ * (round half up); Images.imresize's own kernel is not pinned by the reference. */
+int lrcn_resize_crop_u8(lrcn_ctx *ctx, const uint8_t *src, const int64_t *offsets, const int *heights, const int *widths,
+                        const int *channels, int N, uint8_t *out);
+/* feats (N x 4096 column-major, device) <- every row divided by its sum: generate's `input/sum(input)` (lrcn.jl:595-597) and
+ * what the reference's training features (`featsn`, lrcn.jl:121-123) hold. */
+int lrcn_normalize_features(lrcn_ctx *ctx, float *feats, int N);
 
 /* Parity probes for the VGG operators (lrcn.jl:724-728), reference layouts, any small size:
  * x (W,H,Cin,N) -> y (W,H,Cout,N) [or (W/2,H/2,Cout,N) with pool]; Cin, Cout multiples of 32. */

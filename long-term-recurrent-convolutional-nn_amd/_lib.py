@@ -75,6 +75,10 @@ SIGNATURES = {
     "lrcn_vgg_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "lrcn_preprocess_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_void_p]),
     "lrcn_vgg_forward_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_void_p]),
+    "lrcn_set_average_image": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "lrcn_resize_crop_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                      C.c_int, C.c_void_p]),
+    "lrcn_normalize_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "lrcn_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "lrcn_profile_get": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "lrcn_bench_conv": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),

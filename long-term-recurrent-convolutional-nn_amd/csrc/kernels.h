@@ -120,7 +120,13 @@ void k_repack_conv_w(hipStream_t st, int dtype, const float *w, int Cin, int Cou
 // conv1_1 weight -> [64][ld] T with k = tap*3 + c (27 real, rest zero)
 void k_repack_conv11_w(hipStream_t st, int dtype, const float *w, int Cout, void *out, int64_t ld);
 // out[i] = (bf16)(img[i] - mean[i % 3]) over n = N*S*S*3 bytes: the crop, mean-subtracted, in its own layout (input of conv64 FUSE)
-void k_img_u8_to_bf16(hipStream_t st, const uint8_t *img, int64_t n, float m0, float m1, float m2, void *out);
+// avg != NULL: subtract the full averageImage (S,S,3) column-major, avg(col, row, c) from pixel (row, col, c) (lrcn.jl:770-771), instead
+void k_img_u8_to_bf16(hipStream_t st, const uint8_t *img, int64_t n, float m0, float m1, float m2, const float *avg, int S, void *out);
+// batched resize + centre crop + grey -> RGB of variable-size decoded uint8 images (lrcn.jl:755-765): meta = device array of
+// {int64 byte offset into src, int h, w, channels, pad} per image; out = uint8 crops [N][S][S][3]
+void k_resize_crop_u8(hipStream_t st, const uint8_t *src, const void *meta, int N, int S, uint8_t *out);
+// feats (N x F column-major f32): every row divided by its sum (lrcn.jl:595-597)
+void k_normalize_rows(hipStream_t st, float *feats, int N, int F);
 // conv1_1 weight -> [64][32] bf16 in the K order of the fused conv1_1+conv1_2 kernel (conv64.hip, FUSE)
 void k_repack_conv11_w_fused(hipStream_t st, const float *w, void *out);
 // fc6 weight (4096 x 25088 column-major, k_ref = x + 7y + 49c) -> [4096][25088] T with k = (y*7+x)*512 + c
@@ -132,7 +138,7 @@ void k_im2col11_u8(hipStream_t st, int dtype, const uint8_t *img, int N, int S, 
 // same from the preprocessed float tensor x (S,S,3,N) column-major
 void k_im2col11_f32(hipStream_t st, int dtype, const float *x, int N, int S, void *out, int64_t ld);
 // out(i,j,c,n) = img[n][i][j][c] - mean[c]   (lrcn.jl:766-772)
-void k_preprocess_u8(hipStream_t st, const uint8_t *img, int N, int S, float m0, float m1, float m2, float *out);
+void k_preprocess_u8(hipStream_t st, const uint8_t *img, int N, int S, float m0, float m1, float m2, const float *avg, float *out);
 // reference (W,H,C,N) column-major f32 <-> internal NHWC [n][y][x][C_ld] T   (x = dim 1, y = dim 2)
 void k_ref_to_nhwc(hipStream_t st, int dtype, const float *x, int W, int H, int C, int N, void *out, int C_ld);
 void k_nhwc_to_ref(hipStream_t st, int dtype, const void *in, int W, int H, int C, int N, int C_ld, float *out);

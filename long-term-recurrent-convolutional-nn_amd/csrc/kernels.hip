@@ -561,11 +561,23 @@ template <typename T> __global__ void repack_conv11_w_kernel(const float *w, int
     out[i] = from_f32<T>(v);
 }
 // out[i] = (bf16)(img[i] - mean[i % 3])  : read_image_data's arithmetic (lrcn.jl:770) in the crop's own layout [n][row][col][3]
-__global__ void img_u8_to_bf16_kernel(const uint8_t *img, int64_t n, float m0, float m1, float m2, bf16_t *out) {
+// avg != NULL: the full averageImage (S,S,3) column-major instead of the three channel means; the reference subtracts it BEFORE
+// its last H <-> W permutedims (lrcn.jl:770-771), so pixel (row r, col q, c) meets avg(q, r, c) = avg[q + S r + S^2 c]
+__device__ __forceinline__ float avg_at(const float *avg, int64_t i, int S) {
+    const int c = (int)(i % 3);
+    const int64_t px = i / 3;
+    const int q = (int)(px % S), r = (int)((px / S) % S);
+    return avg[q + (int64_t)S * r + (int64_t)S * S * c];
+}
+__global__ void img_u8_to_bf16_kernel(const uint8_t *img, int64_t n, float m0, float m1, float m2, const float *avg, int S, bf16_t *out) {
     // 12 bytes (4 pixels) per thread: channel phase is the same for every thread
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t i0 = t * 12;
     if (i0 >= n) return;
+    if (avg) {
+        for (int64_t i = i0; i < n && i < i0 + 12; ++i) out[i] = (bf16_t)((float)img[i] - avg_at(avg, i, S));
+        return;
+    }
     if (i0 + 12 <= n) {
         const uint32_t *p = reinterpret_cast<const uint32_t *>(img + i0);
         const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
@@ -642,14 +654,68 @@ __global__ void im2col11_kernel(const void *src, int N, int S, float m0, float m
     for (int c = 0; c < 3; ++c) row[tap * 3 + c] = from_f32<T>(v[c]);
 }
 
-__global__ void preprocess_u8_kernel(const uint8_t *img, int N, int S, float m0, float m1, float m2, float *out) {
+__global__ void preprocess_u8_kernel(const uint8_t *img, int N, int S, float m0, float m1, float m2, const float *avg, float *out) {
     const int64_t total = (int64_t)N * 3 * S * S;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int ii = (int)(i % S), j = (int)((i / S) % S), c = (int)((i / ((int64_t)S * S)) % 3);
         const int n = (int)(i / (3ll * S * S));
-        const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2);
+        const float mean = avg ? avg[j + (int64_t)S * ii + (int64_t)S * S * c] : (c == 0 ? m0 : (c == 1 ? m1 : m2));
         out[i] = (float)img[(((int64_t)n * S + ii) * S + j) * 3 + c] - mean;
     }
+}
+
+// read_image_data's geometry (lrcn.jl:755-765) for a batch of decoded images of different sizes: resize so that the shorter side is
+// 224 and the other div(side * 224, shorter) (:756), centre crop at div offsets (:758-760), grey -> three channels (:762-764).
+// Resampling: bilinear between pixel CENTRES (output (R, Q) of the nh x nw resized image samples the source at
+// ((2R+1) h / (2 nh) - 1/2, (2Q+1) w / (2 nw) - 1/2), clamped to the image), computed in exact integer arithmetic with
+// round-half-up, so that a host restatement reproduces every byte (Images.imresize's own kernel is unpinned).
+struct ImgMeta {
+    int64_t off;
+    int h, w, ch, pad;
+};
+__global__ void resize_crop_u8_kernel(const uint8_t *src, const ImgMeta *meta, int N, int S, uint8_t *out) {
+    const int64_t total = (int64_t)N * S * S;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % S), r = (int)((i / S) % S), n = (int)(i / ((int64_t)S * S));
+        const ImgMeta m = meta[n];
+        const int64_t h = m.h, w = m.w, sm = h < w ? h : w;
+        const int64_t nh = h * S / sm, nw = w * S / sm;          // :756  div(size * 224, minimum(size))
+        const int64_t R = r + (nh - S) / 2, Q = q + (nw - S) / 2;  // :758-760
+        int64_t ny = (2 * R + 1) * h - nh, nx = (2 * Q + 1) * w - nw;  // 2 nh * sy, 2 nw * sx
+        if (ny < 0) ny = 0;
+        if (nx < 0) nx = 0;
+        const int64_t y0 = ny / (2 * nh), fy = ny - y0 * 2 * nh, x0 = nx / (2 * nw), fx = nx - x0 * 2 * nw;
+        const int64_t y1 = y0 + 1 < h ? y0 + 1 : h - 1, x1 = x0 + 1 < w ? x0 + 1 : w - 1;
+        const uint8_t *im = src + m.off;
+        const int ch = m.ch;
+        uint8_t v[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int cs = ch >= 3 ? c : 0;
+            const int64_t p00 = im[(y0 * w + x0) * ch + cs], p01 = im[(y0 * w + x1) * ch + cs], p10 = im[(y1 * w + x0) * ch + cs],
+                          p11 = im[(y1 * w + x1) * ch + cs];
+            const int64_t top = (2 * nw - fx) * p00 + fx * p01, bot = (2 * nw - fx) * p10 + fx * p11;
+            v[c] = (uint8_t)(((2 * nh - fy) * top + fy * bot + 2 * nh * nw) / (4 * nh * nw));
+        }
+        uint8_t *o = out + i * 3;
+        o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
+    }
+}
+
+// feats(n, :) /= sum(feats(n, :))  (generate's input/sum(input), lrcn.jl:595-597; what the reference's `featsn` files hold).
+// feats: N x F column-major f32; one workgroup per row.
+__global__ void normalize_rows_kernel(float *feats, int N, int F) {
+    __shared__ float sh[8];
+    const int n = blockIdx.x;
+    float s = 0.0f;
+    for (int j = threadIdx.x; j < F; j += blockDim.x) s += feats[n + (int64_t)N * j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    float tot = 0.0f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += sh[w];
+    for (int j = threadIdx.x; j < F; j += blockDim.x) feats[n + (int64_t)N * j] /= tot;
 }
 
 template <typename T> __global__ void ref_to_nhwc_kernel(const float *x, int W, int H, int C, int N, T *out, int C_ld) {
@@ -1086,9 +1152,16 @@ void k_repack_conv11_w(hipStream_t st, int dtype, const float *w, int Cout, void
     DISPATCH_T(dtype, hipLaunchKernelGGL(repack_conv11_w_kernel<T>, dim3(cdiv(Cout * ld, 256)), dim3(256), 0, st, w, Cout,
                                          (T *)out, ld));
 }
-void k_img_u8_to_bf16(hipStream_t st, const uint8_t *img, int64_t n, float m0, float m1, float m2, void *out) {
+void k_img_u8_to_bf16(hipStream_t st, const uint8_t *img, int64_t n, float m0, float m1, float m2, const float *avg, int S, void *out) {
     const int64_t threads = (n + 11) / 12;
-    hipLaunchKernelGGL(img_u8_to_bf16_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, img, n, m0, m1, m2, (bf16_t *)out);
+    hipLaunchKernelGGL(img_u8_to_bf16_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, img, n, m0, m1, m2, avg, S,
+                       (bf16_t *)out);
+}
+void k_resize_crop_u8(hipStream_t st, const uint8_t *src, const void *meta, int N, int S, uint8_t *out) {
+    hipLaunchKernelGGL(resize_crop_u8_kernel, dim3(grid1d((int64_t)N * S * S)), dim3(256), 0, st, src, (const ImgMeta *)meta, N, S, out);
+}
+void k_normalize_rows(hipStream_t st, float *feats, int N, int F) {
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3(N), dim3(256), 0, st, feats, N, F);
 }
 void k_repack_conv11_w_fused(hipStream_t st, const float *w, void *out) {
     hipLaunchKernelGGL(repack_conv11_w_fused_kernel, dim3(8), dim3(256), 0, st, w, (bf16_t *)out);
@@ -1107,8 +1180,8 @@ void k_im2col11_f32(hipStream_t st, int dtype, const float *x, int N, int S, voi
     DISPATCH_T(dtype, hipLaunchKernelGGL((im2col11_kernel<T, false>), dim3(cdiv(n, 256)), dim3(256), 0, st, (const void *)x, N,
                                          S, 0.f, 0.f, 0.f, (T *)out, ld));
 }
-void k_preprocess_u8(hipStream_t st, const uint8_t *img, int N, int S, float m0, float m1, float m2, float *out) {
-    hipLaunchKernelGGL(preprocess_u8_kernel, dim3(grid1d((int64_t)N * 3 * S * S)), dim3(256), 0, st, img, N, S, m0, m1, m2,
+void k_preprocess_u8(hipStream_t st, const uint8_t *img, int N, int S, float m0, float m1, float m2, const float *avg, float *out) {
+    hipLaunchKernelGGL(preprocess_u8_kernel, dim3(grid1d((int64_t)N * 3 * S * S)), dim3(256), 0, st, img, N, S, m0, m1, m2, avg,
                        out);
 }
 void k_ref_to_nhwc(hipStream_t st, int dtype, const float *x, int W, int H, int C, int N, void *out, int C_ld) {

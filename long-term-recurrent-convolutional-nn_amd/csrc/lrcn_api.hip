@@ -103,6 +103,12 @@ struct lrcn_ctx {
     double prof_ms = 0.0;
     int64_t prof_launches = 0;
     std::string vgg_routes;  // kernel family per layer of the most recent VGG forward (lrcn_debug_route)
+    // image front end: the full averageImage (lrcn_set_average_image), per-batch image descriptors, float scratch of the unfused path
+    float *avg_img = nullptr;
+    bool avg_on = false;
+    void *img_meta = nullptr;
+    int img_meta_cap = 0;
+    float *pre_f32 = nullptr;
 };
 
 #define FAIL(ctx, code, ...)                          \
@@ -1200,6 +1206,15 @@ int vgg_body(lrcn_ctx *c, int N, const void *src, bool src_u8, const float *mean
     const float m0 = mean ? mean[0] : 0.f, m1 = mean ? mean[1] : 0.f, m2 = mean ? mean[2] : 0.f;
     const char *kf = getenv("LRCN_FUSE11");  // LRCN_FUSE11=0: conv1_1 and conv1_2 as two launches
     const bool fuse11 = vdt == GEMM_T_BF16 && src_u8 && c->conv[0].w_fused && conv64_enabled() && !(kf && kf[0] == '0');
+    const float *avg = (src_u8 && c->avg_on) ? c->avg_img : nullptr;
+    if (avg && !fuse11) {
+        // full averageImage outside the fused path: read_image_data's arithmetic as its own pass into a float tensor (lrcn.jl:770-771),
+        // then the float-input route
+        if (!c->pre_f32) DALLOC(c, c->pre_f32, sizeof(float) * (size_t)c->cfg.max_images * 224 * 224 * 3);
+        k_preprocess_u8(c->stream, reinterpret_cast<const uint8_t *>(src), N, 224, 0.f, 0.f, 0.f, avg, c->pre_f32);
+        src = c->pre_f32;
+        src_u8 = false;
+    }
     c->vgg_routes.clear();
     auto note = [&](const char *r) {
         if (!c->vgg_routes.empty()) c->vgg_routes += ',';
@@ -1207,7 +1222,7 @@ int vgg_body(lrcn_ctx *c, int N, const void *src, bool src_u8, const float *mean
     };
     if (fuse11) {
         // read_image_data's arithmetic as an elementwise pass (38 MB -> 77 MB at N = 256); conv1_1 itself runs inside conv1_2's launch
-        k_img_u8_to_bf16(c->stream, reinterpret_cast<const uint8_t *>(src), (int64_t)N * 224 * 224 * 3, m0, m1, m2, c->img16);
+        k_img_u8_to_bf16(c->stream, reinterpret_cast<const uint8_t *>(src), (int64_t)N * 224 * 224 * 3, m0, m1, m2, avg, 224, c->img16);
     } else if (vdt == GEMM_T_BF16) {
         // conv1_1 fused with the preprocessing arithmetic (conv11.hip): HBM-bound, no im2col in memory
         k_conv11_fused(c->stream, src_u8 ? 1 : 0, src, N, 224, m0, m1, m2, c->conv[0].w, c->conv[0].b, c->actA);
@@ -1451,7 +1466,7 @@ int lrcn_vgg_forward(lrcn_ctx *c, const float *x, int N, float *feats) {
 
 int lrcn_vgg_forward_u8(lrcn_ctx *c, const uint8_t *img, int N, const float mean[3], float *feats) {
     DeviceGuard dg(c);
-    if (!c || !img || !feats || !mean) return LRCN_EINVAL;
+    if (!c || !img || !feats || (!mean && !c->avg_on)) return LRCN_EINVAL;
     int r = vgg_check(c, N);
     if (r) return r;
     r = vgg_body(c, N, img, true, mean);
@@ -1463,9 +1478,62 @@ int lrcn_vgg_forward_u8(lrcn_ctx *c, const uint8_t *img, int N, const float mean
 
 int lrcn_preprocess_u8(lrcn_ctx *c, const uint8_t *img, int N, const float mean[3], float *out) {
     DeviceGuard dg(c);
-    if (!c || !img || !out || !mean || N < 1) return LRCN_EINVAL;
-    k_preprocess_u8(c->stream, img, N, 224, mean[0], mean[1], mean[2], out);
+    if (!c || !img || !out || (!mean && !c->avg_on) || N < 1) return LRCN_EINVAL;
+    k_preprocess_u8(c->stream, img, N, 224, mean ? mean[0] : 0.f, mean ? mean[1] : 0.f, mean ? mean[2] : 0.f, c->avg_on ? c->avg_img : nullptr, out);
     KCHK(c, "preprocess_u8");
+    return LRCN_OK;
+}
+
+int lrcn_set_average_image(lrcn_ctx *c, const float *avg) {
+    DeviceGuard dg(c);
+    if (!c) return LRCN_EINVAL;
+    if (!avg) {
+        c->avg_on = false;
+        return LRCN_OK;
+    }
+    if (!c->avg_img) DALLOC(c, c->avg_img, sizeof(float) * 224 * 224 * 3);
+    HIPCHK(c, hipMemcpyAsync(c->avg_img, avg, sizeof(float) * 224 * 224 * 3, hipMemcpyDeviceToDevice, c->stream));
+    c->avg_on = true;
+    return LRCN_OK;
+}
+
+int lrcn_resize_crop_u8(lrcn_ctx *c, const uint8_t *src, const int64_t *offsets, const int *heights, const int *widths, const int *channels,
+                        int N, uint8_t *out) {
+    DeviceGuard dg(c);
+    if (!c || !src || !offsets || !heights || !widths || !channels || !out) return LRCN_EINVAL;
+    if (N < 1 || N > 65536) FAIL(c, LRCN_EINVAL, "N=%d outside [1,65536]", N);
+    struct Meta {
+        int64_t off;
+        int h, w, ch, pad;
+    };
+    std::vector<Meta> m(N);
+    for (int n = 0; n < N; ++n) {
+        if (heights[n] < 1 || widths[n] < 1 || heights[n] > 32768 || widths[n] > 32768 || (channels[n] != 1 && channels[n] != 3 && channels[n] != 4) ||
+            offsets[n] < 0)
+            FAIL(c, LRCN_EINVAL, "image %d: %d x %d x %d at offset %lld (need 1..32768 pixels per side, 1, 3 or 4 channels)", n, heights[n],
+                 widths[n], channels[n], (long long)offsets[n]);
+        m[n] = Meta{offsets[n], heights[n], widths[n], channels[n], 0};
+    }
+    if (N > c->img_meta_cap) {
+        void *p = nullptr;
+        const int cap = N < 256 ? 256 : N;
+        if (hipMalloc(&p, sizeof(Meta) * (size_t)cap) != hipSuccess) FAIL(c, LRCN_ENOMEM, "image descriptors");
+        c->allocs.push_back(p);  // the old (smaller) buffer stays owned by the context until lrcn_destroy
+        c->img_meta = p;
+        c->img_meta_cap = cap;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->img_meta, m.data(), sizeof(Meta) * (size_t)N, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // m goes out of scope
+    k_resize_crop_u8(c->stream, src, c->img_meta, N, 224, out);
+    KCHK(c, "resize_crop_u8");
+    return LRCN_OK;
+}
+
+int lrcn_normalize_features(lrcn_ctx *c, float *feats, int N) {
+    DeviceGuard dg(c);
+    if (!c || !feats || N < 1) return LRCN_EINVAL;
+    k_normalize_rows(c->stream, feats, N, LRCN_CNNOUT);
+    KCHK(c, "normalize_features");
     return LRCN_OK;
 }
 
@@ -1538,7 +1606,7 @@ int lrcn_conv3x3(lrcn_ctx *c, const float *x, int W, int H, int Cin, int N, cons
 
 int lrcn_vgg_calibrate(lrcn_ctx *c, const uint8_t *img, int N, const float mean[3], float margin) {
     DeviceGuard dg(c);
-    if (!c || !img || !mean) return LRCN_EINVAL;
+    if (!c || !img || (!mean && !c->avg_on)) return LRCN_EINVAL;
     if (!c->vgg_fp8) FAIL(c, LRCN_ESTATE, "lrcn_vgg_calibrate needs a context created with vgg_dtype = LRCN_FP8");
     if (!(margin >= 1.0f) || margin > 16.0f) FAIL(c, LRCN_EINVAL, "margin=%g outside [1,16]", margin);
     int r = vgg_check(c, N);

@@ -86,7 +86,8 @@ def karpathy_features(dataset_json_path, vgg_feats_mat_path):
 
 def load_vgg_mat(path, last_layer="fc7"):
     """MatConvNet model -> (conv_w[13] (3,3,Cin,Cout), conv_b[13], (fc6_w (4096,25088), fc6_b), (fc7_w (4096,4096), fc7_b),
-    average RGB).  Follows get_params_cnn (lrcn.jl:697-721): conv weights as stored, fc weight = transpose(mat(w)), i.e.
+    average RGB).  `load_vgg_mat.average_image` holds, after the call, the full (224,224,3) averageImage when the file stores
+    one (lrcn.jl:113 uses the array as it is; lrcn_set_average_image) and None when it stores only three channel means.  Follows get_params_cnn (lrcn.jl:697-721): conv weights as stored, fc weight = transpose(mat(w)), i.e.
     the (7,7,512,4096) array flattened column-major over (w,h,c) then transposed; stops after `last_layer` inclusive."""
     from scipy.io import loadmat
     m = loadmat(path, squeeze_me=False, struct_as_record=False)
@@ -108,14 +109,22 @@ def load_vgg_mat(path, last_layer="fc7"):
         if name.startswith(last_layer):
             break
     mean = None
+    load_vgg_mat.average_image = None
+    avg = None
     try:
-        meta = m["meta"][0, 0]
-        mean = np.asarray(meta.normalization[0, 0].averageImage, dtype=np.float32).reshape(-1)[:3]
+        avg = np.asarray(m["meta"][0, 0].normalization[0, 0].averageImage, dtype=np.float32)
     except Exception:  # older files keep it under "normalization"
         try:
-            mean = np.asarray(m["normalization"][0, 0].averageImage, dtype=np.float32).mean(axis=(0, 1))
+            avg = np.asarray(m["normalization"][0, 0].averageImage, dtype=np.float32)
         except Exception:
             pass
+    if avg is not None:
+        if avg.size == 3:
+            mean = avg.reshape(-1)
+        elif avg.ndim == 3 and avg.shape[2] == 3:
+            mean = avg.mean(axis=(0, 1))
+            if avg.shape[:2] == (224, 224):
+                load_vgg_mat.average_image = avg
     if len(conv_w) != 13 or len(fcs) != 2:
         raise ValueError("expected 13 conv + 2 fc weighted layers up to %s, found %d + %d" % (last_layer, len(conv_w), len(fcs)))
     return conv_w, conv_b, fcs[0], fcs[1], mean
@@ -124,7 +133,8 @@ def load_vgg_mat(path, last_layer="fc7"):
 def center_crop_224(img):
     """read_image_data's geometry (lrcn.jl:755-765) on a decoded image (PIL.Image or HxW[x3] uint8 array): resize so the
     shorter side is 224 with the other side div(side * 224, shorter), centre crop with div offsets, grey -> 3 channels.
-    -> uint8 [224][224][3] (row, col, channel).  Resampling is bilinear (Images.imresize's kernel is not pinned)."""
+    -> uint8 [224][224][3] (row, col, channel).  Resampling is PIL's bilinear (Images.imresize's kernel is not pinned).
+    Host-side utility only: the driver (tools/lrcn.py) crops on the GPU with lrcn_resize_crop_u8 (lrcn.resize_crop_u8)."""
     from PIL import Image
     if not isinstance(img, Image.Image):
         img = Image.fromarray(np.asarray(img))

@@ -351,13 +351,16 @@ def convnet(ctx, x):
     return feats
 
 
-def convnet_u8(ctx, img_u8, mean=VGG_MEAN, feats=None):
-    """Fused read_image_data arithmetic (lrcn.jl:766-772) + convnet on uint8 crops img[n][row][col][c]."""
+def convnet_u8(ctx, img_u8, mean=VGG_MEAN, feats=None, normalize=False):
+    """Fused read_image_data arithmetic (lrcn.jl:766-772) + convnet on uint8 crops img[n][row][col][c].  mean=None: the
+    averageImage registered with set_average_image.  normalize: divide each feature row by its sum (lrcn.jl:595-597)."""
     N = img_u8.shape[0]
     if feats is None:
         feats = jl_empty(N, CNNOUT)
-    m = (C.c_float * 3)(*mean)
+    m = (C.c_float * 3)(*mean) if mean is not None else None
     ctx._call("lrcn_vgg_forward_u8", C.c_void_p(img_u8.data_ptr()), N, m, _ptr(feats))
+    if normalize:
+        normalize_features(ctx, feats)
     return feats
 
 
@@ -365,9 +368,47 @@ def read_image_data_u8(ctx, img_u8, mean=VGG_MEAN):
     """read_image_data's arithmetic tail (lrcn.jl:766-772) -> (224,224,3,N) column-major float tensor."""
     N = img_u8.shape[0]
     out = jl_empty(224, 224, 3, N)
-    m = (C.c_float * 3)(*mean)
+    m = (C.c_float * 3)(*mean) if mean is not None else None
     ctx._call("lrcn_preprocess_u8", C.c_void_p(img_u8.data_ptr()), N, m, _ptr(out))
     return out
+
+
+def set_average_image(ctx, average_image):
+    """Register the VGG averageImage (lrcn.jl:113), a (224,224,3) array, or None to go back to per-channel means."""
+    if average_image is None:
+        ctx._call("lrcn_set_average_image", None)
+        return
+    a = to_jl(np.asarray(average_image, np.float32).reshape(224, 224, 3))
+    ctx._call("lrcn_set_average_image", _ptr(a))
+    ctx.sync()  # `a` may be freed on return
+
+
+def resize_crop_u8(ctx, images):
+    """read_image_data's geometry (lrcn.jl:755-765) on the GPU for a list of decoded images (uint8 arrays [h][w], [h][w][1],
+    [h][w][3] or [h][w][4]) of any sizes -> uint8 crops tensor [N][224][224][3] on the device (lrcn_resize_crop_u8)."""
+    arrs = [np.ascontiguousarray(np.asarray(im, dtype=np.uint8)) for im in images]
+    arrs = [a[:, :, None] if a.ndim == 2 else a for a in arrs]
+    N = len(arrs)
+    offs = np.zeros(N, np.int64)
+    pos = 0
+    for i, a in enumerate(arrs):
+        offs[i] = pos
+        pos += a.size
+    flat = torch.as_tensor(np.concatenate([a.reshape(-1) for a in arrs])).cuda()
+    hs = (C.c_int * N)(*[a.shape[0] for a in arrs])
+    ws = (C.c_int * N)(*[a.shape[1] for a in arrs])
+    cs = (C.c_int * N)(*[a.shape[2] for a in arrs])
+    out = torch.empty((N, 224, 224, 3), dtype=torch.uint8, device=flat.device)
+    ctx._call("lrcn_resize_crop_u8", C.c_void_p(flat.data_ptr()), offs.ctypes.data_as(C.POINTER(C.c_int64)), hs, ws, cs, N,
+              C.c_void_p(out.data_ptr()))
+    ctx.sync()  # `flat` may be freed on return
+    return out
+
+
+def normalize_features(ctx, feats):
+    """feats (N x 4096, column-major) <- rows divided by their sums, in place: generate's input/sum(input) (lrcn.jl:595-597)."""
+    ctx._call("lrcn_normalize_features", _ptr(feats), feats.shape[0])
+    return feats
 
 
 def conv3x3(ctx, x, w, b, relu=True, pool=False):
@@ -387,7 +428,7 @@ def vgg_set_wg_cap(ctx, cap):
 def vgg_calibrate(ctx, img_u8, mean=VGG_MEAN, margin=1.25):
     """vgg_dtype = LRCN_FP8 only: one bf16 pass over `img_u8` (uint8 crops [n][row][col][c]) that fixes the per-layer
     activation scales of the e4m3 layers (include/lrcn.h lrcn_vgg_calibrate).  No counterpart in the reference."""
-    m = (C.c_float * 3)(*mean)
+    m = (C.c_float * 3)(*mean) if mean is not None else None
     ctx._call("lrcn_vgg_calibrate", C.c_void_p(img_u8.data_ptr()), img_u8.shape[0], m, float(margin))
 
 

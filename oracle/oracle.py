@@ -301,5 +301,48 @@ def preprocess_u8(img, mean):
     return out
 
 
+def preprocess_u8_avg(img, average_image):
+    """read_image_data's arithmetic with the FULL averageImage (lrcn.jl:766-772), restated with numpy in the reference's own
+    order of operations: c1(col,row,ch) [:762-766] -> 255 e1 - averageImage [:770] -> permutedims [2,1,3,4] [:771].
+    img: uint8 [N][S][S][3]; average_image: (S,S,3).  Returns (S,S,3,N) F-order float32."""
+    img = np.asarray(img, np.uint8)
+    avg = np.asarray(average_image, np.float32)
+    outs = []
+    for n in range(img.shape[0]):
+        c1 = np.transpose(img[n].astype(np.float32), (1, 0, 2))   # channelview (3,rows,cols) permuted (3,2,1) -> (cols, rows, 3)
+        f1 = c1 - avg                                             # 255 * e1 .- averageImage  (e1 holds x/255)
+        outs.append(np.transpose(f1, (1, 0, 2)))                  # g1 = permutedims(f1, [2,1,3,4])
+    return np.asfortranarray(np.stack(outs, axis=3))
+
+
+def resize_crop_u8(images, S=224):
+    """NumPy restatement of read_image_data's geometry (lrcn.jl:755-765) with the resampling rule the HIP kernel states
+    (include/lrcn.h lrcn_resize_crop_u8): bilinear between pixel centres, exact integer arithmetic, round half up.
+    images: list of uint8 arrays [h][w] / [h][w][c], c in {1,3,4}.  Returns uint8 [N][S][S][3]."""
+    out = np.zeros((len(images), S, S, 3), np.uint8)
+    for n, im in enumerate(images):
+        im = np.asarray(im, np.uint8)
+        if im.ndim == 2:
+            im = im[:, :, None]
+        h, w, ch = im.shape
+        sm = min(h, w)
+        nh, nw = (h * S) // sm, (w * S) // sm                      # :756
+        R = np.arange(S, dtype=np.int64) + (nh - S) // 2           # :758-760
+        Q = np.arange(S, dtype=np.int64) + (nw - S) // 2
+        ny = np.maximum((2 * R + 1) * h - nh, 0)
+        nx = np.maximum((2 * Q + 1) * w - nw, 0)
+        y0, fy = ny // (2 * nh), ny % (2 * nh)
+        x0, fx = nx // (2 * nw), nx % (2 * nw)
+        y1, x1 = np.minimum(y0 + 1, h - 1), np.minimum(x0 + 1, w - 1)
+        src = im[:, :, :3].astype(np.int64) if ch >= 3 else np.repeat(im[:, :, :1].astype(np.int64), 3, axis=2)  # :762-764
+        p00, p01 = src[y0][:, x0], src[y0][:, x1]
+        p10, p11 = src[y1][:, x0], src[y1][:, x1]
+        FX, FY = fx[None, :, None], fy[:, None, None]
+        top = (2 * nw - FX) * p00 + FX * p01
+        bot = (2 * nw - FX) * p10 + FX * p11
+        out[n] = (((2 * nh - FY) * top + FY * bot + 2 * nh * nw) // (4 * nh * nw)).astype(np.uint8)
+    return out
+
+
 def num_threads():
     return lib().orc_num_threads()

@@ -1,5 +1,5 @@
 import csv,glob,sys
-f=glob.glob(sys.argv[1]+'/*/*kernel_stats.csv')[0]
+f=(glob.glob(sys.argv[1]+'/*/*kernel_stats.csv')+glob.glob(sys.argv[1]+'/*kernel_stats.csv'))[0]
 n=int(sys.argv[2])
 rows=list(csv.DictReader(open(f)))
 tot=sum(float(r['TotalDurationNs']) for r in rows)

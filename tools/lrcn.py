@@ -118,12 +118,27 @@ def main(argv=None):
     mean = L.VGG_MEAN
     if o.cnn:
         print("Reading", o.model)
-        cw, cb, fc6, fc7, m = fmt.load_vgg_mat(o.model)
-        if m is not None:
-            mean = tuple(float(v) for v in m)
-        L.vgg_load(ctx, [L.to_jl(w) for w in cw], [torch.as_tensor(b).cuda() for b in cb],
-                   (L.to_jl(fc6[0]), torch.as_tensor(fc6[1]).cuda()), (L.to_jl(fc7[0]), torch.as_tensor(fc7[1]).cuda()))
+        if o.model.startswith("synthetic"):  # "synthetic[:seed]": He-normal weights (no pretrained file offline) -- tests / benchmarks
+            L.vgg_load(ctx, *L.synthetic_vgg_weights(seed=int(o.model.split(":")[1]) if ":" in o.model else 1, bias_std=0.05))
+        else:
+            cw, cb, fc6, fc7, m = fmt.load_vgg_mat(o.model)
+            if m is not None:
+                mean = tuple(float(v) for v in m)
+            L.vgg_load(ctx, [L.to_jl(w) for w in cw], [torch.as_tensor(b).cuda() for b in cb],
+                       (L.to_jl(fc6[0]), torch.as_tensor(fc6[1]).cuda()), (L.to_jl(fc7[0]), torch.as_tensor(fc7[1]).cuda()))
+            if fmt.load_vgg_mat.average_image is not None:  # the reference subtracts the full array (lrcn.jl:113, 770)
+                L.set_average_image(ctx, fmt.load_vgg_mat.average_image)
+                mean = None
         print("Cnn is initialized")
+
+    def load_crops(paths):
+        """read_image_data (lrcn.jl:750-765) for a batch: decode on the host, resize / crop / grey->RGB on the GPU."""
+        from PIL import Image
+        ims = []
+        for pth in paths:
+            im = Image.open(pth)
+            ims.append(np.asarray(im if im.mode in ("L", "RGB", "RGBA") else im.convert("RGB")))
+        return L.resize_crop_u8(ctx, ims)
     feats = [fmt.load_features(p) for p in o.features]
     idx2word = cap.index_to_word(vocab)
 
@@ -133,12 +148,11 @@ def main(argv=None):
     # ---------------------------------------------------------------- generate (lrcn.jl:127-160)
     if o.generate > 0:
         if o.cnn:
-            from PIL import Image
-            crop = fmt.center_crop_224(Image.open(o.image))
+            crop = load_crops([o.image])
             if vdt == lrcn_amd.LRCN_FP8:
-                L.vgg_calibrate(ctx, torch.as_tensor(crop[None]).cuda(), mean=mean)
-            f = L.from_jl(L.convnet_u8(ctx, torch.as_tensor(crop[None]).cuda(), mean=mean))[0]
-            toks, _ = L.beam_search(ctx, param, L.to_jl((f / f.sum())[None].astype(np.float32)), o.beam_width, o.generate)
+                L.vgg_calibrate(ctx, crop, mean=mean)
+            f = L.convnet_u8(ctx, crop, mean=mean, normalize=True)  # input = input / sum(input)  (lrcn.jl:595-597)
+            toks, _ = L.beam_search(ctx, param, f, o.beam_width, o.generate)
             print(cap.caption_text(toks, idx2word))
             return 0
         split = lists[2] if o.flickr and len(lists) > 2 else lists[min(1, len(lists) - 1)]
@@ -162,16 +176,14 @@ def main(argv=None):
 
     # ---------------------------------------------------------------- extract features (lrcn.jl:162-172, 190-221)
     if o.extfeatures:
-        from PIL import Image
         ids = sorted({c[0][0] for c in lists[0]})
         table, B = {}, max(o.batchsize, 1)
-        for s in range(0, len(ids), B):
+        for s in range(0, len(ids), B):  # the reference extracts image by image (lrcn.jl:190-221); here B images per VGG forward
             chunk = ids[s:s + B]
-            crops = np.stack([fmt.center_crop_224(Image.open(os.path.join(o.imagedir, "%s%012d.jpg" % (o.prefix, i) if o.prefix
-                                                                        else "%d.jpg" % i))) for i in chunk])
+            crops = load_crops([os.path.join(o.imagedir, "%s%012d.jpg" % (o.prefix, i) if o.prefix else "%d.jpg" % i) for i in chunk])
             if vdt == lrcn_amd.LRCN_FP8 and s == 0:  # activation scales of the e4m3 layers from the first batch
-                L.vgg_calibrate(ctx, torch.as_tensor(crops).cuda(), mean=mean)
-            f = L.from_jl(L.convnet_u8(ctx, torch.as_tensor(crops).cuda(), mean=mean))
+                L.vgg_calibrate(ctx, crops, mean=mean)
+            f = L.from_jl(L.convnet_u8(ctx, crops, mean=mean))
             for i, row in zip(chunk, f):
                 table[i] = row.copy()
         fmt.save_features(o.savefile or "feats.npz", table)
