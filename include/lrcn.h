@@ -150,6 +150,31 @@ int lrcn_train_step(lrcn_ctx *ctx, float *const params[9], float *const grads[9]
                     const lrcn_dropout *drop, int step, float lr, float beta1, float beta2, float eps,
                     double *loss_host);
 
+/* ---- data parallelism over the GPUs of a node (new -- the reference is single-device).  One process (or thread) and
+ * one context per GPU.  Rows of a global batch are split over the ranks; every rank passes the GLOBAL batch as norm_B, so the
+ * sum of the ranks' gradients is exactly the single-device gradient of lrcn.jl:564-580, and an identical Adam step follows
+ * everywhere.  Transport: RCCL over xGMI (librccl.so.1 is opened at run time), fp32 on the wire, one all-reduce(SUM) per gradient
+ * group, issued on the context's own per-group streams as soon as that group's gradients are final. ---- */
+#define LRCN_UNIQUE_ID_BYTES 128
+/* Rank 0 creates the id (host buffer of LRCN_UNIQUE_ID_BYTES); the host program hands it to the other ranks by any channel. */
+int lrcn_comm_unique_id(void *id_out);
+/* Collective over the `world` contexts: binds ctx to rank `rank` of the communicator named by the id. */
+int lrcn_comm_init(lrcn_ctx *ctx, int world, int rank, const void *unique_id);
+int lrcn_comm_destroy(lrcn_ctx *ctx);
+/* In-place all-reduce(SUM) of gradient group `group` (0 .. LRCN_GRAD_GROUPS-1; -1 = all groups) of the most recent lrcn_loss_grad:
+ * the group's stream waits for its gradient-ready event, then runs the collective (a no-op without a communicator / with one rank).
+ * Asynchronous; lrcn_comm_join makes the context's stream wait for everything issued on the group streams. */
+int lrcn_allreduce_grads(lrcn_ctx *ctx, float *const grads[9], int group);
+int lrcn_comm_join(lrcn_ctx *ctx);
+/* The whole data-parallel step of SURVEY 8(b) in one call (body of train1's loop, lrcn.jl:369-394, on one rank's rows):
+ *   [img_u8 != NULL: VGG-16 forward of this rank's B crops into feats (B x 4096, caller's buffer), optionally normalised (lrcn.jl:597)]
+ *   -> lossgradient -> per gradient group: all-reduce(SUM) over the ranks -> Adam of that group, overlapped with the rest of the
+ *   backward pass -> the context's stream joins.  img_u8 == NULL: feats is the input.  Without a communicator it is lrcn_train_step. */
+int lrcn_train_step_dp(lrcn_ctx *ctx, float *const params[9], float *const grads[9], float *const mom[9], float *const var[9],
+                       const uint8_t *img_u8, const float mean[3], int normalize, float *feats, const int32_t *tokens, int T, int B,
+                       int norm_B, const lrcn_dropout *drop, int step, float lr, float beta1, float beta2, float eps,
+                       double *loss_host);
+
 /* generate + beam_search (lrcn.jl:585-678): feat 1 x 4096 (normalise beforehand if wanted, lrcn.jl:597).
  * out_tokens (host, >= nword+2 ints) receives the best hypothesis INCLUDING the leading bos; *out_len its length;
  * *out_prob its probability (linear float32 product, no length normalisation). */

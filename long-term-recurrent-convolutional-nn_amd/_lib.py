@@ -67,6 +67,14 @@ SIGNATURES = {
     "lrcn_train_step": (C.c_int, [C.c_void_p, P9, P9, P9, P9, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                   C.POINTER(Dropout), C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
                                   C.POINTER(C.c_double)]),
+    "lrcn_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "lrcn_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "lrcn_comm_destroy": (C.c_int, [C.c_void_p]),
+    "lrcn_allreduce_grads": (C.c_int, [C.c_void_p, P9, C.c_int]),
+    "lrcn_comm_join": (C.c_int, [C.c_void_p]),
+    "lrcn_train_step_dp": (C.c_int, [C.c_void_p, P9, P9, P9, P9, C.c_void_p, C.POINTER(C.c_float), C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                     C.c_int, C.c_int, C.POINTER(Dropout), C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
+                                     C.POINTER(C.c_double)]),
     "lrcn_beam_search": (C.c_int, [C.c_void_p, P9, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32),
                                    C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     "lrcn_beam_search_batch": (C.c_int, [C.c_void_p, P9, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32),

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "../../include/lrcn.h"
+#include "comm.h"
 #include "common.h"
 #include "gemm.h"
 #include "kernels.h"
@@ -109,6 +110,11 @@ struct lrcn_ctx {
     void *img_meta = nullptr;
     int img_meta_cap = 0;
     float *pre_f32 = nullptr;
+    // data parallelism: RCCL communicator (lrcn_comm_init) and one stream per gradient group for [all-reduce -> Adam]
+    LrcnComm *comm = nullptr;
+    hipStream_t bucket[LRCN_GRAD_GROUPS] = {};
+    hipEvent_t bucket_done[LRCN_GRAD_GROUPS] = {};
+    bool bucket_pending[LRCN_GRAD_GROUPS] = {};
 };
 
 #define FAIL(ctx, code, ...)                          \
@@ -576,6 +582,11 @@ void lrcn_destroy(lrcn_ctx *c) {
     for (void *p : c->allocs) (void)hipFree(p);
     for (auto &e : c->grad_ev)
         if (e) (void)hipEventDestroy(e);
+    comm_destroy(c->comm);
+    for (auto &e : c->bucket_done)
+        if (e) (void)hipEventDestroy(e);
+    for (auto &b : c->bucket)
+        if (b) (void)hipStreamDestroy(b);
     for (auto &e : c->prof_ev) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
@@ -840,6 +851,114 @@ int lrcn_train_step(lrcn_ctx *c, float *const p[9], float *const g[9], float *co
     r = lrcn_adam_update(c, p, g, m, v, step, lr, b1, b2, eps);
     if (r) return r;
     return loss_host ? fetch_loss(c, loss_host) : LRCN_OK;
+}
+
+// ------------------------------------------------------------------------------------------- data parallelism
+namespace {
+const int kGradGroup[LRCN_GRAD_GROUPS][2] = {{7, 8}, {2, 3}, {4, 5}, {0, 1}, {6, 6}};  // order of the grad_ev records in loss_impl
+
+// LRCN_DP_FORCE_PIPELINE=1: run the per-group [all-reduce -> Adam] pipeline (and the collectives) even on a one-rank communicator,
+// so that a single-GPU box exercises exactly the code N > 1 runs (tests)
+bool dp_force_pipeline() {
+    const char *k = getenv("LRCN_DP_FORCE_PIPELINE");
+    return k && k[0] == '1';
+}
+
+int ensure_buckets(lrcn_ctx *c) {
+    for (int g = 0; g < LRCN_GRAD_GROUPS; ++g) {
+        if (!c->bucket[g]) HIPCHK(c, hipStreamCreateWithFlags(&c->bucket[g], hipStreamNonBlocking));
+        if (!c->bucket_done[g]) HIPCHK(c, hipEventCreateWithFlags(&c->bucket_done[g], hipEventDisableTiming));
+    }
+    return LRCN_OK;
+}
+
+// bucket stream of `group`: wait for the group's gradient-ready event, then all-reduce its tensors in place (one collective when
+// they are adjacent in memory, which they are in a flat gradient buffer)
+int allreduce_group(lrcn_ctx *c, float *const grads[9], int group) {
+    int64_t sz[9];
+    ctx_sizes(c, sz);
+    hipStream_t s = c->bucket[group];
+    HIPCHK(c, hipStreamWaitEvent(s, c->grad_ev[group], 0));
+    if (c->comm && (comm_world(c->comm) > 1 || dp_force_pipeline())) {
+        char err[256] = "";
+        const int k0 = kGradGroup[group][0], k1 = kGradGroup[group][1];
+        int rc = 0;
+        if (k0 == k1 || sz[k1] == 0) {
+            rc = comm_allreduce_f32(c->comm, grads[k0], (size_t)sz[k0], s, err, sizeof(err));
+        } else if (sz[k0] == 0) {
+            rc = comm_allreduce_f32(c->comm, grads[k1], (size_t)sz[k1], s, err, sizeof(err));
+        } else if (grads[k0] + sz[k0] == grads[k1]) {
+            rc = comm_allreduce_f32(c->comm, grads[k0], (size_t)(sz[k0] + sz[k1]), s, err, sizeof(err));
+        } else {
+            comm_group_begin(c->comm);
+            rc = comm_allreduce_f32(c->comm, grads[k0], (size_t)sz[k0], s, err, sizeof(err));
+            if (!rc) rc = comm_allreduce_f32(c->comm, grads[k1], (size_t)sz[k1], s, err, sizeof(err));
+            comm_group_end(c->comm);
+        }
+        if (rc) FAIL(c, LRCN_EHIP, "%s", err);
+    }
+    c->bucket_pending[group] = true;
+    return LRCN_OK;
+}
+
+int join_buckets(lrcn_ctx *c) {
+    for (int g = 0; g < LRCN_GRAD_GROUPS; ++g)
+        if (c->bucket_pending[g]) {
+            HIPCHK(c, hipEventRecord(c->bucket_done[g], c->bucket[g]));
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->bucket_done[g], 0));
+            c->bucket_pending[g] = false;
+        }
+    return LRCN_OK;
+}
+}  // namespace
+
+int lrcn_comm_unique_id(void *id_out) {
+    if (!id_out) return LRCN_EINVAL;
+    char err[256] = "";
+    if (comm_unique_id(id_out, err, sizeof(err))) {
+        g_create_err = err;
+        return LRCN_EHIP;
+    }
+    return LRCN_OK;
+}
+
+int lrcn_comm_init(lrcn_ctx *c, int world, int rank, const void *unique_id) {
+    DeviceGuard dg(c);
+    if (!c) return LRCN_EINVAL;
+    if (world < 1 || rank < 0 || rank >= world || !unique_id) FAIL(c, LRCN_EINVAL, "comm_init: world=%d rank=%d", world, rank);
+    if (c->comm) FAIL(c, LRCN_ESTATE, "the context already has a communicator");
+    char err[256] = "";
+    c->comm = comm_create(world, rank, unique_id, err, sizeof(err));
+    if (!c->comm) FAIL(c, LRCN_EHIP, "%s", err);
+    return ensure_buckets(c);
+}
+
+int lrcn_comm_destroy(lrcn_ctx *c) {
+    DeviceGuard dg(c);
+    if (!c) return LRCN_EINVAL;
+    HIPCHK(c, hipDeviceSynchronize());
+    comm_destroy(c->comm);
+    c->comm = nullptr;
+    return LRCN_OK;
+}
+
+int lrcn_allreduce_grads(lrcn_ctx *c, float *const grads[9], int group) {
+    DeviceGuard dg(c);
+    if (!c || !grads) return LRCN_EINVAL;
+    if (group < -1 || group >= LRCN_GRAD_GROUPS) FAIL(c, LRCN_EINVAL, "group=%d outside [-1,%d)", group, LRCN_GRAD_GROUPS);
+    int r = ensure_buckets(c);
+    if (r) return r;
+    for (int g = (group < 0 ? 0 : group); g < (group < 0 ? LRCN_GRAD_GROUPS : group + 1); ++g) {
+        r = allreduce_group(c, grads, g);
+        if (r) return r;
+    }
+    return LRCN_OK;
+}
+
+int lrcn_comm_join(lrcn_ctx *c) {
+    DeviceGuard dg(c);
+    if (!c) return LRCN_EINVAL;
+    return join_buckets(c);
 }
 
 int lrcn_lstm(lrcn_ctx *c, const float *W, const float *b, int X, int H, int B, const float *x, const float *h, const float *cc,
@@ -1340,6 +1459,45 @@ int vgg_check(lrcn_ctx *c, int N) {
     return LRCN_OK;
 }
 }  // namespace
+
+int lrcn_train_step_dp(lrcn_ctx *c, float *const p[9], float *const g[9], float *const m[9], float *const v[9], const uint8_t *img_u8,
+                       const float mean[3], int normalize, float *feats, const int32_t *tokens, int T, int B, int norm_B,
+                       const lrcn_dropout *drop, int step, float lr, float b1, float b2, float eps, double *loss_host) {
+    DeviceGuard dg(c);
+    if (!c || !p || !g || !m || !v || !feats || step < 1) return LRCN_EINVAL;
+    int r;
+    if (img_u8) {  // [VGG forward of this rank's crops] -> feats
+        if (!mean && !c->avg_on) FAIL(c, LRCN_EINVAL, "img_u8 given without channel means or an averageImage");
+        r = vgg_check(c, B);
+        if (r) return r;
+        r = vgg_body(c, B, img_u8, true, mean);
+        if (r) return r;
+        k_transpose_f32(c->stream, c->featsRM, 4096, B, 4096, feats, B);
+        if (normalize) k_normalize_rows(c->stream, feats, B, LRCN_CNNOUT);
+        KCHK(c, "train_step_dp (vgg)");
+    }
+    r = loss_impl(c, p, feats, tokens, T, B, norm_B, drop, g, nullptr);
+    if (r) return r;
+    if (!c->comm || (comm_world(c->comm) == 1 && !dp_force_pipeline())) {  // one rank: nothing to hide the update behind -- one Adam launch
+        r = lrcn_adam_update(c, p, g, m, v, step, lr, b1, b2, eps);
+        if (r) return r;
+        return loss_host ? fetch_loss(c, loss_host) : LRCN_OK;
+    }
+    // per gradient group, on its own stream, while the rest of the backward pass is still running on the context's stream:
+    // [wait for the group's gradients] -> [all-reduce over xGMI] -> [Adam of that group].  The backward reads the shadows made
+    // at the start of the step, never the f32 parameters, so updating a group early is safe.
+    r = ensure_buckets(c);
+    if (r) return r;
+    for (int grp = 0; grp < LRCN_GRAD_GROUPS; ++grp) {
+        r = allreduce_group(c, g, grp);
+        if (r) return r;
+        r = lrcn_adam_update_group(c, p, g, m, v, grp, step, lr, b1, b2, eps, c->bucket[grp]);
+        if (r) return r;
+    }
+    r = join_buckets(c);  // the next step's shadow-weight pass reads the updated parameters
+    if (r) return r;
+    return loss_host ? fetch_loss(c, loss_host) : LRCN_OK;
+}
 
 const char *lrcn_debug_route(lrcn_ctx *c, int which) {
     if (which == 1) return c ? c->vgg_routes.c_str() : "";

@@ -88,17 +88,51 @@ class HipOps:
         """`stream` waits until the gradients of GRAD_GROUPS[group] of the last lossgradient are final."""
         self.ctx._call("lrcn_grad_group_wait", group, C.c_void_p(stream.cuda_stream))
 
+    # the [all-reduce -> Adam] pipeline of the torch.distributed backend runs on one stream per gradient group
+    def make_streams(self, n):
+        return [torch.cuda.Stream(device=self.ctx.device) for _ in range(n)]
+
+    def stream_ctx(self, stream):
+        return torch.cuda.stream(stream)
+
+    def join(self, streams):
+        main = torch.cuda.current_stream(self.ctx.device)
+        for s in streams:
+            main.wait_stream(s)  # the next step's shadow-weight pass reads the updated parameters
+
+    # the C-ABI backend: RCCL inside liblrcn_hip (lrcn_comm_init / lrcn_train_step_dp)
+    def comm_init(self, world, rank, unique_id):
+        L.comm_init(self.ctx, world, rank, unique_id)
+
+    def train_step_dp(self, param, grads, optim, feats, tokens, norm_B, pdrop, seed):
+        L.train_step_dp(self.ctx, param, optim, grads, feats, tokens, norm_B=norm_B, pdrop=pdrop, seed=seed)
+
 
 class DataParallelTrainer:
     """train1's batch loop body (lrcn.jl:369-394) sharded over ranks. world_size 1 = no collective.
     `ops` defaults to the HIP operations; tests of the collective logic on CPU (gloo) inject their own."""
 
-    def __init__(self, ctx, param, optim, B_global, world=1, rank=0, pdrop=0.4, seed=0, group=None, ops=None):
+    def __init__(self, ctx, param, optim, B_global, world=1, rank=0, pdrop=0.4, seed=0, group=None, ops=None, backend=None):
+        """backend (world > 1): "abi" = RCCL inside liblrcn_hip (lrcn_comm_init + lrcn_train_step_dp: one C call per step, what a
+        Julia host would drive; the unique id travels over torch.distributed's group) -- the default with the HIP ops;
+        "torch" = torch.distributed all-reduces issued from here (LRCN_DP_BACKEND overrides)."""
         self.ops = ops if ops is not None else HipOps(ctx)
         self.ctx, self.param, self.optim = ctx, param, optim
         self.B_global, self.world, self.rank = B_global, world, rank
         self.pdrop, self.seed = pdrop, seed
         self.group = group
+        backend = os.environ.get("LRCN_DP_BACKEND") or backend
+        if backend is None:
+            backend = "abi" if (world > 1 and hasattr(self.ops, "train_step_dp") and param[0].is_cuda) else "torch"
+        if backend not in ("abi", "torch"):
+            raise L.LrcnError("unknown data-parallel backend %r" % (backend,))
+        self.backend = backend
+        if backend == "abi" and world > 1:
+            uid = torch.zeros(128, dtype=torch.uint8, device=param[0].device)
+            if rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(L.comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(uid, 0, group=group)
+            self.ops.comm_init(world, rank, bytes(uid.cpu().numpy().tobytes()))
         self.flat_grads, self.grads = flat_model_like([tuple(t.shape) for t in param], device=param[0].device)
         self.step_no = 0
         self._feats_next = None
@@ -126,9 +160,9 @@ class DataParallelTrainer:
         if os.environ.get("LRCN_DP_BUCKETS", "1")[:1] == "0":
             return [dist.all_reduce(self.flat_grads, op=dist.ReduceOp.SUM, group=self.group, async_op=True)]
         works = []
-        gpu = self.flat_grads.is_cuda and hasattr(self.ops, "grad_group_wait")
+        gpu = hasattr(self.ops, "grad_group_wait") and hasattr(self.ops, "make_streams")
         if gpu and self._bucket_streams is None:
-            self._bucket_streams = [torch.cuda.Stream(device=self.flat_grads.device) for _ in GRAD_GROUPS]
+            self._bucket_streams = self.ops.make_streams(len(GRAD_GROUPS))
         for k, (a, b) in enumerate(self._group_slices()):
             if a == b:
                 continue  # LRCN-1f has no W2 / b2: nothing to exchange for that group
@@ -136,7 +170,7 @@ class DataParallelTrainer:
             if gpu:
                 s = self._bucket_streams[k]
                 self.ops.grad_group_wait(k, s)  # s waits for the group's event; RCCL's stream then waits for s
-                with torch.cuda.stream(s):
+                with self.ops.stream_ctx(s):
                     works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             else:
                 works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
@@ -183,8 +217,14 @@ class DataParallelTrainer:
         if next_img_u8 is not None and self._side is not None:
             self._feats_next = self._vgg_on_side_stream(next_img_u8)  # concurrent with everything below
         # rank-dependent dropout stream: masks differ per shard like rows of one big batch would
-        self.ops.lossgradient(self.param, feats, tokens, self.B_global, self.pdrop,
-                              (self.seed + self.step_no) * 65536 + self.rank, self.grads)
+        seed = (self.seed + self.step_no) * 65536 + self.rank
+        if self.backend == "abi" and self.world > 1:
+            # one C call: lossgradient + per-group [all-reduce over xGMI -> Adam] on the library's own streams
+            self.ops.train_step_dp(self.param, self.grads, self.optim, feats, tokens, self.B_global, self.pdrop, seed)
+            if next_img_u8 is not None and self._side is None:
+                self._feats_next = self.vgg(next_img_u8)
+            return
+        self.ops.lossgradient(self.param, feats, tokens, self.B_global, self.pdrop, seed, self.grads)
         if self._group_pipeline():
             # per gradient group, on its own stream: [wait for the group's event] -> [all-reduce] -> [Adam of that group], all
             # while the rest of the backward pass runs (it reads the bf16/f32 shadows, never the f32 parameters)
@@ -205,7 +245,7 @@ class DataParallelTrainer:
         reduced, instead of one 0.19-ms launch after the last bucket.  With one rank there is no exchange to hide it behind
         and five launches measure 1 % slower than one (B=32: 1.728 vs 1.708 ms/step), so the single launch stays.
         LRCN_DP_GROUP_ADAM=0/1 forces either; LRCN_DP_BUCKETS=0 selects the single all-reduce + single Adam."""
-        if not (self.flat_grads.is_cuda and hasattr(self.ops, "grad_group_wait") and hasattr(self.ops, "update_group")):
+        if not (hasattr(self.ops, "grad_group_wait") and hasattr(self.ops, "update_group") and hasattr(self.ops, "make_streams")):
             return False
         if os.environ.get("LRCN_DP_BUCKETS", "1")[:1] == "0":
             return False
@@ -213,19 +253,17 @@ class DataParallelTrainer:
         return env[:1] != "0" if env else self.world > 1
 
     def _reduce_and_update_groups(self):
-        main = torch.cuda.current_stream(self.flat_grads.device)
         if self._bucket_streams is None:
-            self._bucket_streams = [torch.cuda.Stream(device=self.flat_grads.device) for _ in GRAD_GROUPS]
+            self._bucket_streams = self.ops.make_streams(len(GRAD_GROUPS))
         self.optim.t += 1
         for k, (a, b) in enumerate(self._group_slices()):
             s = self._bucket_streams[k]
             self.ops.grad_group_wait(k, s)  # s waits for the group's event recorded inside lossgradient
-            with torch.cuda.stream(s):
+            with self.ops.stream_ctx(s):
                 if self.world > 1 and b > a:
                     dist.all_reduce(self.flat_grads[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True).wait()  # s waits for RCCL
                 self.ops.update_group(self.param, self.grads, self.optim, k, s)
-        for s in self._bucket_streams:
-            main.wait_stream(s)  # the next step's shadow-weight pass reads the updated parameters
+        self.ops.join(self._bucket_streams)
 
     def loss_value(self):
         """Global loss of the last step: sum over ranks of the locally normalised partial losses."""

@@ -287,6 +287,50 @@ def train_step(ctx, param, optim, grads, feats, tokens, norm_B=None, pdrop=0.4, 
     return out.value if want_loss else None
 
 
+def comm_unique_id():
+    """RCCL unique id (bytes) for lrcn_comm_init: rank 0 creates it, the host program distributes it."""
+    buf = (C.c_char * 128)()
+    _lib.check(None, _lib.lib().lrcn_comm_unique_id(buf))
+    return bytes(buf)
+
+
+def comm_init(ctx, world, rank, unique_id):
+    """Bind ctx to rank `rank` of a `world`-rank RCCL communicator (collective over the ranks): lrcn_comm_init."""
+    buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
+    ctx._call("lrcn_comm_init", int(world), int(rank), buf)
+
+
+def comm_destroy(ctx):
+    ctx._call("lrcn_comm_destroy")
+
+
+def allreduce_grads(ctx, grads, group=-1):
+    """lrcn_allreduce_grads: in-place all-reduce(SUM) of one gradient group (or all) on the context's group stream."""
+    ctx._call("lrcn_allreduce_grads", _p9(grads), int(group))
+
+
+def comm_join(ctx):
+    ctx._call("lrcn_comm_join")
+
+
+def train_step_dp(ctx, param, optim, grads, feats, tokens, norm_B=None, pdrop=0.4, seed=0, img_u8=None, mean=VGG_MEAN, normalize=False,
+                  want_loss=False):
+    """The data-parallel step in one C call (lrcn_train_step_dp): [VGG forward of img_u8 into feats] + lossgradient + per-group
+    all-reduce over the ranks + per-group Adam.  feats: B x 4096 column-major (input, or output buffer when img_u8 is given)."""
+    tok = _tokens(tokens, feats.device)
+    T, B = tok.shape
+    d, keep = _dropout(pdrop, seed, None, None)
+    optim.t += 1
+    out = C.c_double()
+    m = (C.c_float * 3)(*mean) if mean is not None else None
+    ctx._call("lrcn_train_step_dp", _p9(param), _p9(grads), _p9(optim.m), _p9(optim.v),
+              C.c_void_p(img_u8.data_ptr()) if img_u8 is not None else None, m, int(bool(normalize)), _ptr(feats), C.c_void_p(tok.data_ptr()),
+              T, B, norm_B or B, C.byref(d) if d else None, optim.t, optim.lr, optim.beta1, optim.beta2, optim.eps,
+              C.byref(out) if want_loss else None)
+    del keep
+    return out.value if want_loss else None
+
+
 def average_loss(ctx, param, batches):
     """average_loss (lrcn.jl:407-486): forward-only NLL over batches [(feats, tokens), ...], pdrop 0, captions longer
     than 28 tokens skipped (:438); returns -total/count with count = sum of B*(T+1)."""

@@ -41,6 +41,38 @@ class OracleOps:
         return self._loss
 
 
+class OracleGroupOps(OracleOps):
+    """The same, plus the CPU stand-ins of what the per-group [all-reduce -> Adam] pipeline needs (dp.py
+    _reduce_and_update_groups / the bucketed _allreduce_async): "streams" are labels, the gradient-ready "events" are already
+    complete (lossgradient is synchronous here), and every call is logged so the test can check the ORDER the trainer drives."""
+
+    def __init__(self, dims):
+        super().__init__(dims)
+        self.log = []
+
+    def make_streams(self, n):
+        self.log.append(("make_streams", n))
+        return ["bucket%d" % k for k in range(n)]
+
+    def stream_ctx(self, stream):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def grad_group_wait(self, group, stream):
+        self.log.append(("wait", group, stream))
+
+    def update_group(self, param, grads, optim, group, stream):
+        from lrcn_amd import dp
+        self.log.append(("adam", group, stream, optim.t))
+        for k in dp.GRAD_GROUPS[group]:
+            w, mm, vv = (np.asfortranarray(a.numpy()) for a in (param[k], optim.m[k], optim.v[k]))
+            orc.adam(w, np.asfortranarray(grads[k].numpy()), mm, vv, optim.t)
+            param[k].copy_(torch.as_tensor(w)); optim.m[k].copy_(torch.as_tensor(mm)); optim.v[k].copy_(torch.as_tensor(vv))
+
+    def join(self, streams):
+        self.log.append(("join", len(streams)))
+
+
 class HostAdam:
     def __init__(self, param):
         self.t = 0
@@ -48,9 +80,11 @@ class HostAdam:
         self.v = [torch.zeros_like(p) for p in param]
 
 
-def _worker(rank, world, port, golden, out):
+def _worker(rank, world, port, golden, out, mode="plain"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    if mode == "bucket_one_adam":
+        os.environ["LRCN_DP_GROUP_ADAM"] = "0"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from lrcn_amd import dp
     z = np.load(golden)
@@ -58,24 +92,40 @@ def _worker(rank, world, port, golden, out):
     param = [torch.as_tensor(np.array(z["p_" + n])) for n in orc.PARAM_NAMES]
     Bg = z["feats"].shape[0]
     rows = dp.shard_rows(Bg, world, rank)
-    tr = dp.DataParallelTrainer(None, param, HostAdam(param), Bg, world, rank, pdrop=0.0, ops=OracleOps(dims))
+    ops = OracleOps(dims) if mode == "plain" else OracleGroupOps(dims)
+    tr = dp.DataParallelTrainer(None, param, HostAdam(param), Bg, world, rank, pdrop=0.0, ops=ops)
+    assert tr.backend == "torch"
     feats = torch.as_tensor(z["feats"][rows])
     toks = z["tokens"][:, rows]
     losses = []
     for _ in range(2):
         tr.step(None, toks, feats=feats)
         losses.append(tr.loss_value())
+    if mode == "group_pipeline":
+        # the path N > 1 takes on the GPU: per step, for each gradient group in the order lossgradient finalises them,
+        # [wait for the group's event on its stream] -> [all-reduce] -> [Adam of the group with this step's t], then one join
+        per_step = [e for e in ops.log if e[0] != "make_streams"]
+        assert ops.log[0] == ("make_streams", 5) and len(per_step) == 2 * 11
+        for step in range(2):
+            ev = per_step[step * 11:(step + 1) * 11]
+            for k in range(5):
+                assert ev[2 * k] == ("wait", k, "bucket%d" % k) and ev[2 * k + 1] == ("adam", k, "bucket%d" % k, step + 1), ev
+            assert ev[10] == ("join", 5)
+    elif mode == "bucket_one_adam":
+        waits = [e for e in ops.log if e[0] == "wait"]
+        assert len(waits) == 2 * 5 and not [e for e in ops.log if e[0] == "adam"]  # bucketed all-reduces, then ONE update
     if rank == 0:
         np.savez(out, losses=np.array(losses), **{n: p.numpy() for n, p in zip(orc.PARAM_NAMES, param)})
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_step_equals_full_batch(golden_dir, tmp_path):
+@pytest.mark.parametrize("mode", ["plain", "group_pipeline", "bucket_one_adam"])
+def test_two_rank_step_equals_full_batch(golden_dir, tmp_path, mode):
     golden = os.path.join(golden_dir, "lstm_mid.npz")
     out = str(tmp_path / "dp.npz")
-    port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_worker, args=(2, port, golden, out), nprocs=2, join=True)
+    port = 29500 + (os.getpid() % 2000) + {"plain": 0, "group_pipeline": 1, "bucket_one_adam": 2}[mode]
+    mp.spawn(_worker, args=(2, port, golden, out, mode), nprocs=2, join=True)
     got = np.load(out)
     # single-process reference: two full-batch steps with the oracle
     z = np.load(golden)

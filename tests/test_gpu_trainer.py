@@ -69,7 +69,9 @@ def test_gradient_group_events_and_bucketed_allreduce_path(monkeypatch):
             monkeypatch.setenv("LRCN_DP_GROUP_ADAM", group_adam)  # per-group [all-reduce -> Adam] pipeline on / off
             ctx = L.Context(E, H, H, V, max_B=B, max_T=T, lstm_dtype=lrcn_amd.LRCN_BF16)
             param = L.initweights(ctx, seed=42)
-            tr = dp.DataParallelTrainer(ctx, param, L.initparams(param), B, world, 0, pdrop=0.4, seed=7, group=dist.group.WORLD)
+            # backend "torch": the all-reduces are issued from dp.py over torch.distributed; `world` = 2 is only what the trainer is
+            # told (the process group has one rank), which the C-ABI backend's real ncclCommInitRank(world = 2) could not survive
+            tr = dp.DataParallelTrainer(ctx, param, L.initparams(param), B, world, 0, pdrop=0.4, seed=7, group=dist.group.WORLD, backend="torch")
             rng = np.random.default_rng(3)
             losses = []
             for k in range(3):
@@ -104,3 +106,79 @@ def test_gradient_group_events_and_bucketed_allreduce_path(monkeypatch):
                 np.testing.assert_allclose(a, b, rtol=0, atol=2e-4)
     finally:
         dist.destroy_process_group()
+
+
+def test_c_abi_rccl_step_single_rank(monkeypatch):
+    # lrcn_comm_* / lrcn_allreduce_grads / lrcn_train_step_dp (RCCL opened by the library itself).  A GPU box has one device, so
+    # the communicator has one rank; LRCN_DP_FORCE_PIPELINE=1 makes the library run the N > 1 code path on it anyway: group
+    # streams gated on the gradient-ready events, one ncclAllReduce per group (sum over one rank = identity), per-group Adam, join.
+    # Every variant must reproduce the plain lrcn_train_step trajectory.
+    E = H = 64
+    V, B, T = 300, 8, 5
+    rng = np.random.default_rng(5)
+    batches = [((rng.standard_normal((B, 4096)) * 0.01).astype(np.float32), rng.integers(3, V, size=(T, B)).astype(np.int32)) for _ in range(3)]
+
+    def run(mode):
+        monkeypatch.setenv("LRCN_DP_FORCE_PIPELINE", "1" if mode == "pipeline" else "0")
+        ctx = L.Context(E, H, H, V, max_B=B, max_T=T, lstm_dtype=lrcn_amd.LRCN_BF16)
+        param = L.initweights(ctx, seed=42)
+        opt = L.initparams(param)
+        flat, grads = dp.flat_model_like([tuple(t.shape) for t in param])
+        if mode != "plain":
+            L.comm_init(ctx, 1, 0, L.comm_unique_id())
+        losses = []
+        for k, (f, t) in enumerate(batches):
+            if mode == "plain":
+                losses.append(L.train_step(ctx, param, opt, grads, L.to_jl(f), t, pdrop=0.4, seed=k, want_loss=True))
+            elif mode == "pieces":  # the entry points one by one: lossgradient, all-reduce of every group, join, update!
+                _, val = L.lossgradient(ctx, param, L.to_jl(f), t, pdrop=0.4, seed=k, grads=grads)
+                L.allreduce_grads(ctx, grads, -1)
+                L.comm_join(ctx)
+                L.update(ctx, param, grads, opt)
+                losses.append(val)
+            else:
+                losses.append(L.train_step_dp(ctx, param, opt, grads, L.to_jl(f), t, pdrop=0.4, seed=k, want_loss=True))
+        ctx.sync()
+        out = [L.from_jl(p).copy() for p in param]
+        if mode != "plain":
+            L.comm_destroy(ctx)
+        ctx.close()
+        return losses, out
+
+    l0, p0 = run("plain")
+    for mode in ("single", "pipeline", "pieces"):
+        l, p = run(mode)
+        np.testing.assert_allclose(l, l0, rtol=1e-6)
+        for a, b in zip(p, p0):
+            np.testing.assert_array_equal(a, b)  # same kernels, same order per tensor: bit-identical parameters
+
+
+def test_train_step_dp_with_images_equals_separate_calls():
+    # lrcn_train_step_dp(img_u8 != NULL) = SURVEY 8(b)'s fused step: VGG forward + normalisation + lossgradient + update in one call
+    E = H = 32
+    V, B, T = 100, 2, 3
+    rng = np.random.default_rng(9)
+    imgs = torch.as_tensor(rng.integers(0, 256, size=(B, 224, 224, 3), dtype=np.uint8)).cuda()
+    toks = rng.integers(3, V, size=(T, B)).astype(np.int32)
+    w = L.synthetic_vgg_weights(seed=1, bias_std=0.05)
+    outs = []
+    for fused in (True, False):
+        ctx = L.Context(E, H, H, V, max_B=B, max_T=T, lstm_dtype=lrcn_amd.LRCN_BF16, vgg_dtype=lrcn_amd.LRCN_BF16, max_images=B)
+        L.vgg_load(ctx, *w)
+        param = L.initweights(ctx, seed=3)
+        opt = L.initparams(param)
+        grads = L.zeros_like_model(param)
+        feats = L.jl_empty(B, L.CNNOUT)
+        if fused:
+            val = L.train_step_dp(ctx, param, opt, grads, feats, toks, pdrop=0.0, img_u8=imgs, normalize=True, want_loss=True)
+        else:
+            L.convnet_u8(ctx, imgs, feats=feats, normalize=True)
+            val = L.train_step(ctx, param, opt, grads, feats, toks, pdrop=0.0, want_loss=True)
+        ctx.sync()
+        outs.append((val, L.from_jl(feats).copy(), [L.from_jl(p).copy() for p in param]))
+        ctx.close()
+    assert outs[0][0] == outs[1][0] and np.isfinite(outs[0][0])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    assert abs(outs[0][1].sum(axis=1) - 1.0).max() < 1e-4   # rows normalised to sum 1 (lrcn.jl:597)
+    for a, b in zip(outs[0][2], outs[1][2]):
+        np.testing.assert_array_equal(a, b)
