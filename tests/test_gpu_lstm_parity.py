@@ -280,9 +280,11 @@ def test_error_paths_do_not_abort():
         L.loss(ctx, param, L.jl_zeros(9, 4096), np.zeros((2, 9), np.int32))  # B > max_B
     with pytest.raises(L.LrcnError):
         L.Context(8, 8, 7, 17, max_B=4)  # odd H2
-    # out-of-range token ids are clamped to unk rather than faulting
-    v = L.loss(ctx, param, feats, np.full((2, 4), 1000, np.int32))
-    assert np.isfinite(v)
+    # out-of-range token ids never fault the device (clamped to unk) and are REPORTED, as the reference's BoundsError would be
+    # (lrcn.jl:556/569); the context stays usable
+    with pytest.raises(L.LrcnError, match="token id"):
+        L.loss(ctx, param, feats, np.full((2, 4), 1000, np.int32))
+    assert np.isfinite(L.loss(ctx, param, feats, np.full((2, 4), 5, np.int32)))
 
 
 def test_adam_by_gradient_group_equals_one_launch():
