@@ -57,7 +57,8 @@ constexpr int LDS_BYTES = BIAS_OFF + 64 * 4;
 // FUSE layout: 21 m-tiles (336 pixel rows) per patch, 4 raw-window buffers, conv1_1 weights and both bias vectors
 constexpr int F_PATCH = 21 * 2048;
 constexpr int F_RAW_OFF = 3 * F_PATCH;
-constexpr int F_RAW = 4096;  // 16 DMA slots of 256 B: slot i = window rows 2i, 2i+1 (128 B each, 120 used); slots 10..15 dummy
+constexpr int F_RAW = 4096;  // 24 window rows (20 real) at a pitch of F_RAW_ROW bytes, 120 used per row
+constexpr int F_RAW_ROW = 144;
 constexpr int F_W11_OFF = F_RAW_OFF + 4 * F_RAW;
 constexpr int F_B11_OFF = F_W11_OFF + 64 * 64;
 constexpr int F_BIAS_OFF = F_B11_OFF + 256;
@@ -181,24 +182,29 @@ template <bool POOL, bool FUSE> __global__ __launch_bounds__(512) void conv64_ke
 
     // ================= FUSE: raw-window DMA and the conv1_1 patch producer =================
     auto issue_raw = [&](int tile, int rbuf) {
-        // two 256-byte DMAs per wave: slot ii = 2 wave + k = window rows 2 ii, 2 ii + 1; lane -> (row half, dword i < 30); the
-        // window starts at element (16 ty - 2) * 3 of image row 16 tx - 2 + wrow: dword-aligned, and so is every pixel edge
+        // three 128-byte DMAs per wave, lanes 0..31 only: window row wrow = wave + 8 k (rows 20..23 are dummies that keep the
+        // per-wave count uniform); lane i < 30 -> dword i of the row; the window starts at element (16 ty - 2) * 3 of image row
+        // 16 tx - 2 + wrow: dword-aligned, and so is every pixel edge.  LDS rows are F_RAW_ROW = 144 bytes apart: the producer's 16
+        // lanes of a group read 16 CONSECUTIVE window rows at one byte offset, and 16 x 144 B covers all sixteen 16-byte bank
+        // slots of the 256-byte LDS line once (at the former 128-byte pitch they fell on two: SQ_LDS_BANK_CONFLICT was 39 % of the
+        // kernel's LDS cycles, profiles/r02_pmc_sq_counters_conv64.json).
         const bool live = tile >= 0;
         const int t = live ? tile : 0;
         const int per_img = a.tiles_y * a.tiles_x;
         const int n = t / per_img, r = t - n * per_img;
         const int ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
         const int S = H;
-        const int half = lane >> 5, i = lane & 31;
+        const int i = lane;
         const int e0 = (16 * ty - 2) * 3 + 2 * i;  // first of the lane's two elements inside the image row
+        if (lane < 32) {
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int ii = 2 * wave + k;
-            const int wrow = 2 * ii + half;
-            const int xr = 16 * tx - 2 + wrow;
-            const bool ok = live && i < 30 && wrow < 20 && (unsigned)xr < (unsigned)S && e0 >= 0 && e0 + 2 <= 3 * S;
-            const bf16_t *src = ok ? a.img16 + ((size_t)(n * S + xr) * S * 3 + e0) : reinterpret_cast<const bf16_t *>(a.zero_page);
-            __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(smem + F_RAW_OFF + rbuf * F_RAW + ii * 256), 4, 0, 0);
+            for (int k = 0; k < 3; ++k) {
+                const int wrow = wave + 8 * k;
+                const int xr = 16 * tx - 2 + wrow;
+                const bool ok = live && i < 30 && wrow < 20 && (unsigned)xr < (unsigned)S && e0 >= 0 && e0 + 2 <= 3 * S;
+                const bf16_t *src = ok ? a.img16 + ((size_t)(n * S + xr) * S * 3 + e0) : reinterpret_cast<const bf16_t *>(a.zero_page);
+                __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(smem + F_RAW_OFF + rbuf * F_RAW + wrow * F_RAW_ROW), 4, 0, 0);
+            }
         }
     };
     auto produce = [&](int tile, int pbuf, int rbuf) {
@@ -233,13 +239,13 @@ template <bool POOL, bool FUSE> __global__ __launch_bounds__(512) void conv64_ke
             const int py = q / 18, px = q - 18 * py;
             qv[sl] = q;
             // run kw of pixel (py, px): window row px + kw, 9 bf16 from byte 6 py  (2-byte aligned 16-byte read: replayed, correct)
-            rbl[sl] = raw + px * 128 + 6 * py;
-            rbs[sl] = rbl[sl] + lsel * 128;
+            rbl[sl] = raw + px * F_RAW_ROW + 6 * py;
+            rbs[sl] = rbl[sl] + lsel * F_RAW_ROW;
         }
         asm volatile(
-            "ds_read_b128 %0, %20\n\tds_read_u16 %3, %23 offset:16\n\tds_read_u16 %4, %23 offset:144\n\tds_read_u16 %5, %23 offset:272\n\t"
-            "ds_read_b128 %1, %21\n\tds_read_u16 %6, %24 offset:16\n\tds_read_u16 %7, %24 offset:144\n\tds_read_u16 %8, %24 offset:272\n\t"
-            "ds_read_b128 %2, %22\n\tds_read_u16 %9, %25 offset:16\n\tds_read_u16 %10, %25 offset:144\n\tds_read_u16 %11, %25 offset:272\n\t"
+            "ds_read_b128 %0, %20\n\tds_read_u16 %3, %23 offset:16\n\tds_read_u16 %4, %23 offset:160\n\tds_read_u16 %5, %23 offset:304\n\t"
+            "ds_read_b128 %1, %21\n\tds_read_u16 %6, %24 offset:16\n\tds_read_u16 %7, %24 offset:160\n\tds_read_u16 %8, %24 offset:304\n\t"
+            "ds_read_b128 %2, %22\n\tds_read_u16 %9, %25 offset:16\n\tds_read_u16 %10, %25 offset:160\n\tds_read_u16 %11, %25 offset:304\n\t"
             "ds_read_b128 %12, %26\n\tds_read_b128 %13, %26 offset:1024\n\tds_read_b128 %14, %26 offset:2048\n\tds_read_b128 %15, %26 offset:3072\n\t"
             "ds_read_b128 %16, %27\n\tds_read_b128 %17, %27 offset:64\n\tds_read_b128 %18, %27 offset:128\n\tds_read_b128 %19, %27 offset:192\n\t"
             "s_waitcnt lgkmcnt(0)"

@@ -26,6 +26,9 @@ struct GemmArgs {
     int a_mode, out_mode;
     int H, W, Cin;  // conv geometry (square-agnostic; H, W even)
     int wg_cap;             // > 0: at most this many workgroups (gemm_8p.hip / conv64.hip walk the tiles persistently)
+    int *tile_ctr;          // capped grids only: 8 zeroed ints = per-XCD work queues -- workgroups PULL tiles (8 i + queue) instead of
+                            // walking a fixed share, so one that starts late (its CU still busy with another stream's kernel) does
+                            // fewer tiles instead of stretching the whole launch; NULL = static round-robin walk
     int dbg;                // kernel-development ablation flags (LRCN_DBG env): 1 = skip steady-state DMA, 2 = skip LDS reads + MFMA
     const void *zero_page;  // >= 256 zero bytes, 16-byte aligned (source of padding rows for the direct-to-LDS path) or NULL
     void *ws;               // split-K workspace (f32 slabs [slices][M][N]) or NULL: enables gemm_8p's split-K form

@@ -596,9 +596,55 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
     const int ntiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    if (g.tile_ctr == nullptr || gridDim.y > 1) {
+        for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+            gemm8p_tile<WM, WN, MT, NT, AMODE, SWAP, F8>(g, smem, tile, ntiles);
+            if (tile + (int)gridDim.x < ntiles) __syncthreads();  // the staged output tile / ring are reused by the next tile
+        }
+        return;
+    }
+    // Dynamic tile scheduling for the capped persistent grids of the two-stream training step.  Queue q = the tiles {8 i + q}
+    // (the ids that the XCD renumbering in gemm8p_tile keeps on one XCD's L2); a workgroup pulls from queue blockIdx.x & 7 and,
+    // once that is empty, from the others.  The pull for the NEXT tile is issued before the current tile's arithmetic, so its
+    // latency is hidden; over-claiming costs at most one tile at the tail.  Every workgroup leaves when all queues are empty.
+    // The claimed tile id travels from lane 0 to the other seven waves through a per-workgroup GLOBAL slot (two slots, used
+    // alternately; tile_ctr[8 + 2 blockIdx.x + parity]): the 512 x 128 configuration uses all 160 KiB of LDS, there is no
+    // byte to spare for a broadcast word.
+    auto pull = [&]() -> int {  // one lane
+        const int q0 = blockIdx.x & 7;
+        for (int k = 0; k < 8; ++k) {
+            const int q = (q0 + k) & 7;
+            const int nq = (ntiles - q + 7) >> 3;
+            if (nq <= 0) continue;
+            const int i = atomicAdd(g.tile_ctr + q, 1);
+            if (i < nq) return 8 * i + q;
+        }
+        return -1;
+    };
+    // Both sides are RELAXED device-scope atomics (they execute at the XCD's L2, which both waves of one CU share): an
+    // acquire / release pair here would invalidate L1 and write back L2 once per tile -- measured 25 % slower on the whole stack.
+    // Ordering: lane 0's exchange has returned before it reaches the end-of-tile barrier; the readers come after it.
+    int *slot = g.tile_ctr + 8 + 2 * blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    auto publish = [&](int *p) {  // lane 0 of wave 0
+        const int old = __hip_atomic_exchange(p, pull(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::"v"(old) : "memory");
+    };
+    auto fetch = [&](int *p) -> int {  // one atomic per wave, broadcast to its lanes
+        int t = 0;
+        if (lane == 0) t = __hip_atomic_fetch_add(p, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return __builtin_amdgcn_readfirstlane(t);
+    };
+    int par = 0;
+    if (threadIdx.x == 0) publish(slot);
+    __syncthreads();
+    int tile = fetch(slot);
+    while (tile >= 0) {
+        par ^= 1;
+        if (threadIdx.x == 0) publish(slot + par);  // the NEXT tile: its latency hides under this tile's prologue
         gemm8p_tile<WM, WN, MT, NT, AMODE, SWAP, F8>(g, smem, tile, ntiles);
-        if (tile + (int)gridDim.x < ntiles) __syncthreads();  // the staged output tile / ring are reused by the next tile
+        __syncthreads();  // the staged output tile / ring are free again; lane 0's exchange precedes every wave's fetch
+        tile = fetch(slot + par);
     }
 }
 
@@ -613,7 +659,9 @@ template <int WM, int WN, int MT, int NT, int AMODE, bool SWAP, bool F8 = false>
     const int64_t blocks = (int64_t)cdiv(g.M, BM) * cdiv(g.N, BN);
     if (blocks <= 0 || blocks > 0x7FFFFFFF) return hipErrorInvalidValue;
     int64_t grid = blocks;
-    if (g.wg_cap >= 8 && grid > g.wg_cap) {
+    if (g.wg_cap >= 8 && grid > g.wg_cap && g.tile_ctr && splitk == 1) {
+        grid = g.wg_cap & ~7;  // workgroups pull tiles from the per-XCD queues: no reason to launch fewer than the cap
+    } else if (g.wg_cap >= 8 && grid > g.wg_cap) {
         // the fewest workgroups that still finish in ceil(tiles / cap) rounds (conv5 at 256 images: 392 tiles, cap 224 -> two
         // rounds either way, 200 workgroups instead of 224), as a multiple of 8 so that tile -> XCD stays stable
         const int64_t cap = g.wg_cap & ~7, rounds = (blocks + cap - 1) / cap;

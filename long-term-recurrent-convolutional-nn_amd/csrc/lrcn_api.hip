@@ -111,6 +111,7 @@ struct lrcn_ctx {
     int img_meta_cap = 0;
     float *pre_f32 = nullptr;
     // data parallelism: RCCL communicator (lrcn_comm_init) and one stream per gradient group for [all-reduce -> Adam]
+    int *tile_ctr = nullptr;  // per-layer work queues of the capped persistent convolution grids (GemmArgs::tile_ctr)
     LrcnComm *comm = nullptr;
     hipStream_t bucket[LRCN_GRAD_GROUPS] = {};
     hipEvent_t bucket_done[LRCN_GRAD_GROUPS] = {};
@@ -1256,7 +1257,9 @@ bool conv64_enabled() {
     return !(k && k[0] == '0');
 }
 // f8_inv_scale > 0: write e4m3(out * f8_inv_scale) if the layer's kernel can (returns *wrote_f8), else bf16 as usual
-int conv_layer(lrcn_ctx *c, int dtype, const void *in, const VggLayer &L, int N, void *out, float f8_inv_scale = 0.0f, bool *wrote_f8 = nullptr) {
+constexpr int kTileCtrStride = 8 + 2 * 512;  // ints per layer: 8 queue heads + two hand-off slots per workgroup (<= 512 workgroups)
+int conv_layer(lrcn_ctx *c, int dtype, const void *in, const VggLayer &L, int N, void *out, float f8_inv_scale = 0.0f, bool *wrote_f8 = nullptr,
+               int *tile_ctr = nullptr) {
     if (wrote_f8) *wrote_f8 = false;
     if (conv64_enabled() && conv64_eligible(dtype, L.Cin, L.Cout, L.S, L.S)) {
         const bool f8 = f8_inv_scale > 0.0f && !L.pool;
@@ -1285,13 +1288,14 @@ int conv_layer(lrcn_ctx *c, int dtype, const void *in, const VggLayer &L, int N,
     g.ws = c->vgg_ws;  // one split-K workspace per stream: the VGG forward may run beside the LSTM step (gemm_ws)
     g.ws_bytes = c->vgg_ws ? c->gemm_ws_bytes : 0;
     g.wg_cap = c->vgg_wg_cap;
+    g.tile_ctr = (c->vgg_wg_cap >= 8 && c->vgg_wg_cap <= 512) ? tile_ctr : nullptr;
     hipError_t e = launch_gemm(c->stream, g);
     if (e != hipSuccess) FAIL(c, LRCN_EHIP, "conv layer S=%d Cin=%d Cout=%d: %s", L.S, L.Cin, L.Cout, hipGetErrorString(e));
     return LRCN_OK;
 }
 
 // e4m3 in -> e4m3 out (lrcn.jl:724-728 conv4 .+ b, relu, pool at reduced precision; scales from lrcn_vgg_calibrate)
-int conv_layer_fp8(lrcn_ctx *c, const void *in, const VggLayer &L, int N, void *out) {
+int conv_layer_fp8(lrcn_ctx *c, const void *in, const VggLayer &L, int N, void *out, int *tile_ctr = nullptr) {
     GemmArgs g{};
     g.dtype = GEMM_T_F8;
     g.A = in;
@@ -1311,6 +1315,7 @@ int conv_layer_fp8(lrcn_ctx *c, const void *in, const VggLayer &L, int N, void *
     g.Cin = L.Cin;
     g.zero_page = c->zero_page;
     g.wg_cap = c->vgg_wg_cap;
+    g.tile_ctr = (c->vgg_wg_cap >= 8 && c->vgg_wg_cap <= 512) ? tile_ctr : nullptr;
     hipError_t e = launch_gemm(c->stream, g);
     if (e != hipSuccess) FAIL(c, LRCN_EHIP, "fp8 conv layer S=%d Cin=%d Cout=%d: %s", L.S, L.Cin, L.Cout, hipGetErrorString(e));
     return LRCN_OK;
@@ -1373,6 +1378,19 @@ int vgg_body(lrcn_ctx *c, int N, const void *src, bool src_u8, const float *mean
     }
     if (!fuse11) note(vdt == GEMM_T_BF16 ? "conv11" : gemm_debug_last_route());
     void *cur = c->actA, *nxt = c->actB;
+    // capped persistent grids (the two-stream training step): LRCN_DYN_TILES=1 makes the workgroups of a layer PULL their tiles
+    // from per-XCD queues instead of walking static round-robin shares.  Measured and left off: the hypothesis was that a
+    // workgroup starting late (its CU still held by an LSTM-stream kernel) stretches the whole launch; pulling costs 2 % alone
+    // (6.59 -> 6.74 ms per forward at cap 224) and gains nothing in the step (7.54 -> 7.64 ms) -- the contention is not tail imbalance.
+    int *ctr = nullptr;
+    {
+        static const char *kd = getenv("LRCN_DYN_TILES");
+        if (c->vgg_wg_cap >= 8 && kd && kd[0] == '1') {
+            if (!c->tile_ctr) DALLOC(c, c->tile_ctr, sizeof(int) * 13 * kTileCtrStride);
+            HIPCHK(c, hipMemsetAsync(c->tile_ctr, 0, sizeof(int) * 13 * kTileCtrStride, c->stream));
+            ctr = c->tile_ctr;
+        }
+    }
     std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
     if (c->prof) {
         if (c->prof_used == c->prof_ev.size()) {
@@ -1406,9 +1424,10 @@ int vgg_body(lrcn_ctx *c, int N, const void *src, bool src_u8, const float *mean
         }
         int r;
         if (fp8 && l >= kFp8First)
-            r = conv_layer_fp8(c, cur, c->conv[l], N, nxt);
+            r = conv_layer_fp8(c, cur, c->conv[l], N, nxt, ctr ? ctr + l * kTileCtrStride : nullptr);
         else  // conv2_1 writes the e4m3 input of conv2_2 directly when it runs on conv64.hip
-            r = conv_layer(c, vdt, cur, c->conv[l], N, nxt, (fp8 && l == kFp8First - 1) ? 1.0f / c->act_scale[l] : 0.0f, &in_is_f8);
+            r = conv_layer(c, vdt, cur, c->conv[l], N, nxt, (fp8 && l == kFp8First - 1) ? 1.0f / c->act_scale[l] : 0.0f, &in_is_f8,
+                           ctr ? ctr + l * kTileCtrStride : nullptr);
         if (r) return r;
         note(gemm_debug_last_route());
         std::swap(cur, nxt);
