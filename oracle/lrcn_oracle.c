@@ -49,6 +49,54 @@ static float *fzeros(size_t n) {
  * ------------------------------------------------------------------------------------------------ */
 static void gemm_cm(int tA, int tB, int M, int N, int K, const float *A, int lda, const float *B, int ldb,
                     float beta, float *C, int ldc) {
+#ifdef ORC_FAST_GEMM
+    /* Timed CPU-baseline build only: the two operand orders that the plain loops below walk with long strides or as
+     * millions of 16-element dot products (the reverse pass of every timestep) are re-ordered so that the inner loop streams
+     * contiguous memory.  Same sums, float accumulation; the checker build keeps the plain loops. */
+    if (!tA && tB) { /* C(m,n) = sum_k A(m,k) B(n,k): rank-1 updates over k on a block of 64 columns that stays in L1 */
+#pragma omp parallel for schedule(static)
+        for (int n0 = 0; n0 < N; n0 += 64) {
+            const int nn = N - n0 < 64 ? N - n0 : 64;
+            for (int n = 0; n < nn; ++n) {
+                float *c = &CM(C, ldc, 0, n0 + n);
+                if (beta == 0.0f)
+                    for (int m = 0; m < M; ++m) c[m] = 0.0f;
+                else if (beta != 1.0f)
+                    for (int m = 0; m < M; ++m) c[m] *= beta;
+            }
+            for (int k = 0; k < K; ++k) {
+                const float *a = &CM(A, lda, 0, k), *b = &CM(B, ldb, n0, k);
+                for (int n = 0; n < nn; ++n) {
+                    const float bkn = b[n];
+                    float *c = &CM(C, ldc, 0, n0 + n);
+                    for (int m = 0; m < M; ++m) c[m] += a[m] * bkn;
+                }
+            }
+        }
+        return;
+    }
+    if (tA && !tB && K <= 256) { /* C(m,n) = sum_k A(k,m) B(k,n), short K: transpose A once, then K axpys of length M per column */
+        float *At = (float *)xmalloc(sizeof(float) * (size_t)K * M);
+#pragma omp parallel for schedule(static)
+        for (int m = 0; m < M; ++m)
+            for (int k = 0; k < K; ++k) At[(size_t)k * M + m] = CM(A, lda, k, m);
+#pragma omp parallel for schedule(static)
+        for (int n = 0; n < N; ++n) {
+            float *c = &CM(C, ldc, 0, n);
+            if (beta == 0.0f)
+                for (int m = 0; m < M; ++m) c[m] = 0.0f;
+            else if (beta != 1.0f)
+                for (int m = 0; m < M; ++m) c[m] *= beta;
+            for (int k = 0; k < K; ++k) {
+                const float bkn = CM(B, ldb, k, n);
+                const float *a = At + (size_t)k * M;
+                for (int m = 0; m < M; ++m) c[m] += a[m] * bkn;
+            }
+        }
+        free(At);
+        return;
+    }
+#endif
     if (!tA) {
 #pragma omp parallel
         {
@@ -709,8 +757,87 @@ const int orc_vgg_pool_after[13] = {0, 1, 0, 1, 0, 0, 1, 0, 0, 1, 0, 0, 1};
 
 /* convx(x,w) = conv4(w[1], x; padding=1, mode=1) .+ w[2]   (lrcn.jl:724); mode=1 = cross-correlation:
  *   y(i,j,co,n) = b(co) + sum_{a,b,ci} x(i+a-1, j+b-1, ci, n) * w(a,b,ci,co),  a,b in 0..2, zero padding. */
+#ifdef ORC_FAST_GEMM
+/* The timed CPU baseline build (liblrcn_oracle_f32.so) runs convx as what a CPU library would: im2col of a block of
+ * pixels + a register-blocked SGEMM (4 output channels x 32 pixels of accumulators in AVX2 registers, GCC vector extensions),
+ * OpenMP over (image, pixel block, channel block).  Same arithmetic as the direct loop below (lrcn.jl:724), float accumulation,
+ * another summation order; tests/test_oracle_golden.py checks the two against each other.  The CHECKER build never uses it. */
+typedef float v8f __attribute__((vector_size(32), aligned(4)));
+#define FG_PB 128 /* pixels per block  */
+#define FG_CB 128 /* output channels per block */
+#define FG_KB 288 /* contraction block = 32 input channels x 9 taps */
+static void conv3x3_fast(const float *x, int W, int H, int Cin, int N, const float *w, const float *b, int Cout, int relu, float *y) {
+    const int P = W * H, K = 9 * Cin;
+    const int npb = (P + FG_PB - 1) / FG_PB, ncb = (Cout + FG_CB - 1) / FG_CB;
+    const long ntask = (long)N * npb * ncb;
+#pragma omp parallel
+    {
+        float *col = (float *)xmalloc(sizeof(float) * FG_KB * FG_PB);
+        float *cblk = (float *)xmalloc(sizeof(float) * FG_CB * FG_PB);
+#pragma omp for schedule(dynamic, 1)
+        for (long t = 0; t < ntask; ++t) {
+            const int cb = (int)(t % ncb), pb = (int)((t / ncb) % npb), n = (int)(t / ((long)ncb * npb));
+            const int p0 = pb * FG_PB, pn = P - p0 < FG_PB ? P - p0 : FG_PB;
+            const int c0 = cb * FG_CB, cn = Cout - c0 < FG_CB ? Cout - c0 : FG_CB;
+            for (int c = 0; c < cn; ++c)
+                for (int p = 0; p < FG_PB; ++p) cblk[c * FG_PB + p] = b[c0 + c];
+            for (int k0 = 0; k0 < K; k0 += FG_KB) {
+                const int kn = K - k0 < FG_KB ? K - k0 : FG_KB;
+                /* im2col: col[k][p] = x(i + a - 1, j + bb - 1, ci, n), zero outside; k = a + 3 bb + 9 ci (the weight's own order) */
+                for (int k = 0; k < kn; ++k) {
+                    const int kk = k0 + k, ci = kk / 9, bb = (kk % 9) / 3, a = kk % 3;
+                    const float *xp = x + ((size_t)n * Cin + ci) * P;
+                    float *cr = col + (size_t)k * FG_PB;
+                    for (int p = 0; p < FG_PB; ++p) {
+                        float v = 0.0f;
+                        if (p < pn) {
+                            const int pp = p0 + p, j = pp / W + bb - 1, i = pp % W + a - 1;
+                            if ((unsigned)j < (unsigned)H && (unsigned)i < (unsigned)W) v = xp[(size_t)j * W + i];
+                        }
+                        cr[p] = v;
+                    }
+                }
+                /* cblk[c][p] += sum_k w(k, c0 + c) * col[k][p]: 4 channels x 32 pixels per register tile */
+                for (int c = 0; c < cn; c += 4) {
+                    const int cr4 = cn - c < 4 ? cn - c : 4;
+                    const float *w0 = w + (size_t)(c0 + c) * K + k0;
+                    const float *w1 = cr4 > 1 ? w0 + K : w0, *w2 = cr4 > 2 ? w0 + 2 * (size_t)K : w0, *w3 = cr4 > 3 ? w0 + 3 * (size_t)K : w0;
+                    for (int p = 0; p < FG_PB; p += 32) {
+                        v8f acc[4][4];
+                        for (int r = 0; r < 4; ++r)
+                            for (int q = 0; q < 4; ++q) acc[r][q] = *(const v8f *)(cblk + (size_t)(c + (r < cr4 ? r : 0)) * FG_PB + p + 8 * q);
+                        for (int k = 0; k < kn; ++k) {
+                            const float *cp = col + (size_t)k * FG_PB + p;
+                            const v8f b0 = *(const v8f *)cp, b1 = *(const v8f *)(cp + 8), b2 = *(const v8f *)(cp + 16), b3 = *(const v8f *)(cp + 24);
+                            const float a0 = w0[k], a1 = w1[k], a2 = w2[k], a3 = w3[k];
+                            acc[0][0] += a0 * b0; acc[0][1] += a0 * b1; acc[0][2] += a0 * b2; acc[0][3] += a0 * b3;
+                            acc[1][0] += a1 * b0; acc[1][1] += a1 * b1; acc[1][2] += a1 * b2; acc[1][3] += a1 * b3;
+                            acc[2][0] += a2 * b0; acc[2][1] += a2 * b1; acc[2][2] += a2 * b2; acc[2][3] += a2 * b3;
+                            acc[3][0] += a3 * b0; acc[3][1] += a3 * b1; acc[3][2] += a3 * b2; acc[3][3] += a3 * b3;
+                        }
+                        for (int r = 0; r < cr4; ++r)
+                            for (int q = 0; q < 4; ++q) *(v8f *)(cblk + (size_t)(c + r) * FG_PB + p + 8 * q) = acc[r][q];
+                    }
+                }
+            }
+            for (int c = 0; c < cn; ++c) {
+                float *yp = y + ((size_t)n * Cout + c0 + c) * P + p0;
+                const float *sp = cblk + (size_t)c * FG_PB;
+                for (int p = 0; p < pn; ++p) yp[p] = (relu && sp[p] < 0.0f) ? 0.0f : sp[p];
+            }
+        }
+        free(col);
+        free(cblk);
+    }
+}
+#endif
+
 void orc_conv3x3(const float *x, int W, int H, int Cin, int N, const float *w, const float *b, int Cout,
                  int relu, float *y) {
+#ifdef ORC_FAST_GEMM
+    conv3x3_fast(x, W, H, Cin, N, w, b, Cout, relu, y);
+    return;
+#endif
     const size_t plane = (size_t)W * H;
 #pragma omp parallel
     {

@@ -180,3 +180,30 @@ def test_oracle_sanitizer_build_runs_clean():
     r = subprocess.run(["make", "-s", "-C", here, "-f", os.path.join(here, "Makefile"), "asan"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "oracle selftest ok" in r.stdout
+
+
+def test_fast_baseline_build_matches_the_checker_build():
+    # liblrcn_oracle_f32.so (bench.py's timed cpu_baseline: float accumulation, convolutions as im2col + blocked SGEMM, re-ordered
+    # reverse-pass GEMMs) against the double-accumulating checker on the same inputs: same arithmetic, another summation order
+    import ctypes as C
+    if not orc._has_avx2():
+        pytest.skip("no AVX2/FMA: the fast build is not used on this host")
+    rng = np.random.default_rng(3)
+    for S, Cin, Cout, N in [(14, 64, 72, 2), (10, 3, 64, 1), (30, 40, 130, 1)]:   # pixel-block, channel-block and K-block tails
+        x = rng.standard_normal((S, S, Cin, N)).astype(np.float32)
+        w = (rng.standard_normal((3, 3, Cin, Cout)) * 0.1).astype(np.float32)
+        b = rng.standard_normal(Cout).astype(np.float32)
+        ref = orc.conv3x3(x, w, b, relu=True)
+        xf, wf, bf = orc.fa(x), orc.fa(w), orc.fa(b)
+        y = np.zeros((S, S, Cout, N), np.float32, order="F")
+        orc.lib(True).orc_conv3x3(orc._f(xf), S, S, Cin, N, orc._f(wf), orc._f(bf), Cout, 1, orc._f(y))
+        assert np.abs(y - ref).max() <= 1e-5 * np.abs(ref).max()
+    E, H1, H2, V, B, T = 24, 40, 32, 97, 5, 4
+    m = orc.init_weights(E, H1, H2, V, seed=2)
+    feats = (rng.standard_normal((B, 4096)) * 0.05).astype(np.float32)
+    tokens = rng.integers(0, V, size=(T, B)).astype(np.int32)
+    l0, g0 = orc.loss(m, feats, tokens, want_grad=True)
+    l1, g1 = orc.loss(m, feats, tokens, want_grad=True, fast=True)
+    assert abs(l1 - l0) <= 1e-6 * abs(l0)
+    for n in orc.PARAM_NAMES:
+        np.testing.assert_allclose(g1.p[n], g0.p[n], rtol=1e-3, atol=1e-6, err_msg=n)
