@@ -12,6 +12,7 @@ const lib = get(ENV, "LRCN_HIP_LIB", "liblrcn_hip.so")
 struct Config
     device::Cint; E::Cint; H1::Cint; H2::Cint; V::Cint
     max_B::Cint; max_T::Cint; lstm_dtype::Cint; vgg_dtype::Cint; max_images::Cint
+    n_layers::Cint      # 0 / 2: lrcn.jl's two-layer model; 1: LRCN-1f (include/lrcn.h)
 end
 struct Dropout
     pdrop::Cfloat; seed::UInt64; mask1::Ptr{Cfloat}; mask2::Ptr{Cfloat}
@@ -29,7 +30,7 @@ function check(ctx, rc)
 end
 
 function Context(; device=0, embed=1000, hidden=[1000, 1000], vocab, batchsize=25, maxlen=28, dtype=BF16, images=0)
-    cfg = Ref(Config(device, embed, hidden[1], hidden[2], vocab, batchsize, maxlen, dtype, dtype, images))
+    cfg = Ref(Config(device, embed, hidden[1], hidden[end], vocab, batchsize, maxlen, dtype, dtype, images, length(hidden)))
     out = Ref{Ptr{Cvoid}}(C_NULL)
     check(nothing, ccall((:lrcn_create, lib), Cint, (Ref{Config}, Ref{Ptr{Cvoid}}), cfg, out))
     ctx = Context(out[])
@@ -124,5 +125,41 @@ adam_update_group(ctx, param, grads, mom, var, group, step; lr = 0.001f0, b1 = 0
 # vgg_dtype = LRCN_FP8 contexts: fix the e4m3 activation scales from one bf16 pass over uint8 crops img[c, col, row, n]   (new entry point)
 vgg_calibrate(ctx, img, mean::Vector{Cfloat}; margin = 1.25f0) = check(ctx, ccall((:lrcn_vgg_calibrate, lib), Cint,
     (Ptr{Cvoid}, Ptr{UInt8}, Cint, Ptr{Cfloat}, Cfloat), ctx.h, pointer(img), size(img, 4), mean, margin))
+
+# ---- image front end (lrcn.jl:750-773): decoded images of any size -> uint8 crops [3, 224, 224, N] on the device ----
+# src: device buffer with the N images back to back (row-major [h][w][c] bytes); offsets / heights / widths / channels: host vectors
+resize_crop(ctx, src, offsets::Vector{Int64}, heights::Vector{Cint}, widths::Vector{Cint}, channels::Vector{Cint}, out) =
+    check(ctx, ccall((:lrcn_resize_crop_u8, lib), Cint,
+        (Ptr{Cvoid}, Ptr{UInt8}, Ptr{Int64}, Ptr{Cint}, Ptr{Cint}, Ptr{Cint}, Cint, Ptr{UInt8}),
+        ctx.h, pointer(src), offsets, heights, widths, channels, length(offsets), pointer(out)))
+# the full averageImage of lrcn.jl:113 (device array (224,224,3)); afterwards the *_u8 calls take mean = C_NULL
+set_average_image(ctx, avg) = check(ctx, ccall((:lrcn_set_average_image, lib), Cint, (Ptr{Cvoid}, Ptr{Cfloat}), ctx.h, pointer(avg)))
+# input / sum(input) per row (lrcn.jl:595-597), in place
+normalize_features(ctx, feats) = check(ctx, ccall((:lrcn_normalize_features, lib), Cint, (Ptr{Cvoid}, Ptr{Cfloat}, Cint), ctx.h, pointer(feats), size(feats, 1)))
+
+# ---- data parallelism over the GPUs of a node: one Julia process (or task) + one Context per GPU ----
+# rank 0: id = comm_unique_id(); ship the 128 bytes to the other ranks (Distributed.jl, a file, MPI ...); every rank: comm_init
+function comm_unique_id()
+    id = Vector{UInt8}(undef, 128)
+    rc = ccall((:lrcn_comm_unique_id, lib), Cint, (Ptr{UInt8},), id)
+    rc == 0 || check(nothing, rc)
+    id
+end
+comm_init(ctx, world, rank, id::Vector{UInt8}) = check(ctx, ccall((:lrcn_comm_init, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{UInt8}), ctx.h, world, rank, id))
+allreduce_grads(ctx, grads; group = -1) = check(ctx, ccall((:lrcn_allreduce_grads, lib), Cint, (Ptr{Cvoid}, Ptr{Ptr{Cfloat}}, Cint), ctx.h, ptrs(grads), group))
+comm_join(ctx) = check(ctx, ccall((:lrcn_comm_join, lib), Cint, (Ptr{Cvoid},), ctx.h))
+
+# The body of train1's loop (lrcn.jl:369-394) on this rank's rows in ONE call: [VGG-16 forward of img (uint8 crops) -> feats]
+# + lossgradient + per-group all-reduce over the ranks + per-group Adam.  batchsize = the GLOBAL batch (lrcn.jl:564-568).
+function train_step_dp(ctx, param, grads, mom, var, feats, tokens, T, B, step; img = nothing, mean = Cfloat[123.68, 116.779, 103.939],
+                       normalize = true, batchsize = B, pdrop = 0.4, seed = step, lr = 1f-3, beta1 = 0.9f0, beta2 = 0.999f0, eps = 1f-8)
+    d = Ref(Dropout(pdrop, seed, C_NULL, C_NULL)); out = Ref{Cdouble}(0)
+    check(ctx, ccall((:lrcn_train_step_dp, lib), Cint,
+        (Ptr{Cvoid}, Ptr{Ptr{Cfloat}}, Ptr{Ptr{Cfloat}}, Ptr{Ptr{Cfloat}}, Ptr{Ptr{Cfloat}}, Ptr{UInt8}, Ptr{Cfloat}, Cint, Ptr{Cfloat}, Ptr{Int32},
+         Cint, Cint, Cint, Ref{Dropout}, Cint, Cfloat, Cfloat, Cfloat, Cfloat, Ref{Cdouble}),
+        ctx.h, ptrs(param), ptrs(grads), ptrs(mom), ptrs(var), img === nothing ? Ptr{UInt8}(C_NULL) : Ptr{UInt8}(pointer(img)), mean,
+        normalize ? 1 : 0, pointer(feats), pointer(tokens), T, B, batchsize, d, step, lr, beta1, beta2, eps, out))
+    out[]
+end
 
 end # module

@@ -113,7 +113,9 @@ struct lrcn_ctx {
     // data parallelism: RCCL communicator (lrcn_comm_init) and one stream per gradient group for [all-reduce -> Adam]
     int *tile_ctr = nullptr;  // per-layer work queues of the capped persistent convolution grids (GemmArgs::tile_ctr)
     LrcnComm *comm = nullptr;
+    hipStream_t comm_stream = nullptr;  // every collective of the communicator is issued on this ONE stream, in group order
     hipStream_t bucket[LRCN_GRAD_GROUPS] = {};
+    hipEvent_t ar_done[LRCN_GRAD_GROUPS] = {};
     hipEvent_t bucket_done[LRCN_GRAD_GROUPS] = {};
     bool bucket_pending[LRCN_GRAD_GROUPS] = {};
 };
@@ -586,8 +588,11 @@ void lrcn_destroy(lrcn_ctx *c) {
     comm_destroy(c->comm);
     for (auto &e : c->bucket_done)
         if (e) (void)hipEventDestroy(e);
+    for (auto &e : c->ar_done)
+        if (e) (void)hipEventDestroy(e);
     for (auto &b : c->bucket)
         if (b) (void)hipStreamDestroy(b);
+    if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
     for (auto &e : c->prof_ev) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
@@ -866,19 +871,23 @@ bool dp_force_pipeline() {
 }
 
 int ensure_buckets(lrcn_ctx *c) {
+    if (!c->comm_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
     for (int g = 0; g < LRCN_GRAD_GROUPS; ++g) {
         if (!c->bucket[g]) HIPCHK(c, hipStreamCreateWithFlags(&c->bucket[g], hipStreamNonBlocking));
         if (!c->bucket_done[g]) HIPCHK(c, hipEventCreateWithFlags(&c->bucket_done[g], hipEventDisableTiming));
+        if (!c->ar_done[g]) HIPCHK(c, hipEventCreateWithFlags(&c->ar_done[g], hipEventDisableTiming));
     }
     return LRCN_OK;
 }
 
-// bucket stream of `group`: wait for the group's gradient-ready event, then all-reduce its tensors in place (one collective when
-// they are adjacent in memory, which they are in a flat gradient buffer)
+// The communicator's stream waits for the group's gradient-ready event and all-reduces the group's tensors in place (one collective
+// when they are adjacent in memory, which they are in a flat gradient buffer); the group's own stream -- on which the caller may
+// queue that group's Adam -- waits for the collective.  One stream for all collectives: the same issue order on every rank, no
+// concurrent use of one communicator from several streams.
 int allreduce_group(lrcn_ctx *c, float *const grads[9], int group) {
     int64_t sz[9];
     ctx_sizes(c, sz);
-    hipStream_t s = c->bucket[group];
+    hipStream_t s = c->comm_stream;
     HIPCHK(c, hipStreamWaitEvent(s, c->grad_ev[group], 0));
     if (c->comm && (comm_world(c->comm) > 1 || dp_force_pipeline())) {
         char err[256] = "";
@@ -898,6 +907,8 @@ int allreduce_group(lrcn_ctx *c, float *const grads[9], int group) {
         }
         if (rc) FAIL(c, LRCN_EHIP, "%s", err);
     }
+    HIPCHK(c, hipEventRecord(c->ar_done[group], s));
+    HIPCHK(c, hipStreamWaitEvent(c->bucket[group], c->ar_done[group], 0));
     c->bucket_pending[group] = true;
     return LRCN_OK;
 }
