@@ -34,8 +34,9 @@ class _Vgg(C.Structure):
 
 def build(force=False):
     """Compile the oracle's shared libraries (gcc). Building the checker is not using it."""
-    libs = [os.path.join(HERE, n) for n in ("liblrcn_oracle.so", "liblrcn_oracle_f32.so")]
-    src = [os.path.join(HERE, n) for n in ("lrcn_oracle.c", "lrcn_oracle.h")]
+    libs = [os.path.join(HERE, n) for n in ("liblrcn_oracle.so", "liblrcn_oracle_f32.so", "liblrcn_cpu.so")]
+    src = [os.path.join(HERE, n) for n in ("lrcn_oracle.c", "lrcn_oracle.h", "lrcn_cpu_abi.c", "Makefile")] + [
+        os.path.join(HERE, "..", "include", "lrcn.h")]
     stale = force or any(
         not os.path.exists(l) or os.path.getmtime(l) < max(os.path.getmtime(s) for s in src) for l in libs)
     if stale:
