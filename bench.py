@@ -51,6 +51,8 @@ def cpu_baseline(vgg_w, E, H, V, T, rng, n_layers=2):
     from oracle import oracle as orc
     conv_w, conv_b, fc6, fc7 = vgg_w
     n_img, n_cap = 8, 16
+    ncpu = orc.effective_cpus()       # the container's CPU share, not the host's core count
+    orc.set_num_threads(ncpu)
     img = rng.integers(0, 256, size=(n_img, 224, 224, 3), dtype=np.uint8)
     x = orc.preprocess_u8(img, (123.68, 116.779, 103.939))
     t0 = time.time()
@@ -62,7 +64,7 @@ def cpu_baseline(vgg_w, E, H, V, T, rng, n_layers=2):
     t0 = time.time()
     ref_loss, ref_g = orc.loss(m, feats, tokens, want_grad=True, fast=True)
     t_lstm = (time.time() - t0) / n_cap
-    base = {"value": 1.0 / (t_vgg + t_lstm), "unit": "images/sec", "cores": orc.num_threads(), "kind": "port",
+    base = {"value": 1.0 / (t_vgg + t_lstm), "unit": "images/sec", "cores": ncpu, "kind": "port",
             "sample": "oracle/lrcn_oracle.c, baseline build (float accumulate, OpenMP, convolutions as im2col + register-blocked AVX2 "
                       "SGEMM): VGG-16 fwd on %d images (%.3f s/img = %.0f GFLOP/s) + LSTM lossgradient on %d captions of T=%d "
                       "(%.3f s/caption); Adam excluded (<1%%)" % (n_img, t_vgg, 30.93 / max(t_vgg, 1e-9), n_cap, T, t_lstm)}

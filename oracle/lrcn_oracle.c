@@ -29,6 +29,13 @@ int orc_num_threads(void) {
     return 1;
 #endif
 }
+void orc_set_num_threads(int n) { /* a container's CPU share may be smaller than the machine's core count */
+#ifdef _OPENMP
+    if (n >= 1) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
 
 static void *xmalloc(size_t n) {
     void *p = malloc(n ? n : 1);

@@ -135,8 +135,9 @@ void orc_vgg_forward(const orc_vgg *v, const float *x, int S, int N, float *feat
  * out: (224,224,3,N) col-major with the H<->W swap of :771, out(i,j,c,n) = img(y=j? ...) see .c */
 void orc_preprocess_u8(const uint8_t *img, int S, int N, const float mean[3], float *out);
 
-/* Number of OpenMP threads the library will use. */
+/* Number of OpenMP threads the library will use / set it (e.g. to the container's CPU share). */
 int orc_num_threads(void);
+void orc_set_num_threads(int n);
 
 #ifdef __cplusplus
 }

@@ -101,6 +101,8 @@ def lib(fast=False):
         L.orc_preprocess_u8.restype = None
         L.orc_preprocess_u8.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.c_int, _fp, _fp]
         L.orc_num_threads.restype = C.c_int
+        L.orc_set_num_threads.restype = None
+        L.orc_set_num_threads.argtypes = [C.c_int]
         _LIBS[key] = L
     return _LIBS[key]
 
@@ -347,3 +349,29 @@ def resize_crop_u8(images, S=224):
 
 def num_threads():
     return lib().orc_num_threads()
+
+
+def effective_cpus():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (a GPU box hands a container a share
+    of the host's cores; OpenMP's default thread count is the host's)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
+def set_num_threads(n, fast=None):
+    for f in ((False, True) if fast is None else (fast,)):
+        lib(f).orc_set_num_threads(int(n))

@@ -1,0 +1,26 @@
+#!/bin/bash
+# usage (GPU box, repo root): tools/collect_profiles.sh <tag>     e.g. r02a
+# Produces under gpurun_out/profiles_<tag>/ what profiles/ keeps per round: the rocprofv3 kernel-trace --stats summary of bench.py,
+# the FETCH_SIZE and WRITE_SIZE PMC passes (separate runs, --kernel-trace only) reduced by tools/pmc_traffic.py, and the bench line.
+set -e
+tag=$1
+root=${GRAFT_REPO_ROOT:-$(pwd)}
+out=$root/gpurun_out/profiles_$tag
+rm -rf "$out"; mkdir -p "$out"
+cd "$root"
+python3 bench.py > "$out/bench_line.json" 2> "$out/bench.err" || { tail "$out/bench.err"; exit 1; }
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o p -- python3 "$root/bench.py" --steps 25 --warmup 5 --no-cpu-baseline > "$out/bench_under_rocprof.json" 2> "$out/stats.log"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/fetch" -o p -- python3 "$root/bench.py" --steps 8 --warmup 2 --no-cpu-baseline > /dev/null 2> "$out/fetch.log"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/write" -o p -- python3 "$root/bench.py" --steps 8 --warmup 2 --no-cpu-baseline > /dev/null 2> "$out/write.log"
+cd "$root"
+cp "$out"/stats/p_kernel_stats.csv "$out/kernel_stats.csv"
+python3 tools/pmc_traffic.py "$out"/fetch/p_counter_collection.csv "$out"/write/p_counter_collection.csv "$out/pmc_traffic.json" > /dev/null
+rm -rf "$out/stats" "$out/fetch" "$out/write"   # the raw traces are tens of MB; the summaries are what is kept
+tail -c 1200 "$out/bench_line.json"; echo; python3 - <<PY
+import csv
+rows=list(csv.DictReader(open("$out/kernel_stats.csv")))
+tot=sum(float(r['TotalDurationNs']) for r in rows)
+for r in rows[:12]: print("%-88s %5s calls %9.1f us avg %5.1f%%"%(r['Name'][:88], r['Calls'], float(r['AverageNs'])/1e3, 100*float(r['TotalDurationNs'])/tot))
+PY
+python3 -c "import json; d=json.load(open('$out/pmc_traffic.json')); print({k:v for k,v in d.items() if k!='per_kernel'})"
