@@ -43,33 +43,56 @@ def pmc_traffic(dtype, per_gpu_batch):
 
 
 def cpu_baseline(vgg_w, E, H, V, T, rng, n_layers=2):
-    """The oracle (kind "port": the reference is Julia/GPU-only and cannot run) timed on this box's host cores on a
-    bounded sample of the same workload: VGG forward on 4 images + lossgradient on 16 captions, float accumulation.
-    -> (cpu_baseline object, sample): the sample's inputs and the oracle's outputs, which main() pushes through the HIP
-    path afterwards (outside every timed region) for the `parity` spot-check of the same JSON line."""
+    """The CPU baseline (kind "port": the reference is Julia/GPU-only and cannot run): the SAME step through the SAME C ABI
+    (include/lrcn.h) on this box's host cores -- oracle/liblrcn_cpu_f32.so, the oracle's baseline build behind lrcn_vgg_forward_u8 +
+    lrcn_loss_grad -- on a bounded sample of the workload: 8 crops + 16 captions.  Threads = the container's CPU share.
+    -> (cpu_baseline object, sample): the sample's inputs and outputs, which main() pushes through the HIP path afterwards
+    (outside every timed region) for the `parity` spot-check of the same JSON line."""
+    import ctypes as C
     import numpy as np
+    from lrcn_amd import _lib
     from oracle import oracle as orc
     conv_w, conv_b, fc6, fc7 = vgg_w
     n_img, n_cap = 8, 16
     ncpu = orc.effective_cpus()       # the container's CPU share, not the host's core count
-    orc.set_num_threads(ncpu)
+    A = orc.cpu_abi(_lib.SIGNATURES, fast=True)
+    A.orc_set_num_threads(ncpu)
+    cfg = _lib.Config(0, E, H, H, V, n_cap, T, _lib.LRCN_F32, _lib.LRCN_F32, n_img, n_layers)
+    h = C.c_void_p()
+    assert A.lrcn_create(C.byref(cfg), C.byref(h)) == 0
+
+    def fp(a):
+        return a.ctypes.data_as(C.c_void_p)
+
+    keep = [orc.fa(a) for a in conv_w] + [orc.fa(a) for a in conv_b] + [orc.fa(fc6[0]), orc.fa(fc6[1]), orc.fa(fc7[0]), orc.fa(fc7[1])]
+    assert A.lrcn_vgg_load(h, _lib.P13(*[fp(a).value for a in keep[:13]]), _lib.P13(*[fp(a).value for a in keep[13:26]]), fp(keep[26]),
+                           fp(keep[27]), fp(keep[28]), fp(keep[29])) == 0
     img = rng.integers(0, 256, size=(n_img, 224, 224, 3), dtype=np.uint8)
-    x = orc.preprocess_u8(img, (123.68, 116.779, 103.939))
+    ref_feats = np.zeros((n_img, 4096), np.float32, order="F")
+    mean = (C.c_float * 3)(123.68, 116.779, 103.939)
     t0 = time.time()
-    ref_feats = orc.vgg_forward(conv_w, conv_b, fc6, fc7, x, fast=True)
+    assert A.lrcn_vgg_forward_u8(h, fp(img), n_img, mean, fp(ref_feats)) == 0
     t_vgg = (time.time() - t0) / n_img
     m = orc.init_weights(E, H, H, V, seed=42, n_layers=n_layers)
-    feats = (rng.standard_normal((n_cap, 4096)) * 0.01).astype(np.float32)
+    g = m.zeros_like()
+    feats = orc.fa((rng.standard_normal((n_cap, 4096)) * 0.01).astype(np.float32))
     tokens = rng.integers(3, V, size=(T, n_cap)).astype(np.int32)
+
+    def p9(mm):
+        return _lib.P9(*[fp(a).value if a.size else None for a in mm.arrays()])
+
+    out = C.c_double()
     t0 = time.time()
-    ref_loss, ref_g = orc.loss(m, feats, tokens, want_grad=True, fast=True)
+    assert A.lrcn_loss_grad(h, p9(m), fp(feats), fp(tokens), T, n_cap, n_cap, None, p9(g), C.byref(out)) == 0
     t_lstm = (time.time() - t0) / n_cap
+    A.lrcn_destroy(h)
     base = {"value": 1.0 / (t_vgg + t_lstm), "unit": "images/sec", "cores": ncpu, "kind": "port",
-            "sample": "oracle/lrcn_oracle.c, baseline build (float accumulate, OpenMP, convolutions as im2col + register-blocked AVX2 "
-                      "SGEMM): VGG-16 fwd on %d images (%.3f s/img = %.0f GFLOP/s) + LSTM lossgradient on %d captions of T=%d "
-                      "(%.3f s/caption); Adam excluded (<1%%)" % (n_img, t_vgg, 30.93 / max(t_vgg, 1e-9), n_cap, T, t_lstm)}
-    return base, {"img": img, "ref_feats": ref_feats, "model": m, "feats": feats, "tokens": tokens, "ref_loss": ref_loss,
-                  "ref_grads": ref_g}
+            "sample": "oracle/liblrcn_cpu_f32.so = include/lrcn.h on the host (oracle baseline build: float accumulate, OpenMP, "
+                      "convolutions as im2col + register-blocked AVX2 SGEMM): lrcn_vgg_forward_u8 on %d crops (%.3f s/img = %.0f GFLOP/s) + "
+                      "lrcn_loss_grad on %d captions of T=%d (%.3f s/caption); Adam excluded (<1%%); %d threads = the container's CPU "
+                      "share" % (n_img, t_vgg, 30.93 / max(t_vgg, 1e-9), n_cap, T, t_lstm, ncpu)}
+    return base, {"img": img, "ref_feats": ref_feats, "model": m, "feats": feats, "tokens": tokens, "ref_loss": out.value,
+                  "ref_grads": g}
 
 
 def parity_spot_check(ctx, L, sample, batch_imgs):
@@ -94,7 +117,7 @@ def parity_spot_check(ctx, L, sample, batch_imgs):
         cos.append(float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-300)))
     return {"vgg_rel_max_err": vgg_err, "n_images": int(ref.shape[0]), "vgg_routes": L.debug_route(ctx, 1),
             "loss_rel_err": float(abs(val - sample["ref_loss"]) / abs(sample["ref_loss"])), "n_captions": int(sample["tokens"].shape[1]),
-            "grad_cos_min": min(cos), "checker": "oracle/lrcn_oracle.c on the cpu_baseline sample"}
+            "grad_cos_min": min(cos), "checker": "oracle (liblrcn_cpu_f32.so) on the cpu_baseline sample"}
 
 
 def main():

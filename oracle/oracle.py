@@ -34,7 +34,7 @@ class _Vgg(C.Structure):
 
 def build(force=False):
     """Compile the oracle's shared libraries (gcc). Building the checker is not using it."""
-    libs = [os.path.join(HERE, n) for n in ("liblrcn_oracle.so", "liblrcn_oracle_f32.so", "liblrcn_cpu.so")]
+    libs = [os.path.join(HERE, n) for n in ("liblrcn_oracle.so", "liblrcn_oracle_f32.so", "liblrcn_cpu.so", "liblrcn_cpu_f32.so")]
     src = [os.path.join(HERE, n) for n in ("lrcn_oracle.c", "lrcn_oracle.h", "lrcn_cpu_abi.c", "Makefile")] + [
         os.path.join(HERE, "..", "include", "lrcn.h")]
     stale = force or any(
@@ -349,6 +349,22 @@ def resize_crop_u8(images, S=224):
 
 def num_threads():
     return lib().orc_num_threads()
+
+
+def cpu_abi(signatures, fast=False):
+    """liblrcn_cpu.so (fast=True: liblrcn_cpu_f32.so, the baseline build) bound with the product binding's own signature table
+    (lrcn_amd._lib.SIGNATURES): the C ABI of include/lrcn.h on the host."""
+    name = "liblrcn_cpu_f32.so" if (fast and _has_avx2()) else "liblrcn_cpu.so"
+    path = os.path.join(HERE, name)
+    if not os.path.exists(path):
+        build()
+    L = C.CDLL(path)
+    for n, (res, args) in signatures.items():
+        fn = getattr(L, n)
+        fn.restype, fn.argtypes = res, args
+    L.orc_set_num_threads.restype = None
+    L.orc_set_num_threads.argtypes = [C.c_int]
+    return L
 
 
 def effective_cpus():
