@@ -312,3 +312,30 @@ def test_adam_by_gradient_group_equals_one_launch():
     with pytest.raises(lrcn_amd.LrcnError):
         L.update_group(ctx, param, grads, optim, 5)
     ctx.close()
+
+
+@pytest.mark.parametrize("B", [24, 64, 160, 256])
+def test_recurrence_kernel_routes_by_batch_size_vs_oracle_bf16(B):
+    # The recurrent step takes a different kernel family per batch size: the fused GEMM + cell kernels of lstm_fused.hip with one
+    # row block (B <= 32: <2>), several blocks of 64 rows (B <= 128: <4>), and separate recurrent GEMM (gemm_glds / gemm_8p split-K)
+    # + cell launches above -- the route the B = 256 benchmark runs.  E = H = 256 keeps the oracle fast; dropout masks explicit.
+    rng = np.random.default_rng(B)
+    E = H = 256
+    V, T = 1000, 5
+    m = orc.init_weights(E, H, H, V, seed=7)
+    for n in ("W1", "W2", "Wout", "Wproj"):
+        m.p[n] *= 2.0   # gates well away from the linear regime, so that a wrong recurrence would show
+    feats = (rng.standard_normal((B, 4096)) * 0.05).astype(np.float32)
+    tokens = rng.integers(0, V, size=(T, B)).astype(np.int32)
+    mask1 = ((rng.random((T + 1, B, E)) > 0.3) / 0.7).astype(np.float32)
+    mask2 = ((rng.random((T + 1, B, H)) > 0.3) / 0.7).astype(np.float32)
+    ref_loss, ref_g = orc.loss(m, feats, tokens, mask1=mask1, mask2=mask2, want_grad=True)
+    ctx = L.Context(E, H, H, V, max_B=B, max_T=T, lstm_dtype=lrcn_amd.LRCN_BF16)
+    grads, val = L.lossgradient(ctx, L.model_from_arrays(m.p), L.to_jl(feats), tokens, mask1=mask1, mask2=mask2)
+    assert abs(val - ref_loss) <= 2e-2 * abs(ref_loss), (B, val, ref_loss)
+    for n, g in zip(orc.PARAM_NAMES, grads):
+        a, b = L.from_jl(g).ravel().astype(np.float64), ref_g.p[n].ravel().astype(np.float64)
+        cos = a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30)
+        rel = np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30)
+        assert cos > 0.995 and rel < 0.1, (B, n, cos, rel)
+    ctx.close()
