@@ -5,7 +5,27 @@
 #include <stdint.h>
 
 enum { GEMM_A_PLAIN = 0, GEMM_A_CONV3 = 1 };
-enum { GEMM_OUT_PLAIN = 0, GEMM_OUT_CONV = 1, GEMM_OUT_POOL = 2 };
+enum { GEMM_OUT_PLAIN = 0, GEMM_OUT_CONV = 1, GEMM_OUT_POOL = 2, GEMM_OUT_LSTM_FWD = 3, GEMM_OUT_LSTM_BWD = 4 };
+
+// Epilogue operands of the two LSTM out-modes of gemm_8p.hip (bf16 only): the recurrent GEMM of a timestep with the cell update
+// (forward) / the cell backward of the previous step (backward) computed in the accumulator registers -- no f32 round trip of the
+// pre-activations / dh and no separate cell launch.  Same arithmetic as lstm_fwd_kernel / lstm_bwd_kernel (kernels.hip).
+//   LSTM_FWD: C columns are (unit, gate)-interleaved: B = Wh rows in the order u*4 + gate (prepare_weights' "gi" copy), N = 4H.
+//             acc(row, 4u + gate) + Gx[row][gate*H + u] -> f, i, o, g -> c = c_prev f + i g, h = o tanh(c)        (lrcn.jl:529-536)
+//   LSTM_BWD: C columns are hidden units, N = H, A = dZ of step s, B = Wh^T: dh = acc + dh_ext -> dZ of step s-1, dc   
+struct LstmEpi {
+    int H;
+    int64_t ld_a, ld_h;     // leading dimensions of acts / dz (elements) and of h_new
+    const float *Gx;        // FWD: [M][4H] input-side pre-activations (+ bias) of this step
+    const float *c_prev;    // [M][H] or NULL (first step of the sequence)
+    const float *c_new;     // BWD: [M][H] cell state of step s-1
+    float *c_out;           // FWD: [M][H]
+    void *acts;             // FWD: out, BWD: in -- activated gates [M][ld_a], columns [f | i | o | g]
+    void *h_new;            // FWD: [M][ld_h]
+    const float *dh_ext;    // BWD: [M][H] dh of step s-1 from the layer above / the loss
+    float *dc;              // BWD: [M][H] in/out
+    void *dz_out;           // BWD: [M][ld_a] dZ of step s-1
+};
 enum { GEMM_T_F32 = 0, GEMM_T_BF16 = 1, GEMM_T_F8 = 2 };  // F8: OCP e4m3 A, B and C (gemm_8p.hip CONV3 only)
 
 struct GemmArgs {
@@ -26,6 +46,11 @@ struct GemmArgs {
     int a_mode, out_mode;
     int H, W, Cin;  // conv geometry (square-agnostic; H, W even)
     int wg_cap;             // > 0: at most this many workgroups (gemm_8p.hip / conv64.hip walk the tiles persistently)
+    LstmEpi lstm;           // out_mode GEMM_OUT_LSTM_FWD / _BWD only
+    int cfg_pref;           // gemm_8p.hip: 0 = the dispatcher's tile menu, 2 = prefer the 256 x 128 tile (set by the bg_cus route)
+    int bg_cus;             // > 0: this contraction runs BESIDE the capped persistent convolution grids of another stream and will
+                            // find about this many free CUs (lrcn_api.hip sets it for the LSTM GEMMs when lrcn_vgg_set_wg_cap is
+                            // active): the dispatcher then prefers a route whose workgroups fit them in one round
     int *tile_ctr;          // capped grids only: 8 zeroed ints = per-XCD work queues -- workgroups PULL tiles (8 i + queue) instead of
                             // walking a fixed share, so one that starts late (its CU still busy with another stream's kernel) does
                             // fewer tiles instead of stretching the whole launch; NULL = static round-robin walk

@@ -304,6 +304,19 @@ static hipError_t launch_gemm_routed(hipStream_t stream, const GemmArgs &g, cons
     if (!(knob && knob[0] == '0') && !(knob8 && knob8[0] == '0')) {
         int64_t blocks = 0;
         if (gemm_8p_config(g, &blocks) >= 0 && ((knob8 && knob8[0] == 'f') || blocks >= 128)) { *route = "8p"; return launch_gemm_8p(stream, g); }
+        // Beside the capped convolution grids only ~bg_cus CUs are free: a launch of many small workgroups runs in several rounds
+        // on them, one of few large tiles (less operand traffic per FLOP) in one.  The recurrent GEMM of the B = 256 step
+        // (256 x 4000 x 1024): 126 workgroups of 128 x 64 take 13 us alone but 50 us beside the VGG forward (4 rounds on 32 CUs);
+        // 32 workgroups of 256 x 128 take 25 us either way.
+        static const int bg_minN = getenv("LRCN_BG_MINN") ? atoi(getenv("LRCN_BG_MINN")) : 512;  // development knob
+        if (g.bg_cus > 0 && g.a_mode == GEMM_A_PLAIN && g.M >= 256 && g.M <= 512 && g.N >= bg_minN) {
+            GemmArgs h = g;
+            h.cfg_pref = 2;
+            if (gemm_8p_config(h, &blocks) >= 0 && blocks <= 2 * g.bg_cus) {
+                *route = "8p-bg";
+                return launch_gemm_8p(stream, h);
+            }
+        }
         if (skinny_ok && g.M <= 128) { *route = "skinny"; return launch_gemm_skinny(stream, g); }
         const char *ksk = getenv("LRCN_8P_SPLITK");  // kernel-development knob: 0 disables the split-K form
         const int sk = (ksk && ksk[0] == '0') ? 0 : gemm_8p_splitk(g, &blocks);

@@ -70,7 +70,9 @@ __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float 
 // F8: A and B are OCP e4m3 bytes, a K-tile is 128 elements (the same 128-byte LDS rows), one
 // v_mfma_f32_16x16x128_f8f6f4 replaces two v_mfma_f32_16x16x32_bf16 (same cycles, twice the K), the staged epilogue
 // multiplies by g.scale[col] before the bias and writes e4m3.
-template <int WM, int WN, int MT, int NT, int AMODE, bool SWAP, bool F8>
+__device__ __forceinline__ float sigm8p(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <int WM, int WN, int MT, int NT, int AMODE, bool SWAP, bool F8, int EPI = 0>
 __device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *smem, const int tile, const int ntiles_xy) {
     constexpr int ES = F8 ? 1 : 2;       // bytes per element
     constexpr int KE = 128 / ES;         // elements per K-tile
@@ -344,8 +346,86 @@ __device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *sm
     wait_vmcnt<0>();                             // the tail's dummy pieces
     __builtin_amdgcn_s_barrier();                // nobody reads or DMA-writes the ring any more
 
-    // ---------------------------------------------------------------- epilogue A: bf16 tile staged through LDS
     const int l15 = lane & 15, lq = lane >> 4;
+    // ---------------------------------------------------------------- LSTM epilogues (gemm.h LstmEpi): the cell math in the accumulators.
+    // SWAP layout: a lane holds row (l15) x four consecutive columns.  FWD: those are the four gates of ONE unit (interleaved
+    // weight rows); BWD: four consecutive units.
+    if constexpr (EPI == GEMM_OUT_LSTM_FWD || EPI == GEMM_OUT_LSTM_BWD) {
+        // 1. the f32 accumulator tile goes through LDS (the ring is free; 16-byte chunk c of row r at chunk c ^ (r & 31): the 16 lanes
+        //    of a group write 16 different rows), so that 2. every global access of the cell math is coalesced along a row
+        //    (a first version did the math straight from the MFMA layout -- 16 rows per memory instruction -- and ran 3-10x slower).
+        constexpr int CPRF = BN / 4;  // 16-byte chunks per staged f32 row
+        static_assert(CPRF == 32, "LSTM epilogues are built for the 256 x 128 tile");
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        const int lrow = wr * WTM + mh * QM + i * 16 + l15;
+                        const int ch = (wc * WTN + nh * QN + n * 16 + 4 * lq) >> 2;
+                        *reinterpret_cast<f32x4v *>(smem + lrow * (BN * 4) + ((ch ^ (lrow & 31)) << 4)) = acc[mh][i][nh][n];
+                    }
+        __syncthreads();
+        const LstmEpi &e = g.lstm;
+        const int H = e.H;
+        for (int idx = tid; idx < BM * CPRF; idx += 512) {
+            const int lrow = idx / CPRF, ch = idx - lrow * CPRF;
+            const int row = m0 + lrow, col0 = n0 + 4 * ch;
+            if (row >= M || col0 >= N) continue;
+            const f32x4v a = *reinterpret_cast<const f32x4v *>(smem + lrow * (BN * 4) + ((ch ^ (lrow & 31)) << 4));
+            if constexpr (EPI == GEMM_OUT_LSTM_FWD) {  // columns 4u .. 4u+3 = the gates f, i, o, g of unit u
+                const int u = col0 >> 2;
+                const float *gx = e.Gx + (int64_t)row * 4 * H + u;
+                const float f = sigm8p(a[0] + gx[0]), in = sigm8p(a[1] + gx[H]), o = sigm8p(a[2] + gx[2 * H]), chg = tanhf(a[3] + gx[3 * H]);
+                const float cp = e.c_prev ? e.c_prev[(int64_t)row * H + u] : 0.0f;
+                const float c = cp * f + in * chg;
+                bf16_t *ac = reinterpret_cast<bf16_t *>(e.acts) + (int64_t)row * e.ld_a + u;
+                ac[0] = (bf16_t)f;
+                ac[H] = (bf16_t)in;
+                ac[2 * H] = (bf16_t)o;
+                ac[3 * H] = (bf16_t)chg;
+                e.c_out[(int64_t)row * H + u] = c;
+                reinterpret_cast<bf16_t *>(e.h_new)[(int64_t)row * e.ld_h + u] = (bf16_t)(o * tanhf(c));
+            } else {  // columns = four consecutive hidden units (H % 4 == 0 is checked at launch)
+                typedef __bf16 bf16x4e __attribute__((ext_vector_type(4)));
+                const int u = col0;
+                const int64_t o = (int64_t)row * H + u;
+                const f32x4v dhe = *reinterpret_cast<const f32x4v *>(e.dh_ext + o), cn = *reinterpret_cast<const f32x4v *>(e.c_new + o),
+                             dci = *reinterpret_cast<const f32x4v *>(e.dc + o);
+                f32x4v cp = f32x4v{0.f, 0.f, 0.f, 0.f};
+                if (e.c_prev) cp = *reinterpret_cast<const f32x4v *>(e.c_prev + o);
+                const bf16_t *ac = reinterpret_cast<const bf16_t *>(e.acts) + (int64_t)row * e.ld_a + u;
+                const bf16x4e fv = *reinterpret_cast<const bf16x4e *>(ac), iv = *reinterpret_cast<const bf16x4e *>(ac + H),
+                              ov = *reinterpret_cast<const bf16x4e *>(ac + 2 * H), gv = *reinterpret_cast<const bf16x4e *>(ac + 3 * H);
+                bf16x4e zf, zi, zo, zg;
+                f32x4v dco;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float dh = a[r] + dhe[r];
+                    const float f = (float)fv[r], in = (float)iv[r], og = (float)ov[r], gg = (float)gv[r];
+                    const float tc = tanhf(cn[r]);
+                    const float dov = dh * tc;
+                    const float dcv = dci[r] + dh * og * (1.0f - tc * tc);
+                    zf[r] = (bf16_t)(dcv * cp[r] * f * (1.0f - f));
+                    zi[r] = (bf16_t)(dcv * gg * in * (1.0f - in));
+                    zo[r] = (bf16_t)(dov * og * (1.0f - og));
+                    zg[r] = (bf16_t)(dcv * in * (1.0f - gg * gg));
+                    dco[r] = dcv * f;
+                }
+                bf16_t *z = reinterpret_cast<bf16_t *>(e.dz_out) + (int64_t)row * e.ld_a + u;
+                *reinterpret_cast<bf16x4e *>(z) = zf;
+                *reinterpret_cast<bf16x4e *>(z + H) = zi;
+                *reinterpret_cast<bf16x4e *>(z + 2 * H) = zo;
+                *reinterpret_cast<bf16x4e *>(z + 3 * H) = zg;
+                *reinterpret_cast<f32x4v *>(e.dc + o) = dco;
+            }
+        }
+        return;
+    }
+    // ---------------------------------------------------------------- epilogue A: bf16 tile staged through LDS
     if constexpr (F8) {
         // e4m3 tile staged through LDS: BN bytes per row, 16-byte chunk c of row r at chunk c ^ swz(r) (two 128-byte rows
         // share a 256-byte bank line when BN = 128).  Launch-side checks guarantee N % 16 == 0, ldc % 16 == 0, no beta/f32.
@@ -591,14 +671,14 @@ __device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *sm
 // One workgroup per output tile, or -- g.wg_cap > 0 -- a capped, persistent grid that walks the tiles: the data-parallel
 // step caps the convolution grids below the CU count at small per-GPU batches so that the LSTM stream's chain of small
 // dependent launches always finds idle CUs (DESIGN.md "Stream structure").
-template <int WM, int WN, int MT, int NT, int AMODE, bool SWAP, bool F8>
+template <int WM, int WN, int MT, int NT, int AMODE, bool SWAP, bool F8, int EPI = 0>
 __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
     const int ntiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     if (g.tile_ctr == nullptr || gridDim.y > 1) {
         for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-            gemm8p_tile<WM, WN, MT, NT, AMODE, SWAP, F8>(g, smem, tile, ntiles);
+            gemm8p_tile<WM, WN, MT, NT, AMODE, SWAP, F8, EPI>(g, smem, tile, ntiles);
             if (tile + (int)gridDim.x < ntiles) __syncthreads();  // the staged output tile / ring are reused by the next tile
         }
         return;
@@ -642,19 +722,19 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs g) {
     while (tile >= 0) {
         par ^= 1;
         if (threadIdx.x == 0) publish(slot + par);  // the NEXT tile: its latency hides under this tile's prologue
-        gemm8p_tile<WM, WN, MT, NT, AMODE, SWAP, F8>(g, smem, tile, ntiles);
+        gemm8p_tile<WM, WN, MT, NT, AMODE, SWAP, F8, EPI>(g, smem, tile, ntiles);
         __syncthreads();  // the staged output tile / ring are free again; lane 0's exchange precedes every wave's fetch
         tile = fetch(slot + par);
     }
 }
 
-template <int WM, int WN, int MT, int NT, int AMODE, bool SWAP, bool F8 = false> hipError_t launch_one(hipStream_t s, const GemmArgs &g, int splitk) {
+template <int WM, int WN, int MT, int NT, int AMODE, bool SWAP, bool F8 = false, int EPI = 0> hipError_t launch_one(hipStream_t s, const GemmArgs &g, int splitk) {
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
-    constexpr int ring = 2 * (BM + BN) * 128, ctile = BM * BN * 2;
+    constexpr int ring = 2 * (BM + BN) * 128, ctile = BM * BN * (EPI ? 4 : 2);  // the LSTM epilogues stage the f32 tile
     constexpr int lds = ring > ctile ? ring : ctile;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static LdsAttrMask attr_done{0};
-    auto kern = gemm8p_kernel<WM, WN, MT, NT, AMODE, SWAP, F8>;
+    auto kern = gemm8p_kernel<WM, WN, MT, NT, AMODE, SWAP, F8, EPI>;
     if (hipError_t e = set_max_lds(reinterpret_cast<const void *>(kern), lds, attr_done); e != hipSuccess) return e;
     const int64_t blocks = (int64_t)cdiv(g.M, BM) * cdiv(g.N, BN);
     if (blocks <= 0 || blocks > 0x7FFFFFFF) return hipErrorInvalidValue;
@@ -711,6 +791,7 @@ int gemm_8p_config(const GemmArgs &g, int64_t *blocks) {
     const int64_t b0 = (int64_t)cdiv(g.M, 256) * cdiv(g.N, 256), b1 = (int64_t)cdiv(g.M, 256) * cdiv(g.N, 128);
     int cfg = (g.N > 128 && (b0 >= 200 || g.N % 256 == 0 || g.N > 384)) ? 0 : 1;
     if (cfg == 0 && ((b0 < 200 && b1 >= 200) || (b0 < 128 && b1 >= 128))) cfg = 1;  // the narrower tile when only it fills the chip
+    if (g.cfg_pref == 2 && g.N >= 128) cfg = 1;
     {
         static const char *fc = getenv("LRCN_8P_CFG");  // kernel-development knob: force the 256 x 256 (0) or 256 x 128 (1) tile
         if (fc && (fc[0] == '0' || fc[0] == '1') && g.N > 128) cfg = fc[0] - '0';
@@ -782,12 +863,24 @@ hipError_t launch_splitk_reduce(hipStream_t stream, const GemmArgs &g, int split
 
 hipError_t launch_gemm_8p(hipStream_t stream, const GemmArgs &g0, int splitk) {
     GemmArgs g = g0;
+    const int epi = g0.out_mode;
+    if (epi == GEMM_OUT_LSTM_FWD || epi == GEMM_OUT_LSTM_BWD) {
+        g.out_mode = GEMM_OUT_PLAIN;  // tile menu and operand checks are those of a plain contraction; the kernel template carries the mode
+        g.cfg_pref = 2;
+    }
     static const char *dbg = getenv("LRCN_DBG");  // kernel-development ablation flags (gemm.h)
     g.dbg = dbg ? atoi(dbg) : 0;
     int64_t blocks = 0;
     int cfg = gemm_8p_config(g, &blocks);
     if (cfg < 0) return hipErrorInvalidValue;
     gemm_debug_note_route(nullptr, splitk > 1 ? splitk : cfg);
+    if (epi == GEMM_OUT_LSTM_FWD || epi == GEMM_OUT_LSTM_BWD) {  // 256 x 128 tiles, cell math in the epilogue
+        if (g.dtype != GEMM_T_BF16 || g.a_mode != GEMM_A_PLAIN || splitk > 1 || cfg != 1 || (g.N & 3) || !g.lstm.acts || g.lstm.H < 1 ||
+            (g.lstm.H & 3) || (g.lstm.ld_a & 3))
+            return hipErrorInvalidValue;
+        return epi == GEMM_OUT_LSTM_FWD ? launch_one<4, 2, 2, 2, GEMM_A_PLAIN, true, false, GEMM_OUT_LSTM_FWD>(stream, g, 1)
+                                               : launch_one<4, 2, 2, 2, GEMM_A_PLAIN, true, false, GEMM_OUT_LSTM_BWD>(stream, g, 1);
+    }
     if (splitk > 1) {
         if (gemm_8p_splitk(g, &blocks) != splitk) return hipErrorInvalidValue;
         hipError_t e = dispatch<GEMM_A_PLAIN, true>(stream, g, 1, splitk);

@@ -70,6 +70,11 @@ struct PrepDesc {
     void *dA, *dB, *tA, *tB;
     int64_t ldA, ldB, ldtA, ldtB;
     int tile0;
+    // optional third direct copy of the B side with the ROWS in (unit, gate)-interleaved order: source row g*giH + u -> row 4u + g
+    // (the recurrent weights of gemm_8p.hip's LSTM_FWD epilogue); NULL = none
+    void *dG;
+    int64_t ldG;
+    int giH;
 };
 struct PrepPlan {
     PrepDesc d[PREP_MAX];

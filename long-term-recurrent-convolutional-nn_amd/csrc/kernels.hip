@@ -346,6 +346,12 @@ template <typename T> __global__ __launch_bounds__(256) void prepare_weights_ker
                 for (int k = 0; k < 4; ++k)
                     if (c + k < P.C) v[k] = P.src[(int64_t)r * P.C + c + k];
             }
+            if (P.dG) {  // gate-interleaved rows of the B side (element-wise: the destination is written once per step, 8 MB)
+                const int rg = (r % P.giH) * 4 + r / P.giH;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (c + k >= P.cs && c + k < P.C) reinterpret_cast<T *>(P.dG)[(int64_t)rg * P.ldG + (c + k - P.cs)] = from_f32<T>(v[k]);
+            }
             const bool sideA = c + 3 < P.cs, sideB = c >= P.cs;
             if (vec && c + 3 < P.C && sideA && alA) {
                 if (P.dA) store4(reinterpret_cast<T *>(P.dA) + (int64_t)r * P.ldA + c, v);

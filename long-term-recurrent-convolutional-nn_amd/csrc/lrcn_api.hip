@@ -58,6 +58,7 @@ struct lrcn_ctx {
     void *W1cat = nullptr, *W2cat = nullptr, *st_xh1 = nullptr, *st_xh2 = nullptr;
     int64_t ldXH1 = 0, ldXH2 = 0;
     void *W2x = nullptr, *W2h = nullptr, *W2xT = nullptr, *W2hT = nullptr;
+    void *W1h_gi = nullptr, *W2h_gi = nullptr;  // recurrent weights with (unit, gate)-interleaved rows (gemm_8p.hip LSTM_FWD epilogue), lazily
     void *Wpd = nullptr, *WpT = nullptr, *Wcd = nullptr, *WeT = nullptr, *Wod = nullptr, *WoT = nullptr;
     // activations
     int32_t *tok = nullptr, *tok_in = nullptr, *tok_tgt = nullptr;
@@ -211,6 +212,22 @@ int gemm(lrcn_ctx *c, int dtype, const void *A, int64_t lda, const void *B, int6
     g.zero_page = c->zero_page;
     g.ws = c->gemm_ws;
     g.ws_bytes = c->gemm_ws_bytes;
+    {   // the LSTM GEMMs of a two-stream training step run beside the capped convolution grids (LRCN_BG_ROUTE=0 turns the hint off)
+        static const char *kb = getenv("LRCN_BG_ROUTE");
+        if (c->vgg_wg_cap >= 8 && c->vgg_loaded && !(kb && kb[0] == '0')) {
+            static int ncu = 0;
+            if (!ncu) {
+                hipDeviceProp_t pr;
+                ncu = (hipGetDeviceProperties(&pr, c->cfg.device) == hipSuccess) ? pr.multiProcessorCount : 256;
+            }
+            g.bg_cus = ncu - c->vgg_wg_cap > 0 ? ncu - c->vgg_wg_cap : 0;
+            // ... and the large time-batched GEMMs walk their tiles persistently on that many workgroups instead of queueing hundreds
+            // of them: they get the same CUs either way, but no longer take a convolution workgroup's CU at a kernel boundary
+            static const char *kc = getenv("LRCN_BG_CAP");  // workgroups per free CU (0 = uncapped); 2 measured best (1: the LSTM chain
+            const int capmul = kc ? atoi(kc) : 2;           // becomes the critical path, 4+: the convolutions lose what they gained)
+            if (capmul > 0 && g.bg_cus >= 8) g.wg_cap = g.bg_cus * capmul;
+        }
+    }
     hipError_t e = launch_gemm(c->stream, g);
     if (e != hipSuccess) FAIL(c, LRCN_EHIP, "gemm M=%d N=%d K=%d: %s", M, N, K, hipGetErrorString(e));
     return LRCN_OK;
@@ -234,7 +251,7 @@ DropSpec make_drop(const lrcn_dropout *d, int which) {
 }
 
 // f32 column-major params -> K-contiguous shadows in T (direct and transposed).  See DESIGN.md "shadow weights".
-int prepare_weights(lrcn_ctx *c, const float *const p[9], bool need_bwd, bool cat = false) {
+int prepare_weights(lrcn_ctx *c, const float *const p[9], bool need_bwd, bool cat = false, bool gi = false) {
     const int dt = c->dt, E = c->E, H1 = c->H1, H2 = c->H2, h = c->h, V = c->V;
     if (!p[0] || !p[1] || !p[5] || !p[6] || !p[7] || !p[8] || (c->nl == 2 && (!p[2] || !p[3] || !p[4]))) FAIL(c, LRCN_EINVAL, "null parameter tensor");
     hipStream_t st = c->stream;
@@ -249,9 +266,21 @@ int prepare_weights(lrcn_ctx *c, const float *const p[9], bool need_bwd, bool ca
     const bool b = need_bwd, two = c->nl == 2;
     const int X1 = c->X1;
     // W1: memory [4H1][X1 + H1] -> W1x | W1h (and their transposes [X1][ld4H1] | [H1][ld4H1] for the backward dX GEMMs)
+    if (gi) {
+        if (!c->W1h_gi) DALLOC(c, c->W1h_gi, c->esz * 4 * H1 * c->ldH1);
+        if (two && !c->W2h_gi) DALLOC(c, c->W2h_gi, c->esz * 4 * H2 * c->ldH2);
+    }
     add(p[0], 4 * H1, X1 + H1, X1, c->W1x, c->ldX1, c->W1h, c->ldH1, b ? c->W1xT : nullptr, c->ld4H1, b ? c->W1hT : nullptr, c->ld4H1);
+    if (gi) {
+        PrepDesc &d = plan.d[plan.n - 1];
+        d.dG = c->W1h_gi; d.ldG = c->ldH1; d.giH = H1;
+    }
     if (two) {
         add(p[2], 4 * H2, 2 * H2, H2, c->W2x, c->ldH2, c->W2h, c->ldH2, b ? c->W2xT : nullptr, c->ld4H2, b ? c->W2hT : nullptr, c->ld4H2);
+        if (gi) {
+            PrepDesc &d = plan.d[plan.n - 1];
+            d.dG = c->W2h_gi; d.ldG = c->ldH2; d.giH = H2;
+        }
         add(p[4], h, H1, H1, c->Wpd, c->ldH1, nullptr, 0, b ? c->WpT : nullptr, c->ldh, nullptr, 0);  // Wproj (H1 x h): memory [h][H1]
     }
     add(p[5], h, LRCN_CNNOUT, LRCN_CNNOUT, c->Wcd, LRCN_CNNOUT, nullptr, 0, nullptr, 0, nullptr, 0);   // Wcnn: memory [h][4096]
@@ -273,12 +302,42 @@ bool lstm_fused_on(lrcn_ctx *c, int B, int H, int64_t ldH, int64_t ld4H) {
     const char *mb = getenv("LRCN_LSTM_FUSED_MAXB");  // kernel-development knob: largest batch routed to the fused step kernels
     return !(k && k[0] == '0') && B <= (mb ? atoi(mb) : 128) && lstm_fused_eligible(c->dt, B, H, ldH, ld4H);
 }
+// The recurrent GEMM with the cell math in its epilogue (gemm_8p.hip GEMM_OUT_LSTM_*), for the two-stream training step at 256..512
+// rows per GPU: one launch of 32 (forward) / 8 (backward) workgroups per timestep instead of GEMM + cell kernel.  MEASURED AND LEFT
+// OFF (LRCN_LSTM_EPI=1 turns it on; tests/test_gpu_lstm_parity.py checks it against the oracle): the cell math is HBM/L2 traffic
+// (9 MB per step) that wants many CUs, and inside a 32- or 8-workgroup GEMM it runs at those few CUs' bandwidth -- per timestep,
+// beside the VGG forward: forward 45 us fused vs 27 + 9.6 us, backward 87 us fused vs 55 + 8.7 us; training step 7.49 vs 7.22 ms.
+bool lstm_epi_on(lrcn_ctx *c, int B) {
+    const char *k = getenv("LRCN_LSTM_EPI"), *kb = getenv("LRCN_BG_ROUTE");
+    return c->dt == GEMM_T_BF16 && c->vgg_wg_cap >= 8 && c->vgg_loaded && B >= 256 && B <= 512 && !(c->H1 & 3) && !(c->H2 & 3) &&
+           (k && k[0] == '1') && !(kb && kb[0] == '0');
+}
 int lstm_layer_fwd(lrcn_ctx *c, int S, int B, int H, int64_t ldH, int64_t ld4H, float *Gx, const void *Wh, void *acts,
-                   float *Call, void *Hall) {
+                   float *Call, void *Hall, const void *Wh_gi = nullptr) {
     const int dt = c->dt;
     const bool fused = lstm_fused_on(c, B, H, ldH, ld4H);
+    const bool epi = !fused && Wh_gi && lstm_epi_on(c, B);
     for (int s = 0; s < S; ++s) {
         float *G = Gx + (int64_t)s * B * 4 * H;
+        if (s > 0 && epi) {
+            GemmArgs g{};
+            g.dtype = dt;
+            g.A = boff(Hall, (int64_t)(s - 1) * B * ldH, c->esz); g.lda = ldH;
+            g.B = Wh_gi; g.ldb = ldH;
+            g.M = B; g.N = 4 * H; g.K = (int)ldH;
+            g.a_mode = GEMM_A_PLAIN;
+            g.out_mode = GEMM_OUT_LSTM_FWD;
+            g.zero_page = c->zero_page;
+            g.lstm.H = H; g.lstm.ld_a = ld4H; g.lstm.ld_h = ldH;
+            g.lstm.Gx = G;
+            g.lstm.c_prev = Call + (int64_t)(s - 1) * B * H;
+            g.lstm.c_out = Call + (int64_t)s * B * H;
+            g.lstm.acts = boff(acts, (int64_t)s * B * ld4H, c->esz);
+            g.lstm.h_new = boff(Hall, (int64_t)s * B * ldH, c->esz);
+            hipError_t e = launch_gemm_8p(c->stream, g);
+            if (e != hipSuccess) FAIL(c, LRCN_EHIP, "lstm fwd step (GEMM + cell epilogue): %s", hipGetErrorString(e));
+            continue;
+        }
         if (s > 0 && fused) {  // recurrent GEMM + cell in one launch (small batches: launch-latency bound otherwise)
             hipError_t e = launch_lstm_rec_fwd(c->stream, boff(Hall, (int64_t)(s - 1) * B * ldH, c->esz), ldH, Wh, G,
                                                Call + (int64_t)(s - 1) * B * H, B, H, boff(acts, (int64_t)s * B * ld4H, c->esz), ld4H,
@@ -301,6 +360,33 @@ int lstm_layer_fwd(lrcn_ctx *c, int S, int B, int H, int64_t ldH, int64_t ld4H, 
 int lstm_layer_bwd(lrcn_ctx *c, int S, int B, int H, int64_t ld4H, const void *acts, const float *Call, const float *dHall,
                    const void *WhT, void *dZ) {
     const int dt = c->dt;
+    if (!lstm_fused_on(c, B, H, round_up64(H, 64), ld4H) && lstm_epi_on(c, B)) {
+        // cell backward of the last step, then one launch per step: dh_rec = dZ[s] Wh with the cell backward of s-1 in its epilogue
+        k_lstm_bwd(c->stream, dt, boff(acts, (int64_t)(S - 1) * B * ld4H, c->esz), ld4H, S > 1 ? Call + (int64_t)(S - 2) * B * H : nullptr,
+                   Call + (int64_t)(S - 1) * B * H, dHall + (int64_t)(S - 1) * B * H, H, nullptr, 0, c->dc, 1, B, H,
+                   boff(dZ, (int64_t)(S - 1) * B * ld4H, c->esz), ld4H);
+        for (int s = S - 1; s >= 1; --s) {
+            GemmArgs g{};
+            g.dtype = dt;
+            g.A = boff(dZ, (int64_t)s * B * ld4H, c->esz); g.lda = ld4H;
+            g.B = WhT; g.ldb = ld4H;
+            g.M = B; g.N = H; g.K = (int)ld4H;
+            g.a_mode = GEMM_A_PLAIN;
+            g.out_mode = GEMM_OUT_LSTM_BWD;
+            g.zero_page = c->zero_page;
+            g.lstm.H = H; g.lstm.ld_a = ld4H;
+            g.lstm.acts = const_cast<char *>(boff(acts, (int64_t)(s - 1) * B * ld4H, c->esz));
+            g.lstm.c_prev = s > 1 ? Call + (int64_t)(s - 2) * B * H : nullptr;
+            g.lstm.c_new = Call + (int64_t)(s - 1) * B * H;
+            g.lstm.dh_ext = dHall + (int64_t)(s - 1) * B * H;
+            g.lstm.dc = c->dc;
+            g.lstm.dz_out = boff(dZ, (int64_t)(s - 1) * B * ld4H, c->esz);
+            hipError_t e = launch_gemm_8p(c->stream, g);
+            if (e != hipSuccess) FAIL(c, LRCN_EHIP, "lstm bwd step (GEMM + cell epilogue): %s", hipGetErrorString(e));
+        }
+        KCHK(c, "lstm_layer_bwd (epilogue)");
+        return LRCN_OK;
+    }
     if (lstm_fused_on(c, B, H, round_up64(H, 64), ld4H)) {
         // cell backward of the last step, then one launch per step: dh_rec = dZ[s] Wh fused with the cell backward of s-1
         k_lstm_bwd(c->stream, dt, boff(acts, (int64_t)(S - 1) * B * ld4H, c->esz), ld4H, S > 1 ? Call + (int64_t)(S - 2) * B * H : nullptr,
@@ -351,7 +437,8 @@ int loss_impl(lrcn_ctx *c, const float *const p[9], const float *feats, const in
     const DropSpec d1 = make_drop(drop, 1), d2 = make_drop(drop, 2);
     const DropSpec none{};
 
-    r = prepare_weights(c, p, bwd);
+    const bool epi = lstm_epi_on(c, B) && !lstm_fused_on(c, B, H1, c->ldH1, c->ld4H1);
+    r = prepare_weights(c, p, bwd, false, epi);
     if (r) return r;
     k_build_tokens(st, tokens, T, B, V, c->tok_in, c->tok_tgt, c->logp);  // reads the caller's (T, B) ids once (T = 0: never)
     // feats (B x 4096 column-major = memory [4096][B]) -> F [B][4096] (T)
@@ -364,7 +451,7 @@ int loss_impl(lrcn_ctx *c, const float *const p[9], const float *feats, const in
     if (!two) k_concat_x2(st, dt, c->Xemb, c->ldX1, c->xcnn, c->ldh, S, B, E, h, d1);
     // LSTM 1
     GEMM(c, dt, c->Xemb, c->ldX1, c->W1x, c->ldX1, c->G1, 4 * H1, M, 4 * H1, X1, p[1], true);
-    r = lstm_layer_fwd(c, S, B, H1, c->ldH1, c->ld4H1, c->G1, c->W1h, c->A1, c->C1, c->H1all);
+    r = lstm_layer_fwd(c, S, B, H1, c->ldH1, c->ld4H1, c->G1, c->W1h, c->A1, c->C1, c->H1all, epi ? c->W1h_gi : nullptr);
     if (r) return r;
     const void *Htop = c->H1all;  // the hidden states the logits are computed from
     if (two) {
@@ -373,7 +460,7 @@ int loss_impl(lrcn_ctx *c, const float *const p[9], const float *feats, const in
         k_concat_x2(st, dt, c->X2, c->ldH2, c->xcnn, c->ldh, S, B, h, h, d2);
         // LSTM 2
         GEMM(c, dt, c->X2, c->ldH2, c->W2x, c->ldH2, c->G2, 4 * H2, M, 4 * H2, H2, p[3], true);
-        r = lstm_layer_fwd(c, S, B, H2, c->ldH2, c->ld4H2, c->G2, c->W2h, c->A2, c->C2, c->H2all);
+        r = lstm_layer_fwd(c, S, B, H2, c->ldH2, c->ld4H2, c->G2, c->W2h, c->A2, c->C2, c->H2all, epi ? c->W2h_gi : nullptr);
         if (r) return r;
         Htop = c->H2all;
     }

@@ -314,11 +314,17 @@ def test_adam_by_gradient_group_equals_one_launch():
     ctx.close()
 
 
-@pytest.mark.parametrize("B", [24, 64, 160, 256])
+@pytest.mark.parametrize("B", [24, 64, 160, 256, -256, -320])
 def test_recurrence_kernel_routes_by_batch_size_vs_oracle_bf16(B):
     # The recurrent step takes a different kernel family per batch size: the fused GEMM + cell kernels of lstm_fused.hip with one
     # row block (B <= 32: <2>), several blocks of 64 rows (B <= 128: <4>), and separate recurrent GEMM (gemm_glds / gemm_8p split-K)
     # + cell launches above -- the route the B = 256 benchmark runs.  E = H = 256 keeps the oracle fast; dropout masks explicit.
+    # B < 0: the two-stream training step's route at |B| rows -- VGG weights loaded and the convolution grids capped (what dp.py sets
+    # up), which switches the LSTM GEMMs to the "beside the convolutions" dispatch (256 x 128 tiles for the 256..512-row recurrent
+    # GEMMs: few large workgroups that fit the free CUs in one round), and -- LRCN_LSTM_EPI=1 -- the recurrent GEMM with the cell
+    # math in its epilogue (gemm_8p.hip GEMM_OUT_LSTM_FWD / _BWD, gate-interleaved recurrent weights).
+    beside = B < 0
+    B = abs(B)
     rng = np.random.default_rng(B)
     E = H = 256
     V, T = 1000, 5
@@ -330,8 +336,22 @@ def test_recurrence_kernel_routes_by_batch_size_vs_oracle_bf16(B):
     mask1 = ((rng.random((T + 1, B, E)) > 0.3) / 0.7).astype(np.float32)
     mask2 = ((rng.random((T + 1, B, H)) > 0.3) / 0.7).astype(np.float32)
     ref_loss, ref_g = orc.loss(m, feats, tokens, mask1=mask1, mask2=mask2, want_grad=True)
-    ctx = L.Context(E, H, H, V, max_B=B, max_T=T, lstm_dtype=lrcn_amd.LRCN_BF16)
+    ctx = L.Context(E, H, H, V, max_B=B, max_T=T, lstm_dtype=lrcn_amd.LRCN_BF16, vgg_dtype=lrcn_amd.LRCN_BF16, max_images=1 if beside else 0)
+    if beside:
+        L.vgg_load(ctx, *L.synthetic_vgg_weights(seed=1))
+        L.vgg_set_wg_cap(ctx, 224)
     grads, val = L.lossgradient(ctx, L.model_from_arrays(m.p), L.to_jl(feats), tokens, mask1=mask1, mask2=mask2)
+    if beside:  # the same call WITH the cell-epilogue route (off by default: measured slower, lrcn_api.hip lstm_epi_on): both must
+        grads0, val0 = grads, val   # agree with the oracle and with each other
+        os.environ["LRCN_LSTM_EPI"] = "1"
+        try:
+            grads, val = L.lossgradient(ctx, L.model_from_arrays(m.p), L.to_jl(feats), tokens, mask1=mask1, mask2=mask2)
+        finally:
+            del os.environ["LRCN_LSTM_EPI"]
+        assert abs(val - val0) <= 2e-3 * abs(val0)
+        for n, g, g0 in zip(orc.PARAM_NAMES, grads, grads0):
+            a, b = L.from_jl(g).ravel().astype(np.float64), L.from_jl(g0).ravel().astype(np.float64)
+            assert np.linalg.norm(a - b) <= 2e-2 * np.linalg.norm(b) + 1e-12, n
     assert abs(val - ref_loss) <= 2e-2 * abs(ref_loss), (B, val, ref_loss)
     for n, g in zip(orc.PARAM_NAMES, grads):
         a, b = L.from_jl(g).ravel().astype(np.float64), ref_g.p[n].ravel().astype(np.float64)
