@@ -77,6 +77,7 @@ struct lrcn_ctx {
     void *vgg_ws = nullptr;   // same for fc6/fc7: the VGG forward may run on another stream, concurrently with the LSTM step
     size_t gemm_ws_bytes = 0;
     int last_norm = 1, last_S = 1;
+    int cur_B = 0;  // rows of the loss / lossgradient call in flight (the "beside the convolutions" GEMM hints apply from 256 rows)
     // single-step scratch (lrcn_lstm / lrcn_step / beam search), row-major
     float *st_f32[4] = {nullptr, nullptr, nullptr, nullptr};   // h1,c1,h2,c2 [B][H]
     float *st2_f32[4] = {nullptr, nullptr, nullptr, nullptr};  // ping-pong for the beam gather
@@ -214,7 +215,9 @@ int gemm(lrcn_ctx *c, int dtype, const void *A, int64_t lda, const void *B, int6
     g.ws_bytes = c->gemm_ws_bytes;
     {   // the LSTM GEMMs of a two-stream training step run beside the capped convolution grids (LRCN_BG_ROUTE=0 turns the hint off)
         static const char *kb = getenv("LRCN_BG_ROUTE");
-        if (c->vgg_wg_cap >= 8 && c->vgg_loaded && !(kb && kb[0] == '0')) {
+        // from 256 rows per GPU only: below, the VGG forward's own grids are small, more CUs are free, and the LSTM chain is the critical
+        // path -- the hints measured 1.64 -> 1.79 ms/step at 32 rows, 2.39 -> 2.43 at 64, 4.11 -> 4.12 at 128, 7.31 -> 7.20 at 256
+        if (c->vgg_wg_cap >= 8 && c->vgg_loaded && c->cur_B >= 256 && !(kb && kb[0] == '0')) {
             static int ncu = 0;
             if (!ncu) {
                 hipDeviceProp_t pr;
@@ -437,6 +440,7 @@ int loss_impl(lrcn_ctx *c, const float *const p[9], const float *feats, const in
     const DropSpec d1 = make_drop(drop, 1), d2 = make_drop(drop, 2);
     const DropSpec none{};
 
+    c->cur_B = B;
     const bool epi = lstm_epi_on(c, B) && !lstm_fused_on(c, B, H1, c->ldH1, c->ld4H1);
     r = prepare_weights(c, p, bwd, false, epi);
     if (r) return r;
