@@ -113,6 +113,11 @@ struct lrcn_ctx {
     int img_meta_cap = 0;
     float *pre_f32 = nullptr;
     // data parallelism: RCCL communicator (lrcn_comm_init) and one stream per gradient group for [all-reduce -> Adam]
+    // weight-gradient stream: the dW / db GEMMs of lossgradient feed nothing but update!, so they run on their own stream beside the
+    // reverse recurrences (which are chains of small launches that leave CUs idle); own split-K workspace, fork / join by events
+    hipStream_t wg_stream = nullptr;
+    hipEvent_t wg_fork[4] = {}, wg_done = nullptr;
+    void *wg_ws = nullptr;
     int *tile_ctr = nullptr;  // per-layer work queues of the capped persistent convolution grids (GemmArgs::tile_ctr)
     LrcnComm *comm = nullptr;
     hipStream_t comm_stream = nullptr;  // every collective of the communicator is issued on this ONE stream, in group order
@@ -189,7 +194,7 @@ inline const char *boff(const void *p, int64_t elems, size_t esz) {
 
 // C[M][N] (+)= A[M][K] * B[N][K]^T
 int gemm(lrcn_ctx *c, int dtype, const void *A, int64_t lda, const void *B, int64_t ldb, void *C, int64_t ldc, int M, int N,
-         int K, const float *bias, bool c_f32, bool beta = false, bool relu = false, bool c_is_zero = false) {
+         int K, const float *bias, bool c_f32, bool beta = false, bool relu = false, bool c_is_zero = false, bool on_wg_stream = false) {
     GemmArgs g{};
     g.dtype = dtype;
     g.A = A;
@@ -211,7 +216,7 @@ int gemm(lrcn_ctx *c, int dtype, const void *A, int64_t lda, const void *B, int6
     g.a_mode = GEMM_A_PLAIN;
     g.out_mode = GEMM_OUT_PLAIN;
     g.zero_page = c->zero_page;
-    g.ws = c->gemm_ws;
+    g.ws = on_wg_stream ? c->wg_ws : c->gemm_ws;  // one split-K workspace per stream
     g.ws_bytes = c->gemm_ws_bytes;
     {   // the LSTM GEMMs of a two-stream training step run beside the capped convolution grids (LRCN_BG_ROUTE=0 turns the hint off)
         static const char *kb = getenv("LRCN_BG_ROUTE");
@@ -231,7 +236,7 @@ int gemm(lrcn_ctx *c, int dtype, const void *A, int64_t lda, const void *B, int6
             if (capmul > 0 && g.bg_cus >= 8) g.wg_cap = g.bg_cus * capmul;
         }
     }
-    hipError_t e = launch_gemm(c->stream, g);
+    hipError_t e = launch_gemm(on_wg_stream ? c->wg_stream : c->stream, g);
     if (e != hipSuccess) FAIL(c, LRCN_EHIP, "gemm M=%d N=%d K=%d: %s", M, N, K, hipGetErrorString(e));
     return LRCN_OK;
 }
@@ -489,75 +494,111 @@ int loss_impl(lrcn_ctx *c, const float *const p[9], const float *feats, const in
         TrDesc &d = pl.d[pl.n++];
         d.src = src; d.ld_src = ld_src; d.R = R; d.C = C; d.dst = dst; d.ld_dst = ldM; d.shift = shift;
     };
-    // ---- logits layer: dWout, dbout, dH2 ----
+    // The weight / bias gradients feed nothing but update!: they run on the context's weight-gradient stream (sw), forked from the
+    // main chain by an event each time their operands are final, while the main stream goes on with the reverse recurrences --
+    // chains of small launches that leave most CUs idle (alone on the chip) or some of the 32 free ones (beside the VGG forward).
+    // Both streams only READ shared activations; TA / TB / dxcT / FT and the second split-K workspace belong to sw alone.
+    // grad_ev[g] is recorded on whichever stream finalises group g; the main stream joins sw before the call returns.
+    // Not from 256 rows per GPU beside the capped VGG forward: there the convolutions are the critical path and a second stream
+    // of LSTM-side workgroups takes CUs from them at every kernel boundary (measured on one box, ms/step off -> on: LSTM step
+    // alone 2.117 -> 2.052 at 256 rows, 1.086 -> 1.072 at 32; two-stream step 1.679 -> 1.611 at 32 but 7.38 -> 7.54 at 256).
+    // LRCN_WG_STREAM=0 / 1 forces it off / on.
+    const char *kwg = getenv("LRCN_WG_STREAM");
+    const bool beside_vgg = c->vgg_wg_cap >= 8 && c->vgg_loaded && B >= 256;
+    const bool par = kwg ? kwg[0] != '0' : !beside_vgg;
+    hipStream_t sw = par ? c->wg_stream : st;
+    int nfork = 0;
+    auto fork = [&]() -> int {  // sw waits for everything issued on the main stream so far
+        if (!par) return LRCN_OK;
+        HIPCHK(c, hipEventRecord(c->wg_fork[nfork], st));
+        HIPCHK(c, hipStreamWaitEvent(sw, c->wg_fork[nfork], 0));
+        ++nfork;
+        return LRCN_OK;
+    };
+#define FORK()                  \
+    do {                        \
+        int _r = fork();        \
+        if (_r) return _r;      \
+    } while (0)
+    // ---- logits layer: dWout, dbout (sw) | dH2 (main) ----
+    FORK();
     {
         TrPlan pl{};
         tr(pl, c->dLog, c->ldV, M, V, c->TA, 0);      // dLog^T [V][ldM]
         tr(pl, Htop, c->ldH2, M, H2, c->TB, 0);       // H2all^T [H2][ldM]
-        k_transpose_multi(st, dt, pl);
+        k_transpose_multi(sw, dt, pl);
     }
-    GEMM(c, dt, c->TA, ldM, c->TB, ldM, grads[7], H2, V, H2, M, nullptr, true);
-    k_colsum(st, dt, c->dLog, c->ldV, M, V, grads[8]);
-    HIPCHK(c, hipEventRecord(c->grad_ev[0], st));  // group 0: Wout, bout
+    GEMM(c, dt, c->TA, ldM, c->TB, ldM, grads[7], H2, V, H2, M, nullptr, true, false, false, false, par);
+    k_colsum(sw, dt, c->dLog, c->ldV, M, V, grads[8]);
+    HIPCHK(c, hipEventRecord(c->grad_ev[0], sw));  // group 0: Wout, bout
     GEMM(c, dt, c->dLog, c->ldV, c->WoT, c->ldV, two ? c->dH2all : c->dH1all, H2, M, H2, V, nullptr, true);
     if (two) {
         // ---- LSTM 2 ----
         r = lstm_layer_bwd(c, S, B, H2, c->ld4H2, c->A2, c->C2, c->dH2all, c->W2hT, c->dZ2);
         if (r) return r;
+        FORK();
         {
             TrPlan pl{};
             tr(pl, c->dZ2, c->ld4H2, M, 4 * H2, c->TA, 0);                              // dZ2^T [4H2][ldM]
             tr(pl, c->X2, c->ldH2, M, H2, c->TB, 0);                                     // X2^T [2h][ldM]
             tr(pl, c->H2all, c->ldH2, M - B, H2, boff(c->TB, (int64_t)H2 * ldM, es), M > B ? B : 0);  // h2_prev^T (one step later)
-            k_transpose_multi(st, dt, pl);
+            k_transpose_multi(sw, dt, pl);
         }
-        GEMM(c, dt, c->TA, ldM, c->TB, ldM, grads[2], 2 * H2, 4 * H2, 2 * H2, M, nullptr, true);
-        k_colsum(st, dt, c->dZ2, c->ld4H2, M, 4 * H2, grads[3]);
+        GEMM(c, dt, c->TA, ldM, c->TB, ldM, grads[2], 2 * H2, 4 * H2, 2 * H2, M, nullptr, true, false, false, false, par);
+        k_colsum(sw, dt, c->dZ2, c->ld4H2, M, 4 * H2, grads[3]);
     }
-    HIPCHK(c, hipEventRecord(c->grad_ev[1], st));  // group 1: W2, b2
+    HIPCHK(c, hipEventRecord(c->grad_ev[1], sw));  // group 1: W2, b2
     if (two) {
         GEMM(c, dt, c->dZ2, c->ld4H2, c->W2xT, c->ld4H2, c->dX2, c->ldH2, M, H2, 4 * H2, nullptr, false);
         k_dx2_mask_reduce(st, dt, c->dX2, c->ldH2, S, B, h, h, d2, c->dxcnn, c->ldh);
-        // ---- projection and image embedding ----
+        // ---- projection and image embedding: dWproj, dWcnn (sw) | dH1 (main) ----
+        FORK();
         {
             TrPlan pl{};
             tr(pl, c->dX2, c->ldH2, M, h, c->TA, 0);      // dP^T [h][ldM]
             tr(pl, c->H1all, c->ldH1, M, H1, c->TB, 0);   // H1all^T [H1][ldM]
-            k_transpose_multi(st, dt, pl);
+            k_transpose_multi(sw, dt, pl);
         }
-        GEMM(c, dt, c->TA, ldM, c->TB, ldM, grads[4], H1, h, H1, M, nullptr, true);
+        GEMM(c, dt, c->TA, ldM, c->TB, ldM, grads[4], H1, h, H1, M, nullptr, true, false, false, false, par);
         GEMM(c, dt, c->dX2, c->ldH2, c->WpT, c->ldh, c->dH1all, H1, M, H1, h, nullptr, true);
-        k_transpose(st, dt, 1, c->dxcnn, c->ldh, B, h, c->dxcT, ldB, 0);     // dxcnn^T [h][ldB]
-        k_cast_rows(st, dt, feats, B, LRCN_CNNOUT, B, c->FT, ldB);           // feats^T [4096][ldB] (it already is, in memory)
-        GEMM(c, dt, c->dxcT, ldB, c->FT, ldB, grads[5], LRCN_CNNOUT, h, LRCN_CNNOUT, B, nullptr, true);
-        HIPCHK(c, hipEventRecord(c->grad_ev[2], st));  // group 2: Wproj, Wcnn
+        k_transpose(sw, dt, 1, c->dxcnn, c->ldh, B, h, c->dxcT, ldB, 0);     // dxcnn^T [h][ldB]
+        k_cast_rows(sw, dt, feats, B, LRCN_CNNOUT, B, c->FT, ldB);           // feats^T [4096][ldB] (it already is, in memory)
+        GEMM(c, dt, c->dxcT, ldB, c->FT, ldB, grads[5], LRCN_CNNOUT, h, LRCN_CNNOUT, B, nullptr, true, false, false, false, par);
+        HIPCHK(c, hipEventRecord(c->grad_ev[2], sw));  // group 2: Wproj, Wcnn
     }
     // ---- LSTM 1 ----
     r = lstm_layer_bwd(c, S, B, H1, c->ld4H1, c->A1, c->C1, c->dH1all, c->W1hT, c->dZ1);
     if (r) return r;
+    FORK();
     {
         TrPlan pl{};
         tr(pl, c->dZ1, c->ld4H1, M, 4 * H1, c->TA, 0);
         tr(pl, c->Xemb, c->ldX1, M, X1, c->TB, 0);
         tr(pl, c->H1all, c->ldH1, M - B, H1, boff(c->TB, (int64_t)X1 * ldM, es), M > B ? B : 0);
-        k_transpose_multi(st, dt, pl);
+        k_transpose_multi(sw, dt, pl);
     }
-    GEMM(c, dt, c->TA, ldM, c->TB, ldM, grads[0], X1 + H1, 4 * H1, X1 + H1, M, nullptr, true);
-    k_colsum(st, dt, c->dZ1, c->ld4H1, M, 4 * H1, grads[1]);
-    HIPCHK(c, hipEventRecord(c->grad_ev[3], st));  // group 3: W1, b1
+    GEMM(c, dt, c->TA, ldM, c->TB, ldM, grads[0], X1 + H1, 4 * H1, X1 + H1, M, nullptr, true, false, false, false, par);
+    k_colsum(sw, dt, c->dZ1, c->ld4H1, M, 4 * H1, grads[1]);
+    HIPCHK(c, hipEventRecord(c->grad_ev[3], sw));  // group 3: W1, b1
     GEMM(c, dt, c->dZ1, c->ld4H1, c->W1xT, c->ld4H1, c->dXemb, c->ldX1, M, X1, 4 * H1, nullptr, true);
     if (!two) {
         // LRCN-1f: d[embedding | x_cnn] -- mask all E + h columns in place, sum the right h columns over the steps -> d x_cnn,
-        // then the image-embedding gradient exactly as in the two-layer model
+        // then the image-embedding gradient exactly as in the two-layer model (on sw, after the dW1 GEMM that shares its scratch)
         k_dx2_mask_reduce(st, GEMM_T_F32, c->dXemb, c->ldX1, S, B, E, h, d1, c->dxcnn, c->ldh);
-        k_transpose(st, dt, 1, c->dxcnn, c->ldh, B, h, c->dxcT, ldB, 0);
-        k_cast_rows(st, dt, feats, B, LRCN_CNNOUT, B, c->FT, ldB);
-        GEMM(c, dt, c->dxcT, ldB, c->FT, ldB, grads[5], LRCN_CNNOUT, h, LRCN_CNNOUT, B, nullptr, true);
-        HIPCHK(c, hipEventRecord(c->grad_ev[2], st));  // group 2: Wcnn
+        FORK();
+        k_transpose(sw, dt, 1, c->dxcnn, c->ldh, B, h, c->dxcT, ldB, 0);
+        k_cast_rows(sw, dt, feats, B, LRCN_CNNOUT, B, c->FT, ldB);
+        GEMM(c, dt, c->dxcT, ldB, c->FT, ldB, grads[5], LRCN_CNNOUT, h, LRCN_CNNOUT, B, nullptr, true, false, false, false, par);
+        HIPCHK(c, hipEventRecord(c->grad_ev[2], sw));  // group 2: Wcnn
     }
     HIPCHK(c, hipMemsetAsync(grads[6], 0, sizeof(float) * (size_t)V * E, st));
     k_embed_scatter(st, c->dXemb, c->ldX1, c->tok_in, S, B, E, V, two ? d1 : none, grads[6]);
     HIPCHK(c, hipEventRecord(c->grad_ev[4], st));  // group 4: Wembed
+    if (par) {  // join: whatever follows on the main stream (update!, the next call's scratch reuse) comes after the weight gradients
+        HIPCHK(c, hipEventRecord(c->wg_done, sw));
+        HIPCHK(c, hipStreamWaitEvent(st, c->wg_done, 0));
+    }
+#undef FORK
     KCHK(c, "backward");
     return LRCN_OK;
 }
@@ -676,6 +717,10 @@ void lrcn_destroy(lrcn_ctx *c) {
     for (void *p : c->allocs) (void)hipFree(p);
     for (auto &e : c->grad_ev)
         if (e) (void)hipEventDestroy(e);
+    for (auto &e : c->wg_fork)
+        if (e) (void)hipEventDestroy(e);
+    if (c->wg_done) (void)hipEventDestroy(c->wg_done);
+    if (c->wg_stream) (void)hipStreamDestroy(c->wg_stream);
     comm_destroy(c->comm);
     for (auto &e : c->bucket_done)
         if (e) (void)hipEventDestroy(e);
@@ -776,6 +821,11 @@ int lrcn_create(const lrcn_config *cfg, lrcn_ctx **out) {
             if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return LRCN_EHIP;
         c->gemm_ws_bytes = 48u << 20;
         DALLOC(c, c->gemm_ws, c->gemm_ws_bytes);
+        DALLOC(c, c->wg_ws, c->gemm_ws_bytes);
+        if (hipStreamCreateWithFlags(&c->wg_stream, hipStreamNonBlocking) != hipSuccess) return LRCN_EHIP;
+        for (auto &e : c->wg_fork)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return LRCN_EHIP;
+        if (hipEventCreateWithFlags(&c->wg_done, hipEventDisableTiming) != hipSuccess) return LRCN_EHIP;
         if (cfg->max_images > 0) DALLOC(c, c->vgg_ws, c->gemm_ws_bytes);
         for (int i = 0; i < 4; ++i) {
             DALLOC(c, c->st_f32[i], sizeof(float) * B * Hm);
