@@ -811,12 +811,19 @@ int gemm_8p_config(const GemmArgs &g, int64_t *blocks) {
 // / ReLU / output type.  (f32 atomics instead of slabs were 8x slower here: 16 scattered rows per wave instruction.)
 // Returns the number of slices (0 = not applicable).
 int gemm_8p_splitk(const GemmArgs &g, int64_t *blocks) {
-    if (g.dtype != GEMM_T_BF16 || !gemm_glds_eligible(g) || g.M < 256 || g.N < 128 || (g.N % 4) || g.a_mode != GEMM_A_PLAIN || g.out_mode != GEMM_OUT_PLAIN) return 0;
+    if (g.dtype != GEMM_T_BF16 || !gemm_glds_eligible(g) || g.M < 256 || g.N < 128 || (g.N % 4)) return 0;
+    // plain contractions, and (small image batches: conv5 at 32 images is 50 square tiles) 3x3 convolutions with a bf16 NHWC output,
+    // optionally 2x2-pooled: the slabs keep the kernel's window-major row order, splitk_reduce_conv_kernel undoes it
+    const bool conv = g.a_mode == GEMM_A_CONV3 && g.out_mode != GEMM_OUT_PLAIN && !g.c_f32 && !g.beta && (g.M & 3) == 0;
+    if (!conv && (g.a_mode != GEMM_A_PLAIN || g.out_mode != GEMM_OUT_PLAIN)) return 0;
     if (!g.ws || (g.ldc % 4) || ((uintptr_t)g.C & 15)) return 0;
-    const int kt = g.K / 64;
+    const int kt = conv ? 9 * (g.Cin / 64) : g.K / 64;
     const int64_t b1 = (int64_t)cdiv(g.M, 256) * cdiv(g.N, 128);
     int s = (int)(256 / b1);
-    if (s > kt / 8) s = kt / 8;
+    // slices of >= 8 K-tiles; >= 12 for convolutions (measured per layer, ms without -> with: conv5 at 32 / 16 / 8 images 0.058 -> 0.045,
+    // 0.045 -> 0.032, 0.044 -> 0.030; conv4_2 at 8 images 0.057 -> 0.045; but conv3_1 at 4 images, two slices of 9: 0.023 -> 0.030)
+    const int min_slice = conv ? 12 : 8;
+    if (s > kt / min_slice) s = kt / min_slice;
     if (s > 16) s = 16;
     while (s >= 2 && (size_t)s * g.M * g.N * sizeof(float) > g.ws_bytes) --s;
     if (s < 2) return 0;
@@ -850,10 +857,56 @@ template <typename T> __global__ void splitk_reduce_kernel(const float *ws, int 
         }
     }
 }
+// The convolution form: slab rows are in the kernel's window-major pixel order (common.h decode_pixel: rows 4 w .. 4 w + 3 = one 2x2
+// window).  One thread per (window, 4 channels): bias, ReLU, then either the four pixels to their NHWC places or their maximum to
+// the pooled tensor's row w.  bf16 output.
+__global__ void splitk_reduce_conv_kernel(const float *ws, int S, int M, int N, const float *bias, int relu, bf16_t *C, int64_t ldc, int H,
+                                          int W, int pool) {
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    const int n4 = N >> 2;
+    const int64_t total = (int64_t)(M >> 2) * n4;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int w = (int)(idx / n4), c4 = (int)(idx - (int64_t)w * n4) * 4;
+        const f32x4v b = bias ? *reinterpret_cast<const f32x4v *>(bias + c4) : f32x4v{0.f, 0.f, 0.f, 0.f};
+        f32x4v best = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+            const int m = 4 * w + sub;
+            f32x4v v = *reinterpret_cast<const f32x4v *>(ws + (size_t)m * N + c4);
+            for (int s = 1; s < S; ++s) v += *reinterpret_cast<const f32x4v *>(ws + ((size_t)s * M + m) * N + c4);
+            v += b;
+            if (relu)
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
+            if (pool) {
+                if (sub == 0) best = v;
+                else
+                    for (int r = 0; r < 4; ++r) best[r] = fmaxf(best[r], v[r]);
+            } else {
+                const PixDecode p = decode_pixel(m, H, W);
+                bf16_t *c = C + (((int64_t)p.n * H + p.y) * W + p.x) * ldc + c4;
+                bf16x4 o;
+                for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+                *reinterpret_cast<bf16x4 *>(c) = o;
+            }
+        }
+        if (pool) {
+            bf16x4 o;
+            for (int r = 0; r < 4; ++r) o[r] = (bf16_t)best[r];
+            *reinterpret_cast<bf16x4 *>(C + (int64_t)w * ldc + c4) = o;
+        }
+    }
+}
 }  // namespace
 
 // C = act((beta ? C : 0) + sum of the `splits` f32 slabs [M][N] in g.ws + bias), written in C's type (N, ldc multiples of 4)
 hipError_t launch_splitk_reduce(hipStream_t stream, const GemmArgs &g, int splits) {
+    if (g.a_mode == GEMM_A_CONV3) {
+        const int64_t total = (int64_t)(g.M >> 2) * (g.N >> 2);
+        const int grid = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+        hipLaunchKernelGGL(splitk_reduce_conv_kernel, dim3(grid), dim3(256), 0, stream, reinterpret_cast<const float *>(g.ws), splits, g.M, g.N,
+                           g.bias, g.relu, reinterpret_cast<bf16_t *>(g.C), g.ldc, g.H, g.W, g.out_mode == GEMM_OUT_POOL ? 1 : 0);
+        return hipGetLastError();
+    }
     const int64_t total = (int64_t)g.M * (g.N >> 2);
     const int grid = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
     hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, reinterpret_cast<const float *>(g.ws), splits, g.M,
@@ -883,7 +936,7 @@ hipError_t launch_gemm_8p(hipStream_t stream, const GemmArgs &g0, int splitk) {
     }
     if (splitk > 1) {
         if (gemm_8p_splitk(g, &blocks) != splitk) return hipErrorInvalidValue;
-        hipError_t e = dispatch<GEMM_A_PLAIN, true>(stream, g, 1, splitk);
+        hipError_t e = g.a_mode == GEMM_A_CONV3 ? dispatch<GEMM_A_CONV3, true>(stream, g, 1, splitk) : dispatch<GEMM_A_PLAIN, true>(stream, g, 1, splitk);
         if (e != hipSuccess) return e;
         return launch_splitk_reduce(stream, g, splitk);
     } else {

@@ -34,6 +34,12 @@ LAYERS = [
     ("conv4_3", 28, 512, 512, 1, 64, "8p:0"),
     ("conv5_1", 14, 512, 512, 0, 256, "8p:0"),
     ("conv5_3", 14, 512, 512, 1, 256, "8p:0"),
+    # small image batches (what 8-way data parallelism leaves of 256; the decode batches): too few tiles for the chip -> the K range is
+    # split over workgroups, f32 slabs, and the reduce kernel applies bias / ReLU / pool and undoes the window-major row order
+    ("conv5_1@32", 14, 512, 512, 0, 32, "8p-splitk:2"),
+    ("conv5_3@32", 14, 512, 512, 1, 32, "8p-splitk:2"),
+    ("conv4_3@4", 28, 512, 512, 1, 4, "8p-splitk:4"),
+    ("conv3_2@2", 56, 256, 256, 0, 2, "8p-splitk:3"),
 ]
 
 

@@ -17,7 +17,7 @@ LAYERS = [("conv1_2", 224, 64, 64, 1), ("conv2_1", 112, 64, 128, 0), ("conv2_2",
 def main():
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     only = sys.argv[2].split(",") if len(sys.argv) > 2 else None
-    ctx = L.Context(8, 8, 8, 17, max_B=2, max_T=1, lstm_dtype=lrcn_amd.LRCN_BF16, vgg_dtype=lrcn_amd.LRCN_BF16)
+    ctx = L.Context(8, 8, 8, 17, max_B=2, max_T=1, lstm_dtype=lrcn_amd.LRCN_BF16, vgg_dtype=lrcn_amd.LRCN_BF16, max_images=1)  # max_images: the VGG stream's split-K workspace
     lib = lrcn_amd._lib.lib()
     tot_f = tot_t = 0.0
     for name, S, cin, cout, pool in LAYERS:
@@ -28,7 +28,7 @@ def main():
         fl = 2.0 * N * S * S * cout * 9 * cin
         tot_f += fl
         tot_t += ms.value
-        print("%-8s S=%3d Cin=%3d Cout=%3d pool=%d  %8.3f ms  %7.1f TF" % (name, S, cin, cout, pool, ms.value, fl / ms.value / 1e9))
+        print("%-8s S=%3d Cin=%3d Cout=%3d pool=%d  %8.3f ms  %7.1f TF  %s" % (name, S, cin, cout, pool, ms.value, fl / ms.value / 1e9, L.debug_route(ctx)))
     print("sum %.3f ms  %.1f TF" % (tot_t, tot_f / tot_t / 1e9))
 
 
