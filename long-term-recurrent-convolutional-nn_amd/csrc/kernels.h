@@ -35,9 +35,12 @@ void k_lstm_bwd(hipStream_t st, int dtype, const void *acts, int64_t ld_a, const
 // update (forward) / the dh GEMM of step s + the cell backward of step s-1.
 bool lstm_fused_eligible(int dtype, int B, int H, int64_t ldh, int64_t ld4);
 hipError_t launch_lstm_rec_fwd(hipStream_t st, const void *h_prev, int64_t ldh, const void *Wh, const float *Gx, const float *c_prev, int B,
-                               int H, void *acts, int64_t ld_a, float *c_new, void *h_new, const void *zero_page);
+                               int H, void *acts, int64_t ld_a, float *c_new, void *h_new, const void *zero_page, bool alone = false);
 hipError_t launch_lstm_rec_bwd(hipStream_t st, const void *dz_s, int64_t ld4, const void *WhT, const void *acts, const float *c_prev,
-                               const float *c_new, const float *dh_ext, float *dc, int B, int H, void *dz_out, const void *zero_page);
+                               const float *c_new, const float *dh_ext, float *dc, int B, int H, void *dz_out, const void *zero_page,
+                               bool alone = false);
+// alone: nothing else runs on the GPU beside the LSTM step -- up to LRCN_LSTM_REC2 rows (default 64) the step kernels then take
+// their 8-units-per-workgroup forms (125 / 250 workgroups instead of 63; lstm_fused.hip)
 
 // X2[m][j<nl] *= mask ; X2[m][nl+j] = xcnn[b][j] * mask (j < nr); mask over nl+nr columns      (lrcn.jl:546-547: nl = nr = h;
 // LRCN-1f: nl = E, nr = h)

@@ -305,6 +305,8 @@ int prepare_weights(lrcn_ctx *c, const float *const p[9], bool need_bwd, bool ca
 
 // One LSTM layer over all S steps.  Gx f32 [M][4H] holds the input-side pre-activations (+bias) on entry and the full
 // pre-activations on exit; acts/Call/Hall receive the per-step results.  (lrcn.jl:528-538, time-batched)
+// nothing runs beside the LSTM step: no VGG forward with capped grids on another stream (what the two-stream trainer sets up)
+bool lstm_alone(const lrcn_ctx *c) { return !(c->vgg_wg_cap >= 8 && c->vgg_loaded); }
 bool lstm_fused_on(lrcn_ctx *c, int B, int H, int64_t ldH, int64_t ld4H) {
     const char *k = getenv("LRCN_LSTM_FUSED");  // LRCN_LSTM_FUSED=0: GEMM + cell as separate launches at every batch size
     const char *mb = getenv("LRCN_LSTM_FUSED_MAXB");  // kernel-development knob: largest batch routed to the fused step kernels
@@ -349,7 +351,7 @@ int lstm_layer_fwd(lrcn_ctx *c, int S, int B, int H, int64_t ldH, int64_t ld4H, 
         if (s > 0 && fused) {  // recurrent GEMM + cell in one launch (small batches: launch-latency bound otherwise)
             hipError_t e = launch_lstm_rec_fwd(c->stream, boff(Hall, (int64_t)(s - 1) * B * ldH, c->esz), ldH, Wh, G,
                                                Call + (int64_t)(s - 1) * B * H, B, H, boff(acts, (int64_t)s * B * ld4H, c->esz), ld4H,
-                                               Call + (int64_t)s * B * H, boff(Hall, (int64_t)s * B * ldH, c->esz), c->zero_page);
+                                               Call + (int64_t)s * B * H, boff(Hall, (int64_t)s * B * ldH, c->esz), c->zero_page, lstm_alone(c));
             if (e != hipSuccess) FAIL(c, LRCN_EHIP, "lstm_rec_fwd: %s", hipGetErrorString(e));
             continue;
         }
@@ -404,7 +406,7 @@ int lstm_layer_bwd(lrcn_ctx *c, int S, int B, int H, int64_t ld4H, const void *a
             hipError_t e = launch_lstm_rec_bwd(c->stream, boff(dZ, (int64_t)s * B * ld4H, c->esz), ld4H, WhT,
                                                boff(acts, (int64_t)(s - 1) * B * ld4H, c->esz), s > 1 ? Call + (int64_t)(s - 2) * B * H : nullptr,
                                                Call + (int64_t)(s - 1) * B * H, dHall + (int64_t)(s - 1) * B * H, c->dc, B, H,
-                                               boff(dZ, (int64_t)(s - 1) * B * ld4H, c->esz), c->zero_page);
+                                               boff(dZ, (int64_t)(s - 1) * B * ld4H, c->esz), c->zero_page, lstm_alone(c));
             if (e != hipSuccess) FAIL(c, LRCN_EHIP, "lstm_rec_bwd: %s", hipGetErrorString(e));
         }
         KCHK(c, "lstm_layer_bwd (fused)");

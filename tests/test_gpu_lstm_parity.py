@@ -359,3 +359,33 @@ def test_recurrence_kernel_routes_by_batch_size_vs_oracle_bf16(B):
         rel = np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30)
         assert cos > 0.995 and rel < 0.1, (B, n, cos, rel)
     ctx.close()
+
+
+@pytest.mark.parametrize("B,H", [(40, 320), (32, 1000), (100, 512)])
+def test_fused_recurrence_small_batch_forms_equal_ring_forms(B, H, monkeypatch):
+    # lstm_fused.hip has two forms of the one-launch-per-timestep kernels: 16 hidden units per workgroup with one LDS-DMA ring per wave
+    # (any H, any B <= 128), and -- up to LRCN_LSTM_REC2 rows (default 64) -- 8 units per workgroup: forward (H <= 1024) with the 32-row
+    # h block staged once and shared by the four gate waves, every byte requested up front; backward as 16-row x 8-unit workgroups on
+    # the ring.  Same arithmetic in the same K order per wave: losses within 1e-4, gradients within 1e-2 in norm of each other, and
+    # both within bf16 tolerance of the oracle.  B = 40 / 100: row-block tails (32-row blocks forward, 16-row blocks backward);
+    # H = 1000: the benchmark's K = 1024 / 4032, last workgroup with 8 valid units; H = 320 / 512: K-slices of 5 / 8 K-tiles.
+    rng = np.random.default_rng(B + H)
+    E, V, T = 64, 300, 4
+    m = orc.init_weights(E, H, H, V, seed=5)
+    feats = (rng.standard_normal((B, 4096)) * 0.05).astype(np.float32)
+    tokens = rng.integers(0, V, size=(T, B)).astype(np.int32)
+    ref_loss, ref_g = orc.loss(m, feats, tokens, want_grad=True)
+    res = {}
+    for knob in ("128", "0"):
+        monkeypatch.setenv("LRCN_LSTM_REC2", knob)
+        ctx = L.Context(E, H, H, V, max_B=B, max_T=T, lstm_dtype=lrcn_amd.LRCN_BF16)
+        grads, val = L.lossgradient(ctx, L.model_from_arrays(m.p), L.to_jl(feats), tokens)
+        res[knob] = (val, [L.from_jl(g).astype(np.float64) for g in grads])
+        ctx.close()
+        assert abs(val - ref_loss) <= 2e-2 * abs(ref_loss)
+        for n, g in zip(orc.PARAM_NAMES, res[knob][1]):
+            a, b = g.ravel(), ref_g.p[n].ravel().astype(np.float64)
+            assert a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30) > 0.99, (knob, n)
+    assert abs(res["128"][0] - res["0"][0]) <= 1e-4 * abs(ref_loss)
+    for n, a, b in zip(orc.PARAM_NAMES, res["128"][1], res["0"][1]):
+        assert np.linalg.norm(a - b) <= 1e-2 * np.linalg.norm(b) + 1e-12, n
