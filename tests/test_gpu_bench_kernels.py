@@ -173,3 +173,26 @@ def test_beam_width_larger_than_vocabulary_is_rejected():
     seq, _ = L.beam_search(ctx, param, feat, 5, 3)  # K == V is legal
     assert seq[0] == 1
     ctx.close()
+
+
+def test_vgg_forward_with_layer_inputs_beyond_4GiB_equals_256_image_chunks(biased_vgg):
+    # 1280 images: conv2_2's bf16 input is 4.1 GB, past what the direct-to-LDS kernels address with 32-bit offsets -- the layer is cut
+    # into launches of whole images (lrcn_api.hip launch_conv_chunked) instead of falling through to the register-staged kernel.
+    # Same kernels, same tiles per image => the features equal those of five 256-image forwards (fc6/fc7 split K differently: 1e-3).
+    w, _ = biased_vgg
+    N = 1280
+    g = torch.Generator(device="cuda")
+    g.manual_seed(77)
+    imgs = torch.randint(0, 256, (N, 224, 224, 3), generator=g, device="cuda", dtype=torch.uint8)
+    ctx = L.Context(8, 8, 8, 17, max_B=2, max_T=1, vgg_dtype=lrcn_amd.LRCN_BF16, max_images=N)
+    L.vgg_load(ctx, *w)
+    big = L.from_jl(L.convnet_u8(ctx, imgs)).copy()
+    routes = L.debug_route(ctx, 1)
+    ctx.close()
+    assert routes.startswith("conv64-fused11,conv64,8p:2," + ",".join(["8p:0"] * 9)), routes
+    ctx = L.Context(8, 8, 8, 17, max_B=2, max_T=1, vgg_dtype=lrcn_amd.LRCN_BF16, max_images=256)
+    L.vgg_load(ctx, *w)
+    for s0 in range(0, N, 256):
+        part = L.from_jl(L.convnet_u8(ctx, imgs[s0:s0 + 256]))
+        assert rel_max_err(big[s0:s0 + 256], part) <= 1e-3, s0
+    ctx.close()
