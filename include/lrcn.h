@@ -245,6 +245,11 @@ int lrcn_profile_get(lrcn_ctx *ctx, double *conv_ms, int64_t *conv_launches);
 /* Diagnostic: average milliseconds of one bf16 3x3 convolution layer (N images of S x S x Cin -> Cout, optional fused
  * pool) on random data, `iters` back-to-back launches timed with HIP events.  Kernel-development aid, not the product path. */
 int lrcn_bench_conv(lrcn_ctx *ctx, int N, int S, int Cin, int Cout, int pool, int iters, double *ms_out);
+/* Kernel-development aid: with LRCN_STAMPS=1 in the environment, lrcn_bench_conv's launches of the phase-interleaved kernel record, per
+ * output tile, the shader clock at the boundaries of its segments (8 x uint64 per tile: [0] tile start, [1] first K-tile's DMA issued,
+ * [2] ... landed, [3] main loop done, [4] accumulators staged in LDS, [5] stores issued, [6] unused, [7] 100 MHz wall counter at tile
+ * start).  lrcn_debug_stamps copies the first n values of the most recent launch to the host.  Not the product path. */
+int lrcn_debug_stamps(lrcn_ctx *ctx, unsigned long long *host_out, int64_t n);
 /* Same for one bf16 NT contraction C[M][N] = A[M][K] B[N][K]^T (K a multiple of 64, N of 8) through the library's dispatch. */
 int lrcn_bench_gemm(lrcn_ctx *ctx, int M, int N, int K, int iters, double *ms_out);
 

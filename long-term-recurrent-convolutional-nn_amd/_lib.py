@@ -89,6 +89,7 @@ SIGNATURES = {
     "lrcn_normalize_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "lrcn_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "lrcn_profile_get": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "lrcn_debug_stamps": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int64]),
     "lrcn_bench_conv": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "lrcn_bench_gemm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "lrcn_conv3x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,

@@ -45,6 +45,21 @@ static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 struct PixDecode {
     int n, y, x;
 };
+// The same with the two divisions as multiply-high by host-made reciprocals (fastdiv_inv below): exact while (m >> 2) * d < 2^32 for
+// both divisors d = W / 2 and H / 2; iw == 0 selects the dividing form.  (gemm_8p.hip decodes 4..8 rows per lane in a tile's prologue
+// and 16 in its store loop: with 32-bit divisions those were 2.6k + 8k of the tile's 18.5k cycles outside the K loop.)
+__device__ __forceinline__ PixDecode decode_pixel(int m, int H, int W);
+__device__ __forceinline__ PixDecode decode_pixel_fast(int m, int H, int W, unsigned iw, unsigned ih) {
+    if (iw == 0) return decode_pixel(m, H, W);
+    const unsigned sub = (unsigned)m & 3u, w = (unsigned)m >> 2, W2 = (unsigned)W >> 1, H2 = (unsigned)H >> 1;
+    const unsigned q1 = __umulhi(w, iw), wx = w - q1 * W2;
+    const unsigned q2 = __umulhi(q1, ih), wy = q1 - q2 * H2;
+    PixDecode p;
+    p.n = (int)q2;
+    p.y = (int)(2 * wy + (sub >> 1));
+    p.x = (int)(2 * wx + (sub & 1));
+    return p;
+}
 __device__ __forceinline__ PixDecode decode_pixel(int m, int H, int W) {
     const int sub = m & 3;
     int w = m >> 2;
@@ -58,3 +73,6 @@ __device__ __forceinline__ PixDecode decode_pixel(int m, int H, int W) {
     p.x = 2 * wx + (sub & 1);
     return p;
 }
+
+// floor(2^32 / d) + 1: umulhi(n, inv) == n / d for every n with n * d < 2^32 (0 when d < 2: no reciprocal, divide)
+inline unsigned fastdiv_inv(unsigned d) { return d < 2 ? 0u : (unsigned)((1ull << 32) / d + 1); }

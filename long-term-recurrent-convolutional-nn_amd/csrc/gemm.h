@@ -45,6 +45,7 @@ struct GemmArgs {
     int relu;
     int a_mode, out_mode;
     int H, W, Cin;  // conv geometry (square-agnostic; H, W even)
+    unsigned inv_w2, inv_h2;  // gemm_8p.hip: reciprocals of W / 2 and H / 2 for decode_pixel_fast (set by launch_gemm_8p; 0 = divide)
     int wg_cap;             // > 0: at most this many workgroups (gemm_8p.hip / conv64.hip walk the tiles persistently)
     LstmEpi lstm;           // out_mode GEMM_OUT_LSTM_FWD / _BWD only
     int cfg_pref;           // gemm_8p.hip: 0 = the dispatcher's tile menu, 2 = prefer the 256 x 128 tile (set by the bg_cus route)
@@ -54,6 +55,7 @@ struct GemmArgs {
     int *tile_ctr;          // capped grids only: 8 zeroed ints = per-XCD work queues -- workgroups PULL tiles (8 i + queue) instead of
                             // walking a fixed share, so one that starts late (its CU still busy with another stream's kernel) does
                             // fewer tiles instead of stretching the whole launch; NULL = static round-robin walk
+    unsigned long long *stamps;  // kernel-development: per-tile s_memtime stamps of gemm8p_tile's segments (8 per tile), or NULL
     int dbg;                // kernel-development ablation flags (LRCN_DBG env): 1 = skip steady-state DMA, 2 = skip LDS reads + MFMA
     const void *zero_page;  // >= 256 zero bytes, 16-byte aligned (source of padding rows for the direct-to-LDS path) or NULL
     void *ws;               // split-K workspace (f32 slabs [slices][M][N]) or NULL: enables gemm_8p's split-K form

@@ -70,6 +70,13 @@ __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float 
 // F8: A and B are OCP e4m3 bytes, a K-tile is 128 elements (the same 128-byte LDS rows), one
 // v_mfma_f32_16x16x128_f8f6f4 replaces two v_mfma_f32_16x16x32_bf16 (same cycles, twice the K), the staged epilogue
 // multiplies by g.scale[col] before the bias and writes e4m3.
+// max(x, 0) as ONE integer max on the bits (non-negative floats order like ints, every negative float and -0 is a negative int;
+// a NaN keeps its payload if positive): fmaxf costs two VALU instructions (it quiets NaNs first), and the staged epilogue applies
+// it to 128 accumulators per lane.  lo = 0: ReLU; lo = INT_MIN: identity.
+__device__ __forceinline__ float relu_bits(float x, int lo) {
+    const int b = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, b > lo ? b : lo);
+}
 __device__ __forceinline__ float sigm8p(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 template <int WM, int WN, int MT, int NT, int AMODE, bool SWAP, bool F8, int EPI = 0>
@@ -89,6 +96,13 @@ __device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *sm
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WN, wc = wave % WN;
     const int grp = wave >> 2;  // waves 4..7 run one barrier behind waves 0..3
+    // kernel-development stamps (GemmArgs::stamps, LRCN_STAMPS=1 through lrcn_bench_conv): wave 0 / lane 0 writes the shader clock at
+    // the segment boundaries of this tile into a buffer nothing else reads; slot 7 = the 100 MHz wall counter at tile start
+    auto stamp = [&](int k) {
+        if (g.stamps && tid == 0) g.stamps[(size_t)tile * 8 + k] = k == 7 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();
+    };
+    stamp(7);
+    stamp(0);
     const int M = g.M, N = g.N;
     const int tiles_n = (N + BN - 1) / BN;
     int bid = tile;
@@ -142,15 +156,12 @@ __device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *sm
             a_mask[hf][j] = ~0u;
             if (m < M) {
                 if (AMODE == GEMM_A_CONV3) {
-                    const PixDecode p = decode_pixel(m, g.H, g.W);
+                    const PixDecode p = decode_pixel_fast(m, g.H, g.W, g.inv_w2, g.inv_h2);
                     a_voff[hf][j] = (unsigned)((uint64_t)((p.n * g.H + p.y) * g.W + p.x) * (uint64_t)(g.Cin * ES) + src_chunk * 16);  // < NREC: launch check
-                    unsigned mk = 0;
-#pragma unroll
-                    for (int t = 0; t < 9; ++t) {
-                        const int y = p.y + t / 3 - 1, x = p.x + t % 3 - 1;
-                        if ((unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W) mk |= 1u << t;
-                    }
-                    a_mask[hf][j] = ~mk;  // stored inverted: see stage_a
+                    // bit t = kh * 3 + kw SET = tap t falls outside the image (stored inverted: see stage_a): a border row / column
+                    // knocks out one row / column of taps
+                    a_mask[hf][j] = (p.y == 0 ? 0x007u : 0u) | (p.y == g.H - 1 ? 0x1C0u : 0u) | (p.x == 0 ? 0x049u : 0u) |
+                                    (p.x == g.W - 1 ? 0x124u : 0u) | ~0x1FFu;
                 } else {
                     a_voff[hf][j] = (unsigned)((uint64_t)m * (uint64_t)(g.lda * ES) + src_chunk * 16);
                 }
@@ -233,15 +244,34 @@ __device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *sm
         fb[s] = base + A_BYTES + (wc * WTN) * 128 + fo;
     }
 
+    // bf16 tiles that leave through the LDS-staged epilogue (every convolution, bf16 GEMM outputs): the bias is the accumulators'
+    // INITIAL value (a pooled window's four pixels share it, so max commutes) -- its loads hide under the prologue's DMA wait and the
+    // epilogue is convert + ReLU + LDS write only (with the adds there, and the bias vectors loaded one by one in front of them,
+    // staging took 5.3k cycles of a tile's 18.5k outside the K loop; the pooled form 7.5k)
+    const bool staged = !F8 && EPI == 0 && !g.c_f32 && !g.beta && gridDim.y == 1 && (g.ldc % 8) == 0 && ((uintptr_t)g.C & 15) == 0 &&
+                        (N % 8) == 0 && (!SWAP || (N % 4) == 0);
+    const bool bias_init = staged && g.bias != nullptr;
     f32x4v acc[2][MT][2][NT];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+        for (int n = 0; n < NT; ++n) {
+            f32x4v bv = f32x4v{0.f, 0.f, 0.f, 0.f};
+            if (bias_init) {
+                if constexpr (SWAP) {  // registers 0..3 = four consecutive channels
+                    const int col = n0 + wc * WTN + b * QN + n * 16 + (lane >> 4) * 4;
+                    if (col < N) bv = *reinterpret_cast<const f32x4v *>(g.bias + col);
+                } else {  // registers 0..3 = the four pixels of one window, lane & 15 = channel
+                    const int col = n0 + wc * WTN + b * QN + n * 16 + (lane & 15);
+                    const float sb = col < N ? g.bias[col] : 0.0f;
+                    bv = f32x4v{sb, sb, sb, sb};
+                }
+            }
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+            for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int n = 0; n < NT; ++n) acc[a][i][b][n] = f32x4v{0.f, 0.f, 0.f, 0.f};
+                for (int i = 0; i < MT; ++i) acc[a][i][b][n] = bv;
+        }
 
     uint4 af[MT][2], bf0[NT][2], bf1[NT][2];
     auto read_a = [&](int buf, auto mhc) {
@@ -307,8 +337,10 @@ __device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *sm
         stage_b(0, 0, k0, true);
         stage_b(0, 1, k0, true);
         stage_a(0, 1, k0, true);
+        stamp(1);  // prologue DMA issued
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
+        stamp(2);  // ... landed (and the previous tile's stores retired: one in-order counter)
         if (grp == 1) __builtin_amdgcn_s_barrier();  // stagger
     }
     KStep kn = kstep_of(kbeg + (KT > 1 ? 1 : 0));  // tile t+1
@@ -345,6 +377,7 @@ __device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *sm
     if (grp == 0) __builtin_amdgcn_s_barrier();  // un-stagger
     wait_vmcnt<0>();                             // the tail's dummy pieces
     __builtin_amdgcn_s_barrier();                // nobody reads or DMA-writes the ring any more
+    stamp(3);  // main loop done
 
     const int l15 = lane & 15, lq = lane >> 4;
     // ---------------------------------------------------------------- LSTM epilogues (gemm.h LstmEpi): the cell math in the accumulators.
@@ -432,6 +465,15 @@ __device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *sm
         constexpr int CSTR = BN, CPR8 = BN / 16, RPL = 256 / BN > 1 ? 256 / BN : 1;
         auto swz = [](int r) { return (r / RPL) & (CPR8 - 1); };
         if (!SWAP) {
+            float scp[2][NT], biasp[2][NT];  // all of the lane's scales / biases first: one L2 round trip instead of 2 x 2 NT dependent ones
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const int col = n0 + wc * WTN + nh * QN + n * 16 + l15;
+                    scp[nh][n] = (g.scale && col < N) ? g.scale[col] : 1.0f;
+                    biasp[nh][n] = (g.bias && col < N) ? g.bias[col] : 0.0f;
+                }
 #pragma unroll
             for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
@@ -441,9 +483,8 @@ __device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *sm
 #pragma unroll
                         for (int n = 0; n < NT; ++n) {
                             const int lcol = wc * WTN + nh * QN + n * 16 + l15;
-                            const int col = n0 + lcol;
-                            const float sc = (g.scale && col < N) ? g.scale[col] : 1.0f;
-                            const float bias = (g.bias && col < N) ? g.bias[col] : 0.0f;
+                            const float sc = scp[nh][n];
+                            const float bias = biasp[nh][n];
                             const f32x4v a = acc[mh][i][nh][n];
                             float v = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])) * sc + bias;  // sc > 0: max commutes
                             if (g.relu) v = fmaxf(v, 0.0f);
@@ -452,15 +493,23 @@ __device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *sm
                             smem[prow * CSTR + pos] = (unsigned char)(pack_fp8x4(v, v, 0.f, 0.f) & 0xFF);
                         }
         } else {
+            f32x4v biasv[2][NT], scv[2][NT];
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const int col = n0 + wc * WTN + nh * QN + n * 16 + lq * 4;
+                    biasv[nh][n] = f32x4v{0.f, 0.f, 0.f, 0.f};
+                    scv[nh][n] = f32x4v{1.f, 1.f, 1.f, 1.f};
+                    if (g.bias && col < N) biasv[nh][n] = *reinterpret_cast<const f32x4v *>(g.bias + col);
+                    if (g.scale && col < N) scv[nh][n] = *reinterpret_cast<const f32x4v *>(g.scale + col);
+                }
 #pragma unroll
             for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
                     const int lcol = wc * WTN + nh * QN + n * 16 + lq * 4;
-                    const int col = n0 + lcol;
-                    f32x4v bias = f32x4v{0.f, 0.f, 0.f, 0.f}, sc = f32x4v{1.f, 1.f, 1.f, 1.f};
-                    if (g.bias && col < N) bias = *reinterpret_cast<const f32x4v *>(g.bias + col);
-                    if (g.scale && col < N) sc = *reinterpret_cast<const f32x4v *>(g.scale + col);
+                    const f32x4v bias = biasv[nh][n], sc = scv[nh][n];
 #pragma unroll
                     for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
@@ -492,7 +541,7 @@ __device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *sm
                 const int row = m0 + lrow;
                 if (row >= M) continue;
                 if (g.out_mode == GEMM_OUT_CONV) {
-                    const PixDecode p = decode_pixel(row, g.H, g.W);
+                    const PixDecode p = decode_pixel_fast(row, g.H, g.W, g.inv_w2, g.inv_h2);
                     off = (((int64_t)p.n * g.H + p.y) * g.W + p.x) * g.ldc + col;
                 } else {
                     off = (int64_t)row * g.ldc + col;
@@ -504,11 +553,12 @@ __device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *sm
         }
         return;
     }
-    const bool staged = !g.c_f32 && !g.beta && gridDim.y == 1 && (g.ldc % 8) == 0 && ((uintptr_t)g.C & 15) == 0 &&
-                        (N % 8) == 0 && (!SWAP || (N % 4) == 0);
     if (staged) {
         constexpr int CSTR = BN * 2;  // bytes per staged row; 16-byte chunk c of row r lives at chunk c ^ (r & 15)
-        if (!SWAP) {  // fused 2x2 max-pool: registers 0..3 = the four pixels of one window, lane&15 = channel
+        const int relu_lo = g.relu ? 0 : (int)0x80000000;  // relu_bits: branch-free ReLU (or identity)
+        typedef short s16x2 __attribute__((ext_vector_type(2)));
+        const s16x2 relu_lo2 = g.relu ? s16x2{0, 0} : s16x2{(short)0x8000, (short)0x8000};  // ReLU on the PACKED bf16 pair: one integer max
+        if (!SWAP) {  // fused 2x2 max-pool: registers 0..3 = the four pixels of one window (bias already inside), lane&15 = channel
 #pragma unroll
             for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
@@ -518,70 +568,80 @@ __device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *sm
 #pragma unroll
                         for (int n = 0; n < NT; ++n) {
                             const int lcol = wc * WTN + nh * QN + n * 16 + l15;
-                            const int col = n0 + lcol;
-                            const float bias = (g.bias && col < N) ? g.bias[col] : 0.0f;
                             const f32x4v a = acc[mh][i][nh][n];
-                            float v = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])) + bias;
-                            if (g.relu) v = fmaxf(v, 0.0f);
+                            const float v = relu_bits(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), relu_lo);
                             const int prow = (wr * WTM + mh * QM + i * 16) / 4 + lq;
                             const int pos = ((lcol >> 3) ^ (prow & 15)) * 16 + (lcol & 7) * 2;
                             *reinterpret_cast<bf16_t *>(smem + prow * CSTR + pos) = (bf16_t)v;
                         }
-        } else {  // lane&15 = row (pixel), registers 0..3 = four consecutive channels
+        } else {  // lane&15 = row (pixel), registers 0..3 = four consecutive channels (bias already inside)
 #pragma unroll
             for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
                     const int lcol = wc * WTN + nh * QN + n * 16 + lq * 4;
-                    const int col = n0 + lcol;
-                    f32x4v bias = f32x4v{0.f, 0.f, 0.f, 0.f};
-                    if (g.bias && col < N) bias = *reinterpret_cast<const f32x4v *>(g.bias + col);
 #pragma unroll
                     for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
                         for (int i = 0; i < MT; ++i) {
-                            f32x4v a = acc[mh][i][nh][n] + bias;
-                            if (g.relu) {
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) a[r] = fmaxf(a[r], 0.0f);
-                            }
-                            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-                            bf16x4 o;
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) o[r] = (bf16_t)a[r];
+                            const f32x4v a = acc[mh][i][nh][n];
+                            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                            typedef short s16x4 __attribute__((ext_vector_type(4)));
+                            const bf16x2 o0 = bf16x2{(bf16_t)a[0], (bf16_t)a[1]}, o1 = bf16x2{(bf16_t)a[2], (bf16_t)a[3]};
+                            const s16x2 r0 = __builtin_elementwise_max(__builtin_bit_cast(s16x2, o0), relu_lo2),
+                                        r1 = __builtin_elementwise_max(__builtin_bit_cast(s16x2, o1), relu_lo2);
                             const int lrow = wr * WTM + mh * QM + i * 16 + l15;
                             const int pos = ((lcol >> 3) ^ (lrow & 15)) * 16 + (lcol & 7) * 2;
-                            *reinterpret_cast<bf16x4 *>(smem + lrow * CSTR + pos) = o;
+                            *reinterpret_cast<s16x4 *>(smem + lrow * CSTR + pos) = s16x4{r0[0], r0[1], r1[0], r1[1]};
                         }
                 }
         }
         __syncthreads();
-        const int rows_out = SWAP ? BM : BM / 4;
+        stamp(4);  // accumulators staged
+        constexpr int rows_out = SWAP ? BM : BM / 4;
         bf16_t *Cb = reinterpret_cast<bf16_t *>(g.C);
-        for (int idx = tid; idx < rows_out * CPR; idx += 512) {
-            const int lrow = idx / CPR, ch = idx - lrow * CPR;
-            const int col = n0 + ch * 8;
-            if (col >= N) continue;
-            int64_t off;
-            if (!SWAP) {
-                const int prow = (m0 >> 2) + lrow;
-                if (prow >= (M >> 2)) continue;
-                off = (int64_t)prow * g.ldc + col;
-            } else {
-                const int row = m0 + lrow;
-                if (row >= M) continue;
-                if (g.out_mode == GEMM_OUT_CONV) {
-                    const PixDecode p = decode_pixel(row, g.H, g.W);
-                    off = (((int64_t)p.n * g.H + p.y) * g.W + p.x) * g.ldc + col;
-                } else {
-                    off = (int64_t)row * g.ldc + col;
-                }
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        constexpr int ITER = rows_out * CPR / 512;  // 16-byte chunks per thread
+        static_assert(ITER * 512 == rows_out * CPR, "whole passes of the workgroup");
+        // HB chunks of the thread out of LDS, then their stores (read-wait-store per chunk was ITER dependent LDS round trips in
+        // front of the store issue; all ITER = 16 at once made hipcc spill)
+        constexpr int HB = ITER > 4 ? 4 : ITER;
+        static_assert(ITER % HB == 0, "whole batches");
+        int tid_e = tid;  // opaque copy: otherwise hipcc hoists every iteration's index arithmetic out of the persistent TILE loop and
+        asm volatile("" : "+v"(tid_e));  // keeps ~26 registers alive across the K loop (spilled at kernel start, reloaded here per tile)
+        for (int kb = 0; kb < ITER; kb += HB) {
+            u32x4 chunk[HB];
+#pragma unroll
+            for (int k = 0; k < HB; ++k) {
+                const int idx = tid_e + 512 * (kb + k), lrow = idx / CPR, ch = idx - lrow * CPR;
+                chunk[k] = *reinterpret_cast<const u32x4 *>(smem + lrow * CSTR + ((ch ^ (lrow & 15)) << 4));
             }
-            // non-temporal: the tile is not re-read by this kernel, keep the im2col panels and weights in L2 (+2 % on the VGG stack)
-            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-            __builtin_nontemporal_store(*reinterpret_cast<const u32x4 *>(smem + lrow * CSTR + ((ch ^ (lrow & 15)) << 4)),
-                                        reinterpret_cast<u32x4 *>(Cb + off));
+#pragma unroll
+            for (int k = 0; k < HB; ++k) {
+                const int idx = tid_e + 512 * (kb + k);
+                const int lrow = idx / CPR, ch = idx - lrow * CPR;
+                const int col = n0 + ch * 8;
+                if (col >= N) continue;
+                int64_t off;
+                if (!SWAP) {
+                    const int prow = (m0 >> 2) + lrow;
+                    if (prow >= (M >> 2)) continue;
+                    off = (int64_t)prow * g.ldc + col;
+                } else {
+                    const int row = m0 + lrow;
+                    if (row >= M) continue;
+                    if (g.out_mode == GEMM_OUT_CONV) {
+                        const PixDecode p = decode_pixel_fast(row, g.H, g.W, g.inv_w2, g.inv_h2);
+                        off = (((int64_t)p.n * g.H + p.y) * g.W + p.x) * g.ldc + col;
+                    } else {
+                        off = (int64_t)row * g.ldc + col;
+                    }
+                }
+                // non-temporal: the tile is not re-read by this kernel, keep the im2col panels and weights in L2 (+2 % on the VGG stack)
+                __builtin_nontemporal_store(chunk[k], reinterpret_cast<u32x4 *>(Cb + off));
+            }
         }
+        stamp(5);  // stores issued
         return;
     }
 
@@ -631,7 +691,7 @@ __device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *sm
                     if (row >= M || col0 >= N) continue;
                     int64_t off0;
                     if (g.out_mode == GEMM_OUT_CONV) {
-                        const PixDecode p = decode_pixel(row, g.H, g.W);
+                        const PixDecode p = decode_pixel_fast(row, g.H, g.W, g.inv_w2, g.inv_h2);
                         off0 = (((int64_t)p.n * g.H + p.y) * g.W + p.x) * g.ldc + col0;
                     } else {
                         off0 = (int64_t)row * g.ldc + col0;
@@ -923,6 +983,15 @@ hipError_t launch_gemm_8p(hipStream_t stream, const GemmArgs &g0, int splitk) {
     }
     static const char *dbg = getenv("LRCN_DBG");  // kernel-development ablation flags (gemm.h)
     g.dbg = dbg ? atoi(dbg) : 0;
+    g.inv_w2 = g.inv_h2 = 0;
+    if ((g.a_mode == GEMM_A_CONV3 || g.out_mode == GEMM_OUT_CONV || g.out_mode == GEMM_OUT_POOL) && g.W >= 4 && g.H >= 4) {
+        const uint64_t wmax = (uint64_t)((g.M + 511) >> 2) + 128, dmax = (uint64_t)(g.W > g.H ? g.W : g.H) >> 1;  // rows past M in the last tile included
+        static const char *nofd = getenv("LRCN_FASTDIV");  // LRCN_FASTDIV=0: the dividing decode (tests compare the two)
+        if (wmax * dmax < (1ull << 32) && !(nofd && nofd[0] == '0')) {
+            g.inv_w2 = fastdiv_inv((unsigned)g.W >> 1);
+            g.inv_h2 = fastdiv_inv((unsigned)g.H >> 1);
+        }
+    }
     int64_t blocks = 0;
     int cfg = gemm_8p_config(g, &blocks);
     if (cfg < 0) return hipErrorInvalidValue;

@@ -118,6 +118,8 @@ struct lrcn_ctx {
     hipStream_t wg_stream = nullptr;
     hipEvent_t wg_fork[4] = {}, wg_done = nullptr;
     void *wg_ws = nullptr;
+    unsigned long long *stamps = nullptr;  // kernel-development: per-tile segment stamps (LRCN_STAMPS=1, lrcn_debug_stamps)
+    int64_t stamps_n = 0;
     int *tile_ctr = nullptr;  // per-layer work queues of the capped persistent convolution grids (GemmArgs::tile_ctr)
     LrcnComm *comm = nullptr;
     hipStream_t comm_stream = nullptr;  // every collective of the communicator is issued on this ONE stream, in group order
@@ -1465,6 +1467,15 @@ int conv_layer(lrcn_ctx *c, int dtype, const void *in, const VggLayer &L, int N,
     g.ws_bytes = c->vgg_ws ? c->gemm_ws_bytes : 0;
     g.wg_cap = c->vgg_wg_cap;
     g.tile_ctr = (c->vgg_wg_cap >= 8 && c->vgg_wg_cap <= 512) ? tile_ctr : nullptr;
+    if (getenv("LRCN_STAMPS")) {  // kernel-development (include/lrcn.h lrcn_debug_stamps)
+        const int64_t need = ((int64_t)g.M / 256 + 1) * ((int64_t)g.N / 128 + 1) * 8;
+        if (need > c->stamps_n) {
+            c->stamps = nullptr;  // the previous, smaller buffer stays on the context's allocation list until lrcn_destroy
+            DALLOC(c, c->stamps, sizeof(unsigned long long) * (size_t)need);
+            c->stamps_n = need;
+        }
+        g.stamps = c->stamps;
+    }
     hipError_t e = launch_conv_chunked(c->stream, g, N, dtype == GEMM_T_BF16 ? 2 : 4);
     if (e != hipSuccess) FAIL(c, LRCN_EHIP, "conv layer S=%d Cin=%d Cout=%d: %s", L.S, L.Cin, L.Cout, hipGetErrorString(e));
     return LRCN_OK;
@@ -1692,6 +1703,15 @@ int lrcn_train_step_dp(lrcn_ctx *c, float *const p[9], float *const g[9], float 
     r = join_buckets(c);  // the next step's shadow-weight pass reads the updated parameters
     if (r) return r;
     return loss_host ? fetch_loss(c, loss_host) : LRCN_OK;
+}
+
+int lrcn_debug_stamps(lrcn_ctx *c, unsigned long long *host_out, int64_t n) {
+    DeviceGuard dg(c);
+    if (!c || !host_out || n < 1) return LRCN_EINVAL;
+    if (!c->stamps || n > c->stamps_n) FAIL(c, LRCN_ESTATE, "no stamps recorded (LRCN_STAMPS=1 and lrcn_bench_conv first), or n > %lld", (long long)c->stamps_n);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(host_out, c->stamps, sizeof(unsigned long long) * (size_t)n, hipMemcpyDeviceToHost));
+    return LRCN_OK;
 }
 
 const char *lrcn_debug_route(lrcn_ctx *c, int which) {
