@@ -316,7 +316,7 @@ bool lstm_fused_on(lrcn_ctx *c, int B, int H, int64_t ldH, int64_t ld4H) {
 }
 // The recurrent GEMM with the cell math in its epilogue (gemm_8p.hip GEMM_OUT_LSTM_*), for the two-stream training step at 256..512
 // rows per GPU: one launch of 32 (forward) / 8 (backward) workgroups per timestep instead of GEMM + cell kernel.  MEASURED AND LEFT
-// OFF (LRCN_LSTM_EPI=1 turns it on; tests/test_gpu_lstm_parity.py checks it against the oracle): the cell math is HBM/L2 traffic
+// OFF (LRCN_LSTM_EPI=1 turns it on; tests/test_gpu_lstm_parity.py checks it against the CPU oracle): the cell math is HBM/L2 traffic
 // (9 MB per step) that wants many CUs, and inside a 32- or 8-workgroup GEMM it runs at those few CUs' bandwidth -- per timestep,
 // beside the VGG forward: forward 45 us fused vs 27 + 9.6 us, backward 87 us fused vs 55 + 8.7 us; training step 7.49 vs 7.22 ms.
 bool lstm_epi_on(lrcn_ctx *c, int B) {
