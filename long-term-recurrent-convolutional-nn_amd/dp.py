@@ -104,6 +104,12 @@ class HipOps:
     def comm_init(self, world, rank, unique_id):
         L.comm_init(self.ctx, world, rank, unique_id)
 
+    def comm_destroy(self):
+        try:
+            L.comm_destroy(self.ctx)
+        except L.LrcnError:
+            pass
+
     def train_step_dp(self, param, grads, optim, feats, tokens, norm_B, pdrop, seed):
         L.train_step_dp(self.ctx, param, optim, grads, feats, tokens, norm_B=norm_B, pdrop=pdrop, seed=seed)
 
@@ -128,11 +134,37 @@ class DataParallelTrainer:
             raise L.LrcnError("unknown data-parallel backend %r" % (backend,))
         self.backend = backend
         if backend == "abi" and world > 1:
-            uid = torch.zeros(128, dtype=torch.uint8, device=param[0].device)
+            # the RCCL unique id travels over torch.distributed's group; byte 128 = rank 0 could make one.  If the library's own
+            # communicator cannot be set up on EVERY rank (librccl not loadable from liblrcn_hip, init error), all ranks agree to use
+            # the torch.distributed collectives instead -- still RCCL over xGMI, issued from Python -- and rank 0 says so.
+            uid = torch.zeros(129, dtype=torch.uint8, device=param[0].device)
+            why = ""
             if rank == 0:
-                uid.copy_(torch.frombuffer(bytearray(L.comm_unique_id()), dtype=torch.uint8))
+                try:
+                    uid[:128].copy_(torch.frombuffer(bytearray(L.comm_unique_id()), dtype=torch.uint8))
+                    uid[128] = 1
+                except L.LrcnError as e:
+                    why = str(e)
             dist.broadcast(uid, 0, group=group)
-            self.ops.comm_init(world, rank, bytes(uid.cpu().numpy().tobytes()))
+            ok = torch.ones(1, dtype=torch.int32, device=param[0].device)
+            host = uid.cpu().numpy()
+            if host[128]:
+                try:
+                    self.ops.comm_init(world, rank, bytes(host[:128].tobytes()))
+                except L.LrcnError as e:
+                    why = str(e)
+                    ok.zero_()
+            else:
+                ok.zero_()
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+            if int(ok.item()) == 0:
+                if hasattr(self.ops, "comm_destroy"):
+                    self.ops.comm_destroy()
+                self.backend = "torch"
+                if rank == 0:
+                    import sys
+                    print("lrcn_amd.dp: C-ABI communicator unavailable (%s); using torch.distributed collectives" % (why or "another rank failed"),
+                          file=sys.stderr)
         self.flat_grads, self.grads = flat_model_like([tuple(t.shape) for t in param], device=param[0].device)
         self.step_no = 0
         self._feats_next = None

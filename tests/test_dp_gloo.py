@@ -92,8 +92,32 @@ def _worker(rank, world, port, golden, out, mode="plain"):
     param = [torch.as_tensor(np.array(z["p_" + n])) for n in orc.PARAM_NAMES]
     Bg = z["feats"].shape[0]
     rows = dp.shard_rows(Bg, world, rank)
-    ops = OracleOps(dims) if mode == "plain" else OracleGroupOps(dims)
-    tr = dp.DataParallelTrainer(None, param, HostAdam(param), Bg, world, rank, pdrop=0.0, ops=ops)
+    if mode == "abi_fallback":
+        # the C-ABI communicator cannot be set up (here: on rank 1 only): every rank must agree to fall back to torch.distributed
+        from lrcn_amd import lrcn as L
+
+        class FailingAbiOps(OracleOps):
+            destroyed = False
+
+            def train_step_dp(self, *a, **k):
+                raise AssertionError("the fallback must not take the C-ABI step")
+
+            def comm_init(self, world_, rank_, uid):
+                assert len(uid) == 128
+                if rank_ == 1:
+                    raise L.LrcnError("simulated: librccl not loadable")
+
+            def comm_destroy(self):
+                self.destroyed = True
+
+        import unittest.mock as mock
+        ops = FailingAbiOps(dims)
+        with mock.patch.object(L, "comm_unique_id", lambda: bytes(range(128))):
+            tr = dp.DataParallelTrainer(None, param, HostAdam(param), Bg, world, rank, pdrop=0.0, ops=ops, backend="abi")
+        assert tr.backend == "torch" and ops.destroyed
+    else:
+        ops = OracleOps(dims) if mode == "plain" else OracleGroupOps(dims)
+        tr = dp.DataParallelTrainer(None, param, HostAdam(param), Bg, world, rank, pdrop=0.0, ops=ops)
     assert tr.backend == "torch"
     feats = torch.as_tensor(z["feats"][rows])
     toks = z["tokens"][:, rows]
@@ -120,11 +144,11 @@ def _worker(rank, world, port, golden, out, mode="plain"):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["plain", "group_pipeline", "bucket_one_adam"])
+@pytest.mark.parametrize("mode", ["plain", "group_pipeline", "bucket_one_adam", "abi_fallback"])
 def test_two_rank_step_equals_full_batch(golden_dir, tmp_path, mode):
     golden = os.path.join(golden_dir, "lstm_mid.npz")
     out = str(tmp_path / "dp.npz")
-    port = 29500 + (os.getpid() % 2000) + {"plain": 0, "group_pipeline": 1, "bucket_one_adam": 2}[mode]
+    port = 29500 + (os.getpid() % 2000) + {"plain": 0, "group_pipeline": 1, "bucket_one_adam": 2, "abi_fallback": 3}[mode]
     mp.spawn(_worker, args=(2, port, golden, out, mode), nprocs=2, join=True)
     got = np.load(out)
     # single-process reference: two full-batch steps with the oracle
