@@ -247,7 +247,7 @@ int lrcn_profile_get(lrcn_ctx *ctx, double *conv_ms, int64_t *conv_launches);
 int lrcn_bench_conv(lrcn_ctx *ctx, int N, int S, int Cin, int Cout, int pool, int iters, double *ms_out);
 /* Kernel-development aid: with LRCN_STAMPS=1 in the environment, lrcn_bench_conv's launches of the phase-interleaved kernel record, per
  * output tile, the shader clock at the boundaries of its segments (8 x uint64 per tile: [0] tile start, [1] first K-tile's DMA issued,
- * [2] ... landed, [3] main loop done, [4] accumulators staged in LDS, [5] stores issued, [6] unused, [7] 100 MHz wall counter at tile
+ * [2] ... landed, [3] main loop done, [4] accumulators staged in LDS, [5] stores issued, [6] / [7] 100 MHz wall counter at tile end /
  * start).  lrcn_debug_stamps copies the first n values of the most recent launch to the host.  Not the product path. */
 int lrcn_debug_stamps(lrcn_ctx *ctx, unsigned long long *host_out, int64_t n);
 /* Same for one bf16 NT contraction C[M][N] = A[M][K] B[N][K]^T (K a multiple of 64, N of 8) through the library's dispatch. */

@@ -97,9 +97,9 @@ __device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *sm
     const int wr = wave / WN, wc = wave % WN;
     const int grp = wave >> 2;  // waves 4..7 run one barrier behind waves 0..3
     // kernel-development stamps (GemmArgs::stamps, LRCN_STAMPS=1 through lrcn_bench_conv): wave 0 / lane 0 writes the shader clock at
-    // the segment boundaries of this tile into a buffer nothing else reads; slot 7 = the 100 MHz wall counter at tile start
+    // the segment boundaries of this tile into a buffer nothing else reads; slots 7 / 6 = the 100 MHz wall counter at tile start / end
     auto stamp = [&](int k) {
-        if (g.stamps && tid == 0) g.stamps[(size_t)tile * 8 + k] = k == 7 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();
+        if (g.stamps && tid == 0) g.stamps[(size_t)tile * 8 + k] = k >= 6 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();
     };
     stamp(7);
     stamp(0);
@@ -642,6 +642,7 @@ __device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *sm
             }
         }
         stamp(5);  // stores issued
+        stamp(6);  // ... and the 100 MHz wall counter again: (stamp 5 - stamp 0) / (stamp 6 - stamp 7) = shader cycles per 10 ns
         return;
     }
 

@@ -46,9 +46,9 @@ def main():
         # whole-tile time: consecutive tiles on one CU are not identifiable without a cap; use start-to-stores-issued + the next wait
         tile = np.median(st[:, 5] - st[:, 0])
         kt = 9 * cin // 64
-        # clock: shader cycles per 100 MHz tick between the earliest and the latest tile start
-        i0, i1 = int(np.argmin(st[:, 7])), int(np.argmax(st[:, 7]))
-        ghz = (st[i1, 0] - st[i0, 0]) / max(1, (st[i1, 7] - st[i0, 7])) / 10.0
+        # clock the chip holds inside the kernel: shader cycles per 10 ns tick of the wall counter, per tile, median
+        ticks = (st[:, 6] - st[:, 7]).astype(np.float64)
+        ghz = float(np.median((st[:, 5] - st[:, 0]) / np.maximum(ticks, 1.0))) / 10.0
         print("%-8s %-6s %6d | %8.0f %8.0f %8.0f %8.0f %8.0f | %8.0f %8.1f  %5.2f" % (name, route, ntiles, seg(0, 1), seg(1, 2), seg(2, 3), seg(3, 4),
                                                                               seg(4, 5), tile, seg(2, 3) / kt, ghz))
     ctx.close()
