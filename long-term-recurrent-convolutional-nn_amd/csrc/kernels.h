@@ -33,6 +33,8 @@ void k_lstm_bwd(hipStream_t st, int dtype, const void *acts, int64_t ld_a, const
 
 // Small-batch fused recurrent steps (lstm_fused.hip; bf16, B <= 64): one launch = the recurrent GEMM of a timestep + the cell
 // update (forward) / the dh GEMM of step s + the cell backward of step s-1.
+// batched beam search: histories = [bos, 0, ...], next input = bos, probabilities = 1 for all R hypotheses (lrcn.jl:608-611)
+void k_beam_init(hipStream_t st, int32_t *seq, int32_t *last, float *p, int R, int Lh, int bos);
 bool lstm_fused_eligible(int dtype, int B, int H, int64_t ldh, int64_t ld4);
 hipError_t launch_lstm_rec_fwd(hipStream_t st, const void *h_prev, int64_t ldh, const void *Wh, const float *Gx, const float *c_prev, int B,
                                int H, void *acts, int64_t ld_a, float *c_new, void *h_new, const void *zero_page, bool alone = false);

@@ -1166,6 +1166,22 @@ void k_img_u8_to_bf16(hipStream_t st, const uint8_t *img, int64_t n, float m0, f
 void k_resize_crop_u8(hipStream_t st, const uint8_t *src, const void *meta, int N, int S, uint8_t *out) {
     hipLaunchKernelGGL(resize_crop_u8_kernel, dim3(grid1d((int64_t)N * S * S)), dim3(256), 0, st, src, (const ImgMeta *)meta, N, S, out);
 }
+namespace {
+__global__ void beam_init_kernel(int32_t *seq, int32_t *last, float *p, int R, int Lh, int bos) {
+    const int64_t total = (int64_t)R * Lh;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i / Lh), j = (int)(i - (int64_t)q * Lh);
+        seq[i] = j == 0 ? bos : 0;
+        if (j == 0) {
+            last[q] = bos;
+            p[q] = 1.0f;
+        }
+    }
+}
+}  // namespace
+void k_beam_init(hipStream_t st, int32_t *seq, int32_t *last, float *p, int R, int Lh, int bos) {
+    hipLaunchKernelGGL(beam_init_kernel, dim3(grid1d((int64_t)R * Lh)), dim3(256), 0, st, seq, last, p, R, Lh, bos);
+}
 void k_normalize_rows(hipStream_t st, float *feats, int N, int F) {
     hipLaunchKernelGGL(normalize_rows_kernel, dim3(N), dim3(256), 0, st, feats, N, F);
 }

@@ -77,6 +77,10 @@ def main():
             outs += L.beam_search_batch(ctx, param, L.to_jl(fbuf[k & 1][s:min(N, s + a.chunk)]), K, nword)
         return outs
 
+    import gc  # see tools/beam_bench.py: a full cyclic-GC pass in the middle of a decode costs more than the decode
+    gc.collect()
+    gc.freeze()
+
     def run(passes):
         ev = vgg_async(0)
         outs = None

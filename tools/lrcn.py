@@ -166,6 +166,9 @@ def main(argv=None):
                 break
         os.makedirs(o.out, exist_ok=True)
         suffix = "_flickr" if o.flickr else ".txt"
+        import gc  # tools/beam_bench.py: keep full cyclic-GC passes (tens of ms with torch's objects) out of the decode loop
+        gc.collect()
+        gc.freeze()
         with open(os.path.join(o.out, "candidates" + suffix), "w") as out, open(os.path.join(o.out, "candidate_ids" + suffix), "w") as ido:
             for s0 in range(0, len(ids), gen_chunk):  # the reference decodes image by image; here gen_chunk images x beam_width rows per step
                 chunk = ids[s0:s0 + gen_chunk]
