@@ -1772,6 +1772,10 @@ int lrcn_bench_conv(lrcn_ctx *c, int N, int S, int Cin, int Cout, int pool, int 
     k_init_uniform(c->stream, tmp, (int64_t)w_e, (float)std::sqrt(2.0 / (9.0 * Cin)), 12, 1);
     k_cast_rows(c->stream, GEMM_T_BF16, tmp, 9 * Cin, Cout, 9 * Cin, w, 9 * Cin);
     k_fill(c->stream, bias, Cout, 0.01f);
+    if (getenv("LRCN_BENCH_ZERO")) {  // all-zero operands: the same instruction stream at the clock the chip holds WITHOUT data toggling
+        (void)hipMemsetAsync(in, 0, 2 * in_e, c->stream);   // (MI355X_MICROARCH.md, DVFS give-back): separates issue efficiency from power
+        (void)hipMemsetAsync(w, 0, 2 * w_e, c->stream);
+    }
     VggLayer L;
     L.w = w; L.b = bias; L.Cin = Cin; L.Cout = Cout; L.S = S; L.pool = pool;
     int r = conv_layer(c, GEMM_T_BF16, in, L, N, out);  // warm-up
