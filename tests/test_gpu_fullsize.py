@@ -4,7 +4,11 @@ B = 128 / 256, bf16), where the CPU oracle would take minutes:
   * sharding: lossgradient on 256 rows == sum over 8 row-shards of 32 normalised by the GLOBAL batch (lrcn.jl:564-568) --
     exactly what the data-parallel ranks compute before the all-reduce (SURVEY 8e), here on one GPU;
   * linearity of the frozen extractor's last layer: VGG features of a batch == features of its halves;
-  * Adam: one update! moves every parameter by at most lr (|m/(sqrt(v)+eps)| <= 1 after bias correction at t = 1)."""
+  * Adam: one update! moves every parameter by at most lr (|m/(sqrt(v)+eps)| <= 1 after bias correction at t = 1);
+  * the normaliser: doubling the reference's global `batchsize` (lrcn.jl:564-568) halves loss and every gradient (a power of two commutes
+    with every rounding on the path: what remains is the summation order of the float atomics, 1e-6);
+  * the batch is a set: permuting its rows leaves the loss and the gradients unchanged up to summation order;
+  * beam width 1 is greedy decoding: each token is the arg-max of the step logits that lrcn() gives for the history so far."""
 import math
 
 import numpy as np
@@ -82,4 +86,68 @@ def test_vgg_batch_equals_its_halves():
     a = L.from_jl(L.convnet_u8(ctx, img[:8].contiguous()))
     b = L.from_jl(L.convnet_u8(ctx, img[8:].contiguous()))
     np.testing.assert_allclose(np.concatenate([a, b]), full, rtol=0, atol=2e-2 * np.abs(full).max())
+    ctx.close()
+
+
+def test_doubling_the_global_batchsize_halves_loss_and_gradients():
+    # a power of two commutes with every rounding on the path, so the two calls differ only by what two IDENTICAL calls differ by at
+    # this size: the summation order of the float atomics (split-K of the skinny GEMMs in gemm_glds.hip, bias column sums, the
+    # embedding scatter, the loss accumulator) -- 1e-4 of a tensor's norm (tools/determinism_check.py; at 32 rows only Wembed varies)
+    V, B, T = 10640, 256, 11
+    ctx, param, feats, tokens = make(V, B, T)
+    g1, l1 = L.lossgradient(ctx, param, L.to_jl(feats), tokens, norm_B=B)
+    g1 = [L.from_jl(g).astype(np.float64) for g in g1]
+    g2, l2 = L.lossgradient(ctx, param, L.to_jl(feats), tokens, norm_B=2 * B)
+    assert abs(l2 - 0.5 * l1) <= 1e-8 * l1
+    for name, a, b in zip("W1 b1 W2 b2 Wproj Wcnn Wembed Wout bout".split(), g1, g2):
+        b = L.from_jl(b).astype(np.float64)
+        rel = np.linalg.norm(b - 0.5 * a) / (np.linalg.norm(0.5 * a) + 1e-300)
+        assert rel < 1e-3, (name, rel)  # a different f32 summation order flips bf16 roundings (4e-3 each) of a few intermediate values
+    ctx.close()
+
+
+def test_permuting_the_batch_rows_changes_nothing():
+    V, B, T = 10640, 256, 11
+    ctx, param, feats, tokens = make(V, B, T)
+    g1, l1 = L.lossgradient(ctx, param, L.to_jl(feats), tokens)
+    g1 = [L.from_jl(g).astype(np.float64) for g in g1]
+    perm = np.random.default_rng(5).permutation(B)
+    g2, l2 = L.lossgradient(ctx, param, L.to_jl(feats[perm]), np.ascontiguousarray(tokens[:, perm]))
+    assert abs(l2 - l1) <= 1e-6 * abs(l1)
+    for name, a, b in zip("W1 b1 W2 b2 Wproj Wcnn Wembed Wout bout".split(), g1, g2):
+        b = L.from_jl(b).astype(np.float64)
+        rel = np.linalg.norm(a - b) / (np.linalg.norm(a) + 1e-30)
+        assert rel < 5e-3, (name, rel)  # bf16 operands, f32 accumulation in another order
+    ctx.close()
+
+
+def test_beam_width_one_is_greedy_decoding():
+    V, N, nword = 10640, 8, 12
+    ctx = L.Context(1000, 1000, 1000, V, max_B=N, max_T=1, lstm_dtype=lrcn_amd.LRCN_BF16)
+    param = L.initweights(ctx, seed=7)
+    param[8].copy_(torch.randn(param[8].shape, device="cuda") * 2.0)  # a spread-out word prior, so that arg-max margins are not razor-thin
+    feats = (np.random.default_rng(1).standard_normal((N, 4096)) * 0.05).astype(np.float32)
+    out = L.beam_search_batch(ctx, param, L.to_jl(feats), 1, nword)
+    state = L.initstate(ctx, N)
+    xc = torch.mm(torch.as_tensor(feats).cuda(), param[5])  # input * Wcnn (lrcn.jl:558, 611)
+    xcnn = L.jl_empty(*xc.shape)
+    xcnn.copy_(xc)
+    tok = np.full(N, L.BOS, np.int32)
+    alive = np.ones(N, bool)
+    for s in range(nword + 1):
+        x_lstm = L.jl_empty(N, 1000)
+        x_lstm.copy_(param[6][torch.as_tensor(tok.astype(np.int64)).cuda()])  # embedding rows of the previous tokens (lrcn.jl:650)
+        logits = L.from_jl(L.lrcn(ctx, param, state, xcnn, x_lstm))
+        top2 = np.sort(logits, axis=1)[:, -2:]
+        nxt = logits.argmax(axis=1).astype(np.int32)
+        for n in range(N):
+            toks = out[n][0]
+            if alive[n] and s + 1 < len(toks) and top2[n, 1] - top2[n, 0] > 0.05:  # bf16 step GEMMs: only clear margins are compared
+                assert toks[s + 1] == nxt[n], (n, s, toks, nxt[n])
+            if s + 1 < len(toks):
+                nxt[n] = toks[s + 1]  # follow the decoder's own history
+                alive[n] &= toks[s + 1] != L.EOS
+            else:
+                alive[n] = False
+        tok = nxt
     ctx.close()
