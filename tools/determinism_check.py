@@ -27,3 +27,16 @@ for wg in ("1", "0"):
         diff = {n: int((x != y).sum()) for n, x, y in zip(names, runs[0][0], runs[a][0])}
         print("WG_STREAM=%s run0 vs run%d: loss %r %r; differing elements %s" % (wg, a, runs[0][1], runs[a][1], {k: v for k, v in diff.items() if v}))
     ctx.close()
+
+import torch  # noqa: E402
+w = L.synthetic_vgg_weights(seed=3, bias_std=0.1)
+g = torch.Generator(device="cuda")
+g.manual_seed(5)
+imgs = torch.randint(0, 256, (B, 224, 224, 3), generator=g, device="cuda", dtype=torch.uint8)
+for vdt, nm in ((lrcn_amd.LRCN_BF16, "bf16"),):
+    ctx = L.Context(8, 8, 8, 17, max_B=2, max_T=1, vgg_dtype=vdt, max_images=B)
+    L.vgg_load(ctx, *w)
+    a = L.from_jl(L.convnet_u8(ctx, imgs)).copy()
+    b = L.from_jl(L.convnet_u8(ctx, imgs)).copy()
+    print("VGG forward %s, %d images: differing feature elements between two calls: %d" % (nm, B, int((a != b).sum())))
+    ctx.close()
