@@ -79,8 +79,22 @@ __device__ __forceinline__ float relu_bits(float x, int lo) {
 }
 __device__ __forceinline__ float sigm8p(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// Per-tile operand addressing of one lane: survives from the epilogue of tile t, where the persistent walk may already set it up for
+// tile t + 1 and issue that tile's first K-tile (below), into tile t + 1's K loop.
+template <int APW, int BPW> struct TileAddr {
+    int m0, n0;
+    unsigned a_voff[2][APW];  // byte offset of this lane's 16-byte chunk of the piece (OOB: row >= M)
+    unsigned a_mask[2][APW];  // conv: bit t CLEAR = tap t reads inside the image
+    unsigned b_voff[2][BPW];
+};
+
+// One output tile.  `pre`: ta already describes `tile` and its first K-tile's DMA is in flight (issued by the previous call).
+// `next_tile` >= 0: the tile this workgroup visits next; where the epilogue leaves ring buffer 0 free early (the bf16 pooled
+// epilogue) it sets ta up for that tile and issues its first K-tile BEFORE the global stores of this one, so that the set-up and the
+// DMA's latency -- a cold HBM fetch of new image rows -- run under the store issue instead of after it.  Returns whether it did.
 template <int WM, int WN, int MT, int NT, int AMODE, bool SWAP, bool F8, int EPI = 0>
-__device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *smem, const int tile, const int ntiles_xy) {
+__device__ __forceinline__ bool gemm8p_tile(const GemmArgs &g, unsigned char *smem, const int tile, const int ntiles_xy, const int next_tile,
+                                            TileAddr<WM * (2 * MT * 16) / 128, WN * (2 * NT * 16) / 128> &ta, const bool pre) {
     constexpr int ES = F8 ? 1 : 2;       // bytes per element
     constexpr int KE = 128 / ES;         // elements per K-tile
     static_assert(WM * WN == 8, "8 waves");
@@ -105,14 +119,6 @@ __device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *sm
     stamp(0);
     const int M = g.M, N = g.N;
     const int tiles_n = (N + BN - 1) / BN;
-    int bid = tile;
-    {   // bijective XCD renumbering: the N-tiles of one im2col panel (consecutive logical ids) share an XCD's L2
-        // (workgroup w sits on XCD w % 8 and visits tiles w, w + G, ...: tile % 8 == w % 8 as long as 8 divides G)
-        const int nwg = ntiles_xy, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    const int nt = bid % tiles_n, mt = bid / tiles_n;
-    const int m0 = mt * BM, n0 = nt * BN;
 
     // Operands are addressed through buffer descriptors (buffer_load_dwordx4 ... lds): the per-lane byte offset of a piece is
     // loop-invariant, the K-step offset rides in the scalar soffset, and a lane whose row / tap falls outside the matrix /
@@ -142,39 +148,47 @@ __device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *sm
         const int hr = (wave * BPW + j) * 8;
         return (hr / QN) * WTN + hf * QN + (hr % QN);
     };
-    unsigned a_voff[2][APW];  // byte offset of this lane's 16-byte chunk of the piece (OOB: row >= M)
-    unsigned a_mask[2][APW];  // conv: bit t CLEAR = tap t reads inside the image
-    unsigned b_voff[2][BPW];
+    auto setup = [&](int t, TileAddr<APW, BPW> &o) {
+        int bid = t;
+        {   // bijective XCD renumbering: the N-tiles of one im2col panel (consecutive logical ids) share an XCD's L2
+            // (workgroup w sits on XCD w % 8 and visits tiles w, w + G, ...: tile % 8 == w % 8 as long as 8 divides G)
+            const int nwg = ntiles_xy, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+            bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        }
+        const int nt = bid % tiles_n, mt = bid / tiles_n;
+        o.m0 = mt * BM;
+        o.n0 = nt * BN;
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
+        for (int hf = 0; hf < 2; ++hf) {
 #pragma unroll
-        for (int j = 0; j < APW; ++j) {
-            const int row = a_piece_row(hf, j) + (lane >> 3);
-            const int m = m0 + row;
-            const int src_chunk = (lane & 7) ^ ((row >> 1) & 7);
-            a_voff[hf][j] = OOB;
-            a_mask[hf][j] = ~0u;
-            if (m < M) {
-                if (AMODE == GEMM_A_CONV3) {
-                    const PixDecode p = decode_pixel_fast(m, g.H, g.W, g.inv_w2, g.inv_h2);
-                    a_voff[hf][j] = (unsigned)((uint64_t)((p.n * g.H + p.y) * g.W + p.x) * (uint64_t)(g.Cin * ES) + src_chunk * 16);  // < NREC: launch check
-                    // bit t = kh * 3 + kw SET = tap t falls outside the image (stored inverted: see stage_a): a border row / column
-                    // knocks out one row / column of taps
-                    a_mask[hf][j] = (p.y == 0 ? 0x007u : 0u) | (p.y == g.H - 1 ? 0x1C0u : 0u) | (p.x == 0 ? 0x049u : 0u) |
-                                    (p.x == g.W - 1 ? 0x124u : 0u) | ~0x1FFu;
-                } else {
-                    a_voff[hf][j] = (unsigned)((uint64_t)m * (uint64_t)(g.lda * ES) + src_chunk * 16);
+            for (int j = 0; j < APW; ++j) {
+                const int row = a_piece_row(hf, j) + (lane >> 3);
+                const int m = o.m0 + row;
+                const int src_chunk = (lane & 7) ^ ((row >> 1) & 7);
+                o.a_voff[hf][j] = OOB;
+                o.a_mask[hf][j] = ~0u;
+                if (m < M) {
+                    if (AMODE == GEMM_A_CONV3) {
+                        const PixDecode p = decode_pixel_fast(m, g.H, g.W, g.inv_w2, g.inv_h2);
+                        o.a_voff[hf][j] = (unsigned)((uint64_t)((p.n * g.H + p.y) * g.W + p.x) * (uint64_t)(g.Cin * ES) + src_chunk * 16);  // < NREC: launch check
+                        // bit t = kh * 3 + kw SET = tap t falls outside the image (stored inverted: see stage_a): a border row / column
+                        // knocks out one row / column of taps
+                        o.a_mask[hf][j] = (p.y == 0 ? 0x007u : 0u) | (p.y == g.H - 1 ? 0x1C0u : 0u) | (p.x == 0 ? 0x049u : 0u) |
+                                          (p.x == g.W - 1 ? 0x124u : 0u) | ~0x1FFu;
+                    } else {
+                        o.a_voff[hf][j] = (unsigned)((uint64_t)m * (uint64_t)(g.lda * ES) + src_chunk * 16);
+                    }
                 }
             }
-        }
 #pragma unroll
-        for (int j = 0; j < BPW; ++j) {
-            const int row = b_piece_row(hf, j) + (lane >> 3);
-            const int n = n0 + row;
-            const int src_chunk = (lane & 7) ^ ((row >> 1) & 7);
-            b_voff[hf][j] = n < N ? (unsigned)((uint64_t)n * (uint64_t)(g.ldb * ES) + src_chunk * 16) : OOB;
+            for (int j = 0; j < BPW; ++j) {
+                const int row = b_piece_row(hf, j) + (lane >> 3);
+                const int n = o.n0 + row;
+                const int src_chunk = (lane & 7) ^ ((row >> 1) & 7);
+                o.b_voff[hf][j] = n < N ? (unsigned)((uint64_t)n * (uint64_t)(g.ldb * ES) + src_chunk * 16) : OOB;
+            }
         }
-    }
+    };
 
     auto kstep_of = [&](int kt) {  // conv: channel slice OUTER, tap INNER (nine consecutive K-tiles re-read one patch: L2 hits)
         KStep k;
@@ -202,14 +216,14 @@ __device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *sm
 #pragma unroll
             for (int j = 0; j < APW; ++j) {
                 // bit `tap` of the INVERTED mask, sign-extended (v_bfe_i32): 0 for a tap inside the image, all ones (= OOB) outside
-                const unsigned vo = a_voff[hf][j] | (unsigned)__builtin_amdgcn_sbfe((int)a_mask[hf][j], k.tap, 1);
+                const unsigned vo = ta.a_voff[hf][j] | (unsigned)__builtin_amdgcn_sbfe((int)ta.a_mask[hf][j], k.tap, 1);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(smem + buf * BUF + a_piece_row(hf, j) * 128), 16, (int)vo, soff, 0, 0);
             }
         } else {
 #pragma unroll
             for (int j = 0; j < APW; ++j) {
-                const bool ok = live && a_voff[hf][j] != OOB;
-                const unsigned char *src = ok ? Aflat + ((int64_t)a_voff[hf][j] + (int64_t)k.koff * ES) : Zp;
+                const bool ok = live && ta.a_voff[hf][j] != OOB;
+                const unsigned char *src = ok ? Aflat + ((int64_t)ta.a_voff[hf][j] + (int64_t)k.koff * ES) : Zp;
                 __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(smem + buf * BUF + a_piece_row(hf, j) * 128), 16, 0, 0);
             }
         }
@@ -221,12 +235,12 @@ __device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *sm
 #pragma unroll
             for (int j = 0; j < BPW; ++j)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(smem + buf * BUF + A_BYTES + b_piece_row(hf, j) * 128), 16,
-                                                         (int)b_voff[hf][j], soff, 0, 0);
+                                                         (int)ta.b_voff[hf][j], soff, 0, 0);
         } else {
 #pragma unroll
             for (int j = 0; j < BPW; ++j) {
-                const bool ok = live && b_voff[hf][j] != OOB;
-                const unsigned char *src = ok ? Bbase + ((int64_t)b_voff[hf][j] + (int64_t)k.kb * ES) : Zp;
+                const bool ok = live && ta.b_voff[hf][j] != OOB;
+                const unsigned char *src = ok ? Bbase + ((int64_t)ta.b_voff[hf][j] + (int64_t)k.kb * ES) : Zp;
                 __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(smem + buf * BUF + A_BYTES + b_piece_row(hf, j) * 128), 16, 0, 0);
             }
         }
@@ -243,6 +257,20 @@ __device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *sm
         fa[s] = base + (wr * WTM) * 128 + fo;
         fb[s] = base + A_BYTES + (wc * WTN) * 128 + fo;
     }
+
+    auto issue_first = [&]() {  // all of the tile's first K-tile -> ring buffer 0
+        const KStep k0 = kstep_of(kbeg);
+        stage_a(0, 0, k0, true);
+        stage_b(0, 0, k0, true);
+        stage_b(0, 1, k0, true);
+        stage_a(0, 1, k0, true);
+    };
+    if (!pre) {
+        setup(tile, ta);
+        issue_first();
+    }
+    stamp(1);  // prologue DMA issued
+    const int m0 = ta.m0, n0 = ta.n0;  // copies: the epilogue may re-point ta at the next tile
 
     // bf16 tiles that leave through the LDS-staged epilogue (every convolution, bf16 GEMM outputs): the bias is the accumulators'
     // INITIAL value (a pooled window's four pixels share it, so max commutes) -- its loads hide under the prologue's DMA wait and the
@@ -330,14 +358,8 @@ __device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *sm
         __builtin_amdgcn_s_barrier();                                                                                      \
     } while (0)
 
-    // ---- prologue: all of tile 0 ----
+    // ---- prologue: the first K-tile (issued above, or by the previous tile's epilogue) ----
     {
-        const KStep k0 = kstep_of(kbeg);
-        stage_a(0, 0, k0, true);
-        stage_b(0, 0, k0, true);
-        stage_b(0, 1, k0, true);
-        stage_a(0, 1, k0, true);
-        stamp(1);  // prologue DMA issued
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         stamp(2);  // ... landed (and the previous tile's stores retired: one in-order counter)
@@ -456,7 +478,7 @@ __device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *sm
                 *reinterpret_cast<f32x4v *>(e.dc + o) = dco;
             }
         }
-        return;
+        return false;
     }
     // ---------------------------------------------------------------- epilogue A: bf16 tile staged through LDS
     if constexpr (F8) {
@@ -551,11 +573,15 @@ __device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *sm
             __builtin_nontemporal_store(*reinterpret_cast<const u32x4 *>(smem + lrow * CSTR + ((ch ^ swz(lrow)) << 4)),
                                         reinterpret_cast<u32x4 *>(C8 + off));
         }
-        return;
+        return false;
     }
     if (staged) {
         constexpr int CSTR = BN * 2;  // bytes per staged row; 16-byte chunk c of row r lives at chunk c ^ (r & 15)
         const int relu_lo = g.relu ? 0 : (int)0x80000000;  // relu_bits: branch-free ReLU (or identity)
+        // The pooled tile (BM / 4 rows) is staged in ring buffer 1's region: buffer 0 is then free for the next tile's first K-tile
+        // while this tile's rows are still being stored.  The full tile needs both buffers (it IS the ring's size).
+        unsigned char *const cst = smem + (SWAP ? 0 : BUF);
+        static_assert(SWAP || (BM / 4) * BN * 2 <= BUF, "pooled tile fits one ring buffer");
         typedef short s16x2 __attribute__((ext_vector_type(2)));
         const s16x2 relu_lo2 = g.relu ? s16x2{0, 0} : s16x2{(short)0x8000, (short)0x8000};  // ReLU on the PACKED bf16 pair: one integer max
         if (!SWAP) {  // fused 2x2 max-pool: registers 0..3 = the four pixels of one window (bias already inside), lane&15 = channel
@@ -572,7 +598,7 @@ __device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *sm
                             const float v = relu_bits(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), relu_lo);
                             const int prow = (wr * WTM + mh * QM + i * 16) / 4 + lq;
                             const int pos = ((lcol >> 3) ^ (prow & 15)) * 16 + (lcol & 7) * 2;
-                            *reinterpret_cast<bf16_t *>(smem + prow * CSTR + pos) = (bf16_t)v;
+                            *reinterpret_cast<bf16_t *>(cst + prow * CSTR + pos) = (bf16_t)v;
                         }
         } else {  // lane&15 = row (pixel), registers 0..3 = four consecutive channels (bias already inside)
 #pragma unroll
@@ -592,7 +618,7 @@ __device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *sm
                                         r1 = __builtin_elementwise_max(__builtin_bit_cast(s16x2, o1), relu_lo2);
                             const int lrow = wr * WTM + mh * QM + i * 16 + l15;
                             const int pos = ((lcol >> 3) ^ (lrow & 15)) * 16 + (lcol & 7) * 2;
-                            *reinterpret_cast<s16x4 *>(smem + lrow * CSTR + pos) = s16x4{r0[0], r0[1], r1[0], r1[1]};
+                            *reinterpret_cast<s16x4 *>(cst + lrow * CSTR + pos) = s16x4{r0[0], r0[1], r1[0], r1[1]};
                         }
                 }
         }
@@ -603,47 +629,59 @@ __device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *sm
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         constexpr int ITER = rows_out * CPR / 512;  // 16-byte chunks per thread
         static_assert(ITER * 512 == rows_out * CPR, "whole passes of the workgroup");
-        // HB chunks of the thread out of LDS, then their stores (read-wait-store per chunk was ITER dependent LDS round trips in
-        // front of the store issue; all ITER = 16 at once made hipcc spill)
-        constexpr int HB = ITER > 4 ? 4 : ITER;
-        static_assert(ITER % HB == 0, "whole batches");
+        // The thread's chunks leave LDS in batches of four, each batch's stores after its reads (read-wait-store per chunk was ITER
+        // dependent LDS round trips in front of the store issue).  The POOLED tile sits outside ring buffer 0, so with a next tile to
+        // prepare its addresses are made and its first K-tile's DMA issued before this tile's stores: per tile, cycles issue + wait +
+        // stores (`tools/tile_stamps.py` under TILE_STAMPS_CAP=224) conv2_2 7528 -> 6536, conv3_3 6540 -> 5368.  For the FULL tile
+        // (which is the ring's size) the same was tried -- all 16 chunks into registers, a barrier, set-up + DMA, then the stores --
+        // and LOST 320-800 cycles per tile: the next tile's wait is the retirement of these stores (one in-order vmcnt; edge tiles
+        // skip stores, so a counted wait cannot exempt them), not the DMA's latency.
+        const bool early = !SWAP && next_tile >= 0;  // workgroup-uniform
         int tid_e = tid;  // opaque copy: otherwise hipcc hoists every iteration's index arithmetic out of the persistent TILE loop and
         asm volatile("" : "+v"(tid_e));  // keeps ~26 registers alive across the K loop (spilled at kernel start, reloaded here per tile)
+        auto store_chunk = [&](int k, const u32x4 &v) {
+            const int idx = tid_e + 512 * k;
+            const int lrow = idx / CPR, ch = idx - lrow * CPR;
+            const int col = n0 + ch * 8;
+            if (col >= N) return;
+            int64_t off;
+            if (!SWAP) {
+                const int prow = (m0 >> 2) + lrow;
+                if (prow >= (M >> 2)) return;
+                off = (int64_t)prow * g.ldc + col;
+            } else {
+                const int row = m0 + lrow;
+                if (row >= M) return;
+                if (g.out_mode == GEMM_OUT_CONV) {
+                    const PixDecode p = decode_pixel_fast(row, g.H, g.W, g.inv_w2, g.inv_h2);
+                    off = (((int64_t)p.n * g.H + p.y) * g.W + p.x) * g.ldc + col;
+                } else {
+                    off = (int64_t)row * g.ldc + col;
+                }
+            }
+            // non-temporal: the tile is not re-read by this kernel, keep the im2col panels and weights in L2 (+2 % on the VGG stack)
+            __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(Cb + off));
+        };
+        auto read_chunk = [&](int k) {
+            const int idx = tid_e + 512 * k, lrow = idx / CPR, ch = idx - lrow * CPR;
+            return *reinterpret_cast<const u32x4 *>(cst + lrow * CSTR + ((ch ^ (lrow & 15)) << 4));
+        };
+        if (early) {
+            setup(next_tile, ta);
+            issue_first();
+        }
+        constexpr int HB = ITER > 4 ? 4 : ITER;
+        static_assert(ITER % HB == 0, "whole batches");
         for (int kb = 0; kb < ITER; kb += HB) {
             u32x4 chunk[HB];
 #pragma unroll
-            for (int k = 0; k < HB; ++k) {
-                const int idx = tid_e + 512 * (kb + k), lrow = idx / CPR, ch = idx - lrow * CPR;
-                chunk[k] = *reinterpret_cast<const u32x4 *>(smem + lrow * CSTR + ((ch ^ (lrow & 15)) << 4));
-            }
+            for (int k = 0; k < HB; ++k) chunk[k] = read_chunk(kb + k);
 #pragma unroll
-            for (int k = 0; k < HB; ++k) {
-                const int idx = tid_e + 512 * (kb + k);
-                const int lrow = idx / CPR, ch = idx - lrow * CPR;
-                const int col = n0 + ch * 8;
-                if (col >= N) continue;
-                int64_t off;
-                if (!SWAP) {
-                    const int prow = (m0 >> 2) + lrow;
-                    if (prow >= (M >> 2)) continue;
-                    off = (int64_t)prow * g.ldc + col;
-                } else {
-                    const int row = m0 + lrow;
-                    if (row >= M) continue;
-                    if (g.out_mode == GEMM_OUT_CONV) {
-                        const PixDecode p = decode_pixel_fast(row, g.H, g.W, g.inv_w2, g.inv_h2);
-                        off = (((int64_t)p.n * g.H + p.y) * g.W + p.x) * g.ldc + col;
-                    } else {
-                        off = (int64_t)row * g.ldc + col;
-                    }
-                }
-                // non-temporal: the tile is not re-read by this kernel, keep the im2col panels and weights in L2 (+2 % on the VGG stack)
-                __builtin_nontemporal_store(chunk[k], reinterpret_cast<u32x4 *>(Cb + off));
-            }
+            for (int k = 0; k < HB; ++k) store_chunk(kb + k, chunk[k]);
         }
         stamp(5);  // stores issued
         stamp(6);  // ... and the 100 MHz wall counter again: (stamp 5 - stamp 0) / (stamp 6 - stamp 7) = shader cycles per 10 ns
-        return;
+        return early;
     }
 
     // ---------------------------------------------------------------- split-K: this slice's partial tile -> its f32 slab
@@ -662,7 +700,7 @@ __device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *sm
                             if (row < M && col0 < N) *reinterpret_cast<f32x4v *>(slab + (size_t)row * N + col0) = acc[mh][i][nh][n];
                         }
         }
-        return;
+        return false;
     }
 
     // ---------------------------------------------------------------- epilogue B: direct stores (f32 / accumulate / odd N)
@@ -727,6 +765,7 @@ __device__ __forceinline__ void gemm8p_tile(const GemmArgs &g, unsigned char *sm
                         }
                     }
                 }
+    return false;
 }
 
 // One workgroup per output tile, or -- g.wg_cap > 0 -- a capped, persistent grid that walks the tiles: the data-parallel
@@ -737,10 +776,14 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
     const int ntiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+    TileAddr<BM / 128, BN / 128> ta;
     if (g.tile_ctr == nullptr || gridDim.y > 1) {
+        bool pre = false;
         for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-            gemm8p_tile<WM, WN, MT, NT, AMODE, SWAP, F8, EPI>(g, smem, tile, ntiles);
-            if (tile + (int)gridDim.x < ntiles) __syncthreads();  // the staged output tile / ring are reused by the next tile
+            const int next = (!(g.dbg & 8) && tile + (int)gridDim.x < ntiles) ? tile + (int)gridDim.x : -1;  // LRCN_DBG=8: no overlap
+            pre = gemm8p_tile<WM, WN, MT, NT, AMODE, SWAP, F8, EPI>(g, smem, tile, ntiles, next, ta, pre);
+            // not issued early: the staged output tile / ring are reused by the next tile's first DMA
+            if (!pre && tile + (int)gridDim.x < ntiles) __syncthreads();
         }
         return;
     }
@@ -783,7 +826,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs g) {
     while (tile >= 0) {
         par ^= 1;
         if (threadIdx.x == 0) publish(slot + par);  // the NEXT tile: its latency hides under this tile's prologue
-        gemm8p_tile<WM, WN, MT, NT, AMODE, SWAP, F8, EPI>(g, smem, tile, ntiles);
+        (void)gemm8p_tile<WM, WN, MT, NT, AMODE, SWAP, F8, EPI>(g, smem, tile, ntiles, -1, ta, false);  // next tile unknown until fetched: no early issue
         __syncthreads();  // the staged output tile / ring are free again; lane 0's exchange precedes every wave's fetch
         tile = fetch(slot + par);
     }

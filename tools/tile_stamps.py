@@ -24,6 +24,8 @@ def main():
     names = sys.argv[2:] or list(LAYERS)
     ctx = L.Context(8, 8, 8, 17, max_B=2, max_T=1, lstm_dtype=lrcn_amd.LRCN_BF16, vgg_dtype=lrcn_amd.LRCN_BF16, max_images=1)
     lib = lrcn_amd._lib.lib()
+    if os.environ.get("TILE_STAMPS_CAP"):  # persistent walk of a capped grid, as in the two-stream training step (224 there)
+        L.vgg_set_wg_cap(ctx, int(os.environ["TILE_STAMPS_CAP"]))
     print("%-8s %-6s %6s | %8s %8s %8s %8s %8s | %8s %8s  %5s" % ("layer", "route", "tiles", "issue", "wait", "mainloop", "stage", "stores",
                                                                   "tile", "K-tile", "GHz"))
     for name in names:
