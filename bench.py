@@ -33,7 +33,7 @@ def pmc_traffic(dtype, per_gpu_batch):
     """HBM-side bytes per launch of the dominant kernel family, from the committed rocprofv3 PMC passes of this same
     command (tools/pmc_traffic.py -> profiles/*.json; FETCH_SIZE/WRITE_SIZE cannot be read from inside the process).
     Only valid for the configuration it was measured on; otherwise null."""
-    path = os.path.join(ROOT, "profiles", "r02c_pmc_traffic_bench_bf16_b256.json")
+    path = os.path.join(ROOT, "profiles", "r02d_pmc_traffic_bench_bf16_b256.json")
     if dtype != "bf16" or per_gpu_batch != 256 or not os.path.exists(path):
         return None
     try:
