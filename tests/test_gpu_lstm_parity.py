@@ -361,14 +361,15 @@ def test_recurrence_kernel_routes_by_batch_size_vs_oracle_bf16(B):
     ctx.close()
 
 
-@pytest.mark.parametrize("B,H", [(40, 320), (32, 1000), (100, 512)])
+@pytest.mark.parametrize("B,H", [(40, 320), (32, 1000), (100, 512), (21, 100)])
 def test_fused_recurrence_small_batch_forms_equal_ring_forms(B, H, monkeypatch):
     # lstm_fused.hip has two forms of the one-launch-per-timestep kernels: 16 hidden units per workgroup with one LDS-DMA ring per wave
     # (any H, any B <= 128), and -- up to LRCN_LSTM_REC2 rows (default 64) -- 8 units per workgroup: forward (H <= 1024) with the 32-row
     # h block staged once and shared by the four gate waves, every byte requested up front; backward as 16-row x 8-unit workgroups on
     # the ring.  Same arithmetic in the same K order per wave: losses within 1e-4, gradients within 1e-2 in norm of each other, and
     # both within bf16 tolerance of the oracle.  B = 40 / 100: row-block tails (32-row blocks forward, 16-row blocks backward);
-    # H = 1000: the benchmark's K = 1024 / 4032, last workgroup with 8 valid units; H = 320 / 512: K-slices of 5 / 8 K-tiles.
+    # H = 1000: the benchmark's K = 1024 / 4032, last workgroup with 8 valid units; H = 320 / 512: K-slices of 5 / 8 K-tiles;
+    # H = 100, B = 21: last workgroup with 4 valid units, K padded to 128 / 448, one partial row block.
     rng = np.random.default_rng(B + H)
     E, V, T = 64, 300, 4
     m = orc.init_weights(E, H, H, V, seed=5)
