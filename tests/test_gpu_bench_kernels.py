@@ -79,7 +79,7 @@ def biased_vgg():
 BENCH_ROUTES = "conv64-fused11,conv64,8p:2," + ",".join(["8p:0"] * 9)
 
 
-@pytest.mark.parametrize("N,cap", [(256, 224), (256, 0), (32, 224)])
+@pytest.mark.parametrize("N,cap", [(256, 224), (256, 0), (32, 224), (34, 64)])  # 34 images, cap 64: persistent walks that end on a partial row tile
 def test_full_vgg_bf16_bench_batch_nonzero_biases_vs_oracle(biased_vgg, N, cap):
     # the bench's VGG forward: N = 256 crops, capped persistent grids (dp.py sets 224), conv1_1 bias as the fused kernel's accumulator
     # input, fc6 / fc7 biases through the split-K reduce; rows {0, N-1} against the oracle's fp32 stack
