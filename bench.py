@@ -199,10 +199,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    run(a.warmup)
     import gc  # a full pass of Python's cyclic GC scans every object torch created (tens of ms): none inside the timed region
-    gc.collect()
-    gc.freeze()
+    if os.environ.get("LRCN_BENCH_GC_LATE"):
+        run(a.warmup)
+        gc.collect()
+        gc.freeze()
+    else:
+        gc.collect()
+        gc.freeze()
+        run(a.warmup)
     barrier()
     _lib = lrcn_amd._lib
     _lib.check(ctx._h, _lib.lib().lrcn_profile(ctx._h, 1))
@@ -213,7 +218,8 @@ def main():
     run(a.steps, events=True)
     barrier()
     dt_s = time.perf_counter() - t0
-    step_ms = sorted(step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(len(step_ev) - 1))
+    step_ms_seq = [step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(len(step_ev) - 1)]
+    step_ms = sorted(step_ms_seq)
     median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     import ctypes as C
     conv_ms, conv_n = C.c_double(), C.c_int64()
@@ -238,7 +244,8 @@ def main():
         out = {
             "metric": "training images/sec (VGG16+LSTM, COCO, batch 256) at 1/2/4/8 MI355X",
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": ms_step, "ms_per_step_median": median_ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "ms_per_step": ms_step, "ms_per_step_median": median_ms,
+            "ms_per_step_first8": [round(x, 3) for x in step_ms_seq[:8]], "ms_per_step_last": round(step_ms_seq[-1], 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": "%s: VGG-16 -> fc7 fwd + %s LSTM "
                                    "E=H=%d V=%d T=%d fwd/bwd + Adam, global batch %d, dp%d, dropout %.1f; synthetic uint8 "

@@ -10,7 +10,12 @@ Deliberate, documented differences from the reference:
     reproducible; here words get ids in order of first occurrence (specials first: `~~`=eos=1, ` `` `=bos=2, `##`=unk=3);
   * the Flickr val/test split follows Julia's `srand(5); shuffle` (`tokenizer.jl:59-63`); here it is an explicit list of
     line numbers, a NumPy permutation with seed 5, or the image ids of a committed test set (`eval/ids_flickr_bm5`);
-  * `delete_unbatchable_captions!` cannot spin (`lrcn.jl:311-318`): a length group with no successor ends the scan.
+  * `delete_unbatchable_captions!` cannot spin (`lrcn.jl:311-318`): the one input on which the reference's scan never ends
+    (unsorted lengths: a batch window that straddles the longest length) raises ValueError here;
+  * `delete_unbatchable_captions(..., reference_tail=False)` is this repo's saner variant (keep, per length, the largest
+    multiple of the batch size).  The DEFAULT reproduces the reference, whose scan always ends by deleting everything from
+    its cursor on once fewer than a batch is left behind it (`lrcn.jl:320-323`) -- i.e. the last <= batch_size captions go even
+    when they form a complete equal-length batch ([3]*20 at batch 10 keeps 10, not 20).
 """
 import json
 import re
@@ -109,9 +114,60 @@ def index_to_word(vocab):
     return out
 
 
-def delete_unbatchable_captions(caps, batch_size):
-    """Keep, per caption length, the largest multiple of `batch_size` captions (lrcn.jl:299-327).  `caps` must be sorted
-    by length.  Returns a new list."""
+def reference_delete_ranges(lengths, batch_size):
+    """The 0-based indices `delete_unbatchable_captions!` removes (lrcn.jl:299-327), by running ITS loop on `lengths` -- the
+    cursor arithmetic below is the reference's, 1-based, statement for statement (integer work: the bar is identical output):
+      :301 limit = n - B + 1          :304 cursor = 1, current_length = lengths[1]
+      :306 a full window of the current length -> cursor += B
+      :308-318 otherwise the cursor jumps to the first caption of the next length PRESENT (findfirst; lengths that do not occur
+               are skipped, :311-317) and [old cursor, new cursor) is deleted
+      :320-323 as soon as cursor >= limit everything from the cursor to the end is deleted and the scan stops.
+    The loop can only be left through :320-323, so the tail [cursor, n] -- between 1 and B captions -- is ALWAYS deleted.
+    n < B: the reference's loop body never runs and nothing is deleted (minibatch would then index out of bounds, :283);
+    here that is an empty result (every caption is unbatchable)."""
+    n, B = len(lengths), int(batch_size)
+    if B <= 0:
+        raise ValueError("batch_size must be positive")
+    if n == 0:
+        return []
+    if n < B:
+        return list(range(n))
+    limit = n - B + 1
+    max_length = max(lengths)
+    first = {}
+    for i, v in enumerate(lengths):          # findfirst(lengths, v), 1-based
+        first.setdefault(v, i + 1)
+    current_length, cur = lengths[0], 1
+    ranges = []
+    while cur < limit:
+        if lengths[cur + B - 2] == current_length:          # lengths[cur+B-1], 1-based
+            cur += B
+        else:
+            old, cur = cur, 0
+            while cur == 0:
+                current_length += 1
+                if current_length > max_length:
+                    break
+                cur = first.get(current_length, 0)
+            if cur == 0:
+                # lrcn.jl:311-318 leaves cursor = 0 here and the outer loop never ends (SURVEY A.8); unreachable for sorted lengths
+                raise ValueError("delete_unbatchable_captions: lengths are not sorted (the reference's scan does not terminate on this input)")
+            ranges.extend(range(old, cur))
+        if cur >= limit:
+            ranges.extend(range(cur, n + 1))
+            break
+    return [i - 1 for i in ranges]
+
+
+def delete_unbatchable_captions(caps, batch_size, reference_tail=True):
+    """`delete_unbatchable_captions!` (lrcn.jl:299-327): drop the captions that cannot sit in an equal-length batch.  `caps` must
+    be sorted by length.  Returns a new list.
+    reference_tail=True (default): exactly the reference's result, see reference_delete_ranges -- per length the largest
+    multiple of `batch_size` survives, EXCEPT that the scan's last window is always deleted (the final <= batch_size captions).
+    reference_tail=False: per length the largest multiple of `batch_size`, nothing else dropped."""
+    if reference_tail:
+        gone = set(reference_delete_ranges([c[1] for c in caps], batch_size))
+        return [c for i, c in enumerate(caps) if i not in gone]
     out, i, n = [], 0, len(caps)
     while i < n:
         j = i
@@ -123,14 +179,17 @@ def delete_unbatchable_captions(caps, batch_size):
     return out
 
 
-def minibatch(caps, word_to_index, batch_size):
+def minibatch(caps, word_to_index, batch_size, reference_tail=True):
     """-> (sequence, input_ids, lengths) exactly as lrcn.jl:257-297: `sequence[k]` is the vector of the k-th word of a
     batch (batches concatenated along k), `input_ids[b]` the image ids of batch b, `lengths` the per-caption lengths of
     the kept captions.  Splits with <= 30000 captions are forced to batch 10 (lrcn.jl:260-270).  Returns the batch size
-    actually used as a fourth value."""
+    actually used as a fourth value.
+    Sizing (lrcn.jl:276-281): the reference allocates `nbatch = div(sum(lengths), batch_size)` word vectors and one id vector
+    per `1:batch_size:length(lengths)`; after the deletion every length group is a whole number of batches, so
+    sum(lengths) / batch_size = sum over batches of T -- the number of rows appended below (asserted)."""
     if len(caps) <= 30000:
         batch_size = 10
-    caps = delete_unbatchable_captions(caps, batch_size)
+    caps = delete_unbatchable_captions(caps, batch_size, reference_tail=reference_tail)
     lengths = [c[1] for c in caps]
     sequence, input_ids = [], []
     for i in range(0, len(caps), batch_size):
@@ -139,6 +198,7 @@ def minibatch(caps, word_to_index, batch_size):
         input_ids.append([g[0][0] for g in group])
         for k in range(T):
             sequence.append([word_to_index.get(g[0][1][k], UNK) for g in group])
+    assert len(sequence) == sum(lengths) // batch_size and len(input_ids) == len(range(0, len(lengths), batch_size))
     return sequence, input_ids, lengths, batch_size
 
 

@@ -85,6 +85,7 @@ def test_minibatcher_contract():
     kept = cap.delete_unbatchable_captions(caps, 25)
     for n in set(c[1] for c in kept):
         assert sum(1 for c in kept if c[1] == n) % 25 == 0
+    kept = cap.delete_unbatchable_captions(caps, 10)  # minibatch() below forces batch 10 on a split this small
     seq, ids, lengths, bs = cap.minibatch(caps, vocab, 25)
     assert bs == 10  # <= 30000 captions: forced to 10 (lrcn.jl:260-270)
     assert len(lengths) % 10 == 0 and len(ids) == len(lengths) // 10 and len(seq) == sum(lengths[::10])
@@ -101,6 +102,107 @@ def test_minibatcher_contract():
     s2, i2, l2, b2 = cap.minibatch(long_caps, vocab, 10)
     assert all(t == cap.UNK for row in s2 for t in row) and list(cap.batches(s2, i2, l2, b2)) == []
     assert cap.caption_text([1, 5, 6, 0, 9], ["~~", "``", "##", "x", "y", "a", "b"]) == "a b ."
+
+
+def _caps_of(lengths):
+    return [((i, ["w"] * n), n) for i, n in enumerate(lengths)]
+
+
+def _julia_trace(lengths, B):
+    """delete_unbatchable_captions! (lrcn.jl:299-327) written out with Julia's own 1-based variables, as a second, independent
+    transcription for the test to compare against (kept deliberately literal; `findfirst` returns 0 when absent in Julia 0.5/0.6)."""
+    L = [None] + list(lengths)          # L[1..n]
+    n = len(lengths)
+    limit = n - B + 1
+    max_length = max(lengths)
+    current_length, current_index = L[1], 1
+    ranges = []
+    guard = 0
+    while current_index < limit:
+        guard += 1
+        assert guard < 10 * n + 10, "the reference would spin here"
+        if L[current_index + B - 1] == current_length:
+            current_index += B
+        else:
+            old_index = current_index
+            current_index = 0
+            while current_index == 0:
+                current_length += 1
+                if current_length > max_length:
+                    break
+                current_index = next((i for i in range(1, n + 1) if L[i] == current_length), 0)
+            ranges += list(range(old_index, current_index))       # old_index:current_index-1
+        if current_index >= limit:
+            ranges += list(range(current_index, n + 1))           # current_index:length(lengths)
+            break
+    return [i for i in range(1, n + 1) if i not in set(ranges)]   # surviving 1-based positions
+
+
+def test_delete_unbatchable_is_the_references_function():
+    """f1: integer work, so the bar is the reference's exact result.  Expectations traced by hand through lrcn.jl:299-327
+    (cursor / limit / ranges written in the comments), then cross-checked against a literal transcription on random inputs."""
+    B = 10
+    cases = [
+        # limit = 11; cursor 1 -> 11 >= limit: delete 11:20 -- the final FULL batch goes (tail rule :320-323)
+        ([3] * 20, 10, list(range(0, 10))),
+        # limit = 31; 1 -> 11 -> 21 -> 31 >= limit at the boundary of the 3-group: delete 31:40, the whole 4-group
+        ([3] * 30 + [4] * 10, 30, list(range(0, 30))),
+        # limit = 33; 1 -> 11 -> 21, window 21..30 straddles: delete 21:25, cursor 26; 26 -> 36 >= 33: delete 36:42
+        ([3] * 25 + [4] * 17, 30, list(range(0, 20)) + list(range(25, 35))),
+        # limit = 52; 2-group (7) has no full window: delete 1:7, cursor 8 (first 3); 8 -> 18 -> 28, window 28..37 straddles:
+        # delete 28:30, current_length 4 is ABSENT (findfirst = 0, loop again), 5 found at 31; 31 -> 41 -> 51 -> 61 >= 52: delete 61:61
+        ([2] * 7 + [3] * 23 + [5] * 31, 50, list(range(7, 27)) + list(range(30, 60))),
+        # a short FIRST group and a skipped length: delete 1:3, cursor 4 (length 6 after skipping 5); 4 -> 14 -> 24 >= limit 16... traced:
+        # n = 25, limit = 16; cursor 1: L[10] = 6 != 4 -> delete 1:3, length 5 absent, 6 at 4; 4 -> 14; L[23] = 6 -> 24 >= 16: delete 24:25
+        ([4] * 3 + [6] * 22, 20, list(range(3, 23))),
+        # the group after a boundary is shorter than a batch and the last group is exactly one batch: it is deleted by the tail rule
+        # n = 33, limit = 24; 1 -> 11; L[20] = 5 != 3 -> 4 found at 11 (empty range); L[20] = 5 != 4 -> delete 11:13, cursor 14;
+        # 14 -> 24 >= 24: delete 24:33
+        ([3] * 10 + [4] * 3 + [5] * 20, 20, list(range(0, 10)) + list(range(13, 23))),
+        # exactly one batch: limit = 1, the loop body never runs, nothing is deleted
+        ([7] * 10, 10, list(range(0, 10))),
+    ]
+    for lengths, n_keep, keep_idx in cases:
+        got = cap.delete_unbatchable_captions(_caps_of(lengths), B)
+        assert [c[0][0] for c in got] == keep_idx, (lengths, [c[0][0] for c in got])
+        assert len(got) == n_keep
+        assert [i - 1 for i in _julia_trace(lengths, B)] == keep_idx
+    # the repo's non-reference variant keeps the final full batch
+    assert len(cap.delete_unbatchable_captions(_caps_of([3] * 20), B, reference_tail=False)) == 20
+    assert len(cap.delete_unbatchable_captions(_caps_of([3] * 30 + [4] * 10), B, reference_tail=False)) == 40
+    # fewer captions than a batch: nothing can be batched (the reference deletes nothing and then indexes out of bounds, :283)
+    assert cap.delete_unbatchable_captions(_caps_of([3] * 4), B) == []
+    assert cap.delete_unbatchable_captions([], B) == []
+    # random sorted inputs, several batch sizes: identical survivors to the literal transcription, all groups whole batches
+    rng = np.random.default_rng(11)
+    for trial in range(200):
+        bs = int(rng.choice([2, 3, 5, 10, 25]))
+        n = int(rng.integers(bs, 400))
+        lengths = sorted(int(x) for x in rng.choice([1, 2, 3, 4, 6, 7, 9, 15, 28, 31], size=n))
+        got = [c[0][0] + 1 for c in cap.delete_unbatchable_captions(_caps_of(lengths), bs)]
+        assert got == _julia_trace(lengths, bs), (lengths, bs)
+        if n > bs:  # (n == bs: the reference deletes nothing whatever the lengths are)
+            kept_len = [lengths[i - 1] for i in got]
+            assert all(kept_len.count(v) % bs == 0 for v in set(kept_len))
+            # and it never keeps MORE than the per-length multiple; it differs from it only in the tail
+            sane = [c[0][0] + 1 for c in cap.delete_unbatchable_captions(_caps_of(lengths), bs, reference_tail=False)]
+            assert set(got) <= set(sane) and len(sane) - len(got) in (0, bs)
+    with pytest.raises(ValueError):   # unsorted: the reference's scan would never end (SURVEY A.8)
+        cap.delete_unbatchable_captions(_caps_of([5] * 12 + [3] * 12), B)
+
+
+def test_minibatch_sizing_matches_reference():
+    """lrcn.jl:276-281: nbatch = div(sum(lengths), batch_size) word vectors, one id vector per batch start."""
+    caps = _caps_of([2] * 7 + [3] * 23 + [5] * 31)
+    vocab = {"~~": 1, "``": 2, "##": 3, "w": 4}
+    seq, ids, lengths, bs = cap.minibatch(caps, vocab, 25)
+    assert bs == 10 and len(lengths) == 50
+    assert len(seq) == sum(lengths) // bs == 2 * 3 + 3 * 5 and len(ids) == len(range(0, len(lengths), bs)) == 5
+    assert [lengths[i] for i in range(0, 50, 10)] == [3, 3, 5, 5, 5]
+    assert ids[0] == list(range(7, 17)) and ids[2] == list(range(30, 40))
+    assert all(row == [4] * 10 for row in seq)
+    seq2, ids2, lengths2, _ = cap.minibatch(caps, vocab, 25, reference_tail=False)
+    assert len(lengths2) == 50  # here the tail the reference deletes is the single leftover caption either way
 
 
 def test_flickr_split_by_ids_and_seed():
