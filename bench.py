@@ -29,17 +29,27 @@ PEAK_BF16_TFLOPS = 2516.0                # MI355X dense bf16 MFMA (MI355X_MICROA
 PEAK_F32_TFLOPS = 157.3
 
 
+PMC_TRAFFIC_FILE = "pmc_traffic_bench_bf16_b256.json"   # profiles/<latest tag>_pmc_traffic_bench_bf16_b256.json
+
+
 def pmc_traffic(dtype, per_gpu_batch):
     """HBM-side bytes per launch of the dominant kernel family, from the committed rocprofv3 PMC passes of this same
-    command (tools/pmc_traffic.py -> profiles/*.json; FETCH_SIZE/WRITE_SIZE cannot be read from inside the process).
-    Only valid for the configuration it was measured on; otherwise null."""
-    path = os.path.join(ROOT, "profiles", "r02d_pmc_traffic_bench_bf16_b256.json")
-    if dtype != "bf16" or per_gpu_batch != 256 or not os.path.exists(path):
-        return None
-    try:
-        return float(json.load(open(path))["traffic_bytes_per_launch"])
-    except Exception:
-        return None
+    command (tools/collect_profiles.sh -> tools/pmc_traffic.py -> profiles/*.json; FETCH_SIZE/WRITE_SIZE cannot be read from
+    inside the process, and a --pmc pass is its own run).  Only quoted for the configuration AND the kernel sources it was
+    measured on: the file records the digest of csrc/ at measurement time; if the sources have changed since, traffic is null
+    and the note says so.  -> (bytes per launch | None, note)"""
+    pdir = os.path.join(ROOT, "profiles")
+    files = sorted(f for f in os.listdir(pdir) if f.endswith(PMC_TRAFFIC_FILE)) if os.path.isdir(pdir) else []
+    if dtype != "bf16" or per_gpu_batch != 256:
+        return None, "no PMC pass for this configuration"
+    for f in reversed(files):
+        try:
+            d = json.load(open(os.path.join(pdir, f)))
+        except Exception:
+            continue
+        if d.get("csrc_digest") == csrc_digest():
+            return float(d["traffic_bytes_per_launch"]), "profiles/%s (csrc digest %s matches)" % (f, d["csrc_digest"])
+    return None, "stale: no profiles/*_%s was taken on the current kernel sources (digest %s)" % (PMC_TRAFFIC_FILE, csrc_digest())
 
 
 def cpu_baseline(vgg_w, E, H, V, T, rng, n_layers=2):
@@ -120,20 +130,213 @@ def parity_spot_check(ctx, L, sample, batch_imgs):
             "grad_cos_min": min(cos), "checker": "oracle (liblrcn_cpu_f32.so) on the cpu_baseline sample"}
 
 
-def main():
+PRESETS = {  # BASELINE.json configs[k] -> flags (SURVEY.md 8d "Config -> shapes"); c4 is the headline and the default
+    "c4": {},
+    "c2": {"layers": 1, "dtype": "f32", "global_batch": 32, "hidden": 512, "vocab": 2540},
+    "c3": {"global_batch": 128, "vocab": 7730, "T": 12},
+}
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)    # >= 50 timed steps after >= 10 warm-up
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--global-batch", type=int, default=256)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
-    ap.add_argument("--hidden", type=int, default=1000)
-    ap.add_argument("--vocab", type=int, default=10640)
-    ap.add_argument("--T", type=int, default=11)
+    ap.add_argument("--config", default="c4", choices=["c2", "c3", "c4", "c5"],
+                    help="BASELINE.json configs[1..4]: c4 = the headline (default); c2 = fp32 VGG + LRCN-1f LSTM-512, batch 32; c3 = Flickr30k-shaped "
+                         "bf16, batch 128; c5 = fp8 VGG + beam-5 caption generation (captions/s; runs tools/caption_bench.py's loop)")
+    ap.add_argument("--global-batch", type=int, default=None)
+    ap.add_argument("--dtype", default=None, choices=["bf16", "f32"])
+    ap.add_argument("--hidden", type=int, default=None)
+    ap.add_argument("--vocab", type=int, default=None)
+    ap.add_argument("--T", type=int, default=None)
     ap.add_argument("--pdrop", type=float, default=0.4)
-    ap.add_argument("--layers", type=int, default=2, choices=[1, 2])  # 1 = LRCN-1f, BASELINE configs[1] (with --dtype f32 --global-batch 32 --hidden 512 --vocab 2540)
+    ap.add_argument("--layers", type=int, default=None, choices=[1, 2])  # 1 = LRCN-1f (this repo's definition of configs[1]'s "1-layer LSTM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    a = ap.parse_args()
+    ap.add_argument("--emulate-world", type=int, default=1,
+                    help="ONE process runs rank 0's shard of an N-rank job (global batch / N rows, the GLOBAL normaliser, no collective): the "
+                         "per-rank step that bounds the N-GPU number, measurable on one GPU.  Labelled; NOT the headline metric.")
+    ap.add_argument("--dp-backend", default=os.environ.get("LRCN_DP_BACKEND", "torch"), choices=["torch", "abi", "auto"],
+                    help="N > 1: 'torch' = per-group all-reduces issued through torch.distributed's RCCL process group (default); 'abi' = RCCL "
+                         "inside liblrcn_hip (lrcn_comm_init + lrcn_train_step_dp, one C call per step); 'auto' (self-launched jobs only) = "
+                         "try 'abi' under a watchdog, rerun with 'torch' if it fails")
+    ap.add_argument("--spinup-ms", type=float, default=150.0,
+                    help="set-up, before the W warm-up steps: keep the GPU busy with VGG forwards of the benchmark's own crops for this long.  "
+                         "The chip needs ~100 ms of load after idle before its clocks settle (measured: steps 1..15 after idle run 7.5 -> 7.0 ms); "
+                         "these are NOT training steps (no lossgradient, no update!) and lie outside the timed region.  0 = off")
+    ap.add_argument("--watchdog-s", type=float, default=float(os.environ.get("LRCN_BENCH_WATCHDOG_S", "900")),
+                    help="self-launched jobs: kill the ranks and fail if they have not finished after this many seconds")
+    a = ap.parse_args(argv)
+    if a.config in PRESETS:
+        for k, v in PRESETS[a.config].items():
+            if getattr(a, k) is None:
+                setattr(a, k, v)
+    for k, v in {"global_batch": 256, "dtype": "bf16", "hidden": 1000, "vocab": 10640, "T": 11, "layers": 2}.items():
+        if getattr(a, k) is None:
+            setattr(a, k, v)
+    return a
+
+
+def workload_name(a):
+    H, Bg = a.hidden, a.global_batch
+    if a.layers == 2 and a.dtype == "bf16" and Bg == 256 and H == 1000 and a.vocab == 10640:
+        return "BASELINE.json configs[3] (C4), MS-COCO-shaped"
+    if a.layers == 1 and a.dtype == "f32" and Bg == 32 and H == 512:
+        return "BASELINE.json configs[1] (C2), Flickr8k-shaped"
+    if a.layers == 2 and a.dtype == "bf16" and Bg == 128 and H == 1000 and a.vocab == 7730:
+        return "BASELINE.json configs[2] (C3), Flickr30k-shaped"
+    return "custom"
+
+
+HEADLINE_METRIC = "training images/sec (VGG16+LSTM, COCO, batch 256) at 1/2/4/8 MI355X"
+
+
+def metric_name(a):
+    w = workload_name(a)
+    if a.emulate_world > 1:
+        return "EMULATED rank-0 step of a %d-rank job (%d of %d rows, global normaliser, no collective) -- not the headline" % (
+            a.emulate_world, a.global_batch // a.emulate_world, a.global_batch)
+    if w.startswith("BASELINE.json configs[3]"):
+        return HEADLINE_METRIC
+    return "training images/sec (VGG16+LSTM), %s" % w
+
+
+def find_free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch(a, argv):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: this process NEVER touches the GPU (no torch import, no HIP call --
+    a parent that had initialised the device could not be replaced or forked safely); it starts the N ranks as a CHILD job
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same flags>`),
+    waits for it under a watchdog, relays rank 0's JSON line and exits with the job's code.  --dp-backend auto: first attempt with the
+    C-ABI communicator, second with torch.distributed's if the first fails or hangs (only the parent can do that safely)."""
+    import signal
+    import subprocess
+    backends = ["abi", "torch"] if a.dp_backend == "auto" else [a.dp_backend]
+    child_argv = [x for x in argv]
+    last_rc = 1
+    for attempt, backend in enumerate(backends):
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver
+        env["LRCN_DP_BACKEND"] = backend
+        env["LRCN_BENCH_LAUNCHED"] = "1"
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(find_free_port()), os.path.abspath(__file__)] + child_argv
+        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True, start_new_session=True)
+        try:
+            out, _ = proc.communicate(timeout=a.watchdog_s)
+            rc = proc.returncode
+        except subprocess.TimeoutExpired:
+            # the exact process group started above, nothing else
+            try:
+                os.killpg(proc.pid, signal.SIGTERM)
+                time.sleep(3)
+                os.killpg(proc.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+            out, _ = proc.communicate()
+            rc = 124
+            print("bench.py: the %d-rank job (dp backend %s) did not finish within %.0f s and was stopped" % (a.gpus, backend, a.watchdog_s),
+                  file=sys.stderr)
+        lines = [ln for ln in (out or "").splitlines() if ln.startswith("{") and '"metric"' in ln]
+        if rc == 0 and lines:
+            line = json.loads(lines[-1])
+            line.setdefault("rccl", {})["launcher"] = "self (bench.py spawned torch.distributed.run; attempt %d of %d)" % (attempt + 1, len(backends))
+            print(json.dumps(line), flush=True)
+            return 0
+        last_rc = rc or 1
+        print("bench.py: %d-rank job with dp backend %s failed (rc %s)%s" % (a.gpus, backend, rc, "; retrying with the next backend"
+                                                                           if attempt + 1 < len(backends) else ""), file=sys.stderr)
+    return last_rc
+
+
+def dryrun_main(a, world, rank):
+    """LRCN_BENCH_DRYRUN=1 (tests/test_bench_launcher.py): the SAME launcher, rank set-up, sharding, trainer (dp.DataParallelTrainer), barrier +
+    max-over-ranks timing and JSON assembly over gloo on the CPU, with tests/dp_oracle_ops.py's stand-ins for the device operations and tiny
+    dimensions.  It proves `--gpus N` produces one well-formed line with n_gpus = N before an N-GPU node exists; it measures nothing."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from lrcn_amd import dp
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import dp_oracle_ops as doo
+    if os.environ.get("LRCN_BENCH_DRYRUN_FAIL_ABI") and os.environ.get("LRCN_DP_BACKEND") == "abi":
+        raise SystemExit("dry run: simulated failure of the C-ABI communicator")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    E = H = 16
+    V, T, Bg = 37, 3, 8
+    rows = dp.shard_rows(Bg, world * a.emulate_world, rank)
+    param, optim, ops = doo.make(E, H, V, seed=42)
+    trainer = dp.DataParallelTrainer(None, param, optim, Bg, world, rank, pdrop=0.0, seed=7, ops=ops, backend="torch")
+    rng = np.random.default_rng(7)
+    feats = torch.as_tensor((rng.standard_normal((Bg, 4096)) * 0.01).astype(np.float32)[rows])
+    toks = rng.integers(3, V, size=(T, Bg)).astype(np.int32)[:, rows]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        trainer.step(None, toks, feats=feats)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        trainer.step(None, toks, feats=feats)
+    barrier()
+    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt_s = float(tt.item())
+    loss = trainer.loss_value()
+    if rank == 0:
+        print(json.dumps({"metric": "DRYRUN (CPU stand-ins, gloo) -- " + metric_name(a), "value": Bg * a.steps / dt_s, "unit": "images/sec",
+                          "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt_s / a.steps, "higher_is_better": True,
+                          "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "dryrun",
+                          "config": {"workload": "dry run of the launcher and the N-rank plumbing", "global_batch": Bg,
+                                     "per_gpu_batch": rows.stop - rows.start, "parallelism": "dp%d" % world, "last_loss": loss},
+                          "rccl": {"world": world, "backend": "gloo-dryrun", "launched_by": os.environ.get("LRCN_BENCH_LAUNCHED", "0")}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+def csrc_digest():
+    """sha256 over the kernel sources: a committed PMC measurement is only quoted for the sources it was taken on."""
+    import hashlib
+    d = os.path.join(ROOT, "long-term-recurrent-convolutional-nn_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    a = parse_args(argv)
+    if a.config == "c5":
+        return caption_main(a, argv)
+    world_env = os.environ.get("WORLD_SIZE")
+    if a.gpus > 1 and world_env is None:
+        return launch(a, argv)          # before any torch / HIP import
+    world = int(world_env or "1")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    if a.emulate_world > 1 and world > 1:
+        raise SystemExit("--emulate-world is a one-process measurement")
+    if os.environ.get("LRCN_BENCH_DRYRUN"):
+        return dryrun_main(a, world, rank)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     import numpy as np
     import torch
@@ -142,13 +345,6 @@ def main():
     from lrcn_amd import dp
     from lrcn_amd import lrcn as L
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (a.gpus, a.gpus))
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -157,7 +353,7 @@ def main():
     dt = lrcn_amd.LRCN_BF16 if a.dtype == "bf16" else lrcn_amd.LRCN_F32
     E = H = a.hidden
     V, T, Bg = a.vocab, a.T, a.global_batch
-    rows = dp.shard_rows(Bg, world, rank)
+    rows = dp.shard_rows(Bg, world * a.emulate_world, rank)
     B = rows.stop - rows.start
 
     ctx = L.Context(E, H, H, V, max_B=B, max_T=T, lstm_dtype=dt, vgg_dtype=dt, max_images=B, n_layers=a.layers)
@@ -165,7 +361,8 @@ def main():
     L.vgg_load(ctx, *vgg_w)
     param = L.initweights(ctx, seed=42)          # identical on every rank (same seed)
     optim = L.initparams(param)
-    trainer = dp.DataParallelTrainer(ctx, param, optim, Bg, world, rank, pdrop=a.pdrop, seed=7)
+    backend = a.dp_backend if a.dp_backend != "auto" else "torch"   # 'auto' is resolved by launch(); a torchrun-launched job cannot retry
+    trainer = dp.DataParallelTrainer(ctx, param, optim, Bg, world, rank, pdrop=a.pdrop, seed=7, backend=backend)
 
     # synthetic inputs: uint8 crops uniform seed 1234; Zipf(1.0) word ids >= 3, seed 7; one T per batch
     g = torch.Generator(device="cuda")
@@ -199,15 +396,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    import gc  # a full pass of Python's cyclic GC scans every object torch created (tens of ms): none inside the timed region
-    if os.environ.get("LRCN_BENCH_GC_LATE"):
-        run(a.warmup)
-        gc.collect()
-        gc.freeze()
-    else:
-        gc.collect()
-        gc.freeze()
-        run(a.warmup)
+    import gc  # a full pass of Python's cyclic GC scans every object torch created (tens of ms): none inside the timed region,
+    gc.collect()  # and none between the warm-up and the timed region either (an idle gap there restarts the clock ramp)
+    gc.freeze()
+    # set-up: device spin-up (see --spinup-ms).  VGG forwards only: no training state changes, the W warm-up steps stay W.
+    spun = 0
+    if a.spinup_ms > 0:
+        t_spin = time.perf_counter()
+        while (time.perf_counter() - t_spin) * 1e3 < a.spinup_ms:
+            L.convnet_u8(ctx, imgs_all[0])
+            torch.cuda.synchronize()
+            spun += 1
+    run(a.warmup)
     barrier()
     _lib = lrcn_amd._lib
     _lib.check(ctx._h, _lib.lib().lrcn_profile(ctx._h, 1))
@@ -233,7 +433,7 @@ def main():
 
     if rank == 0:
         ms_step = 1e3 * dt_s / a.steps
-        value = Bg * a.steps / dt_s
+        value = (B if a.emulate_world > 1 else Bg) * a.steps / dt_s
         # dominant kernel family: the 12 convolution launches conv1_2..conv5_3 (2 x conv64_kernel + 10 x gemm8p_kernel<CONV3>)
         # bf16: conv1_1 runs inside conv1_2's launch (conv64.hip FUSE), so its FLOPs belong to the 12 timed launches
         fused11 = a.dtype == "bf16" and os.environ.get("LRCN_FUSE11", "1")[:1] != "0" and os.environ.get("LRCN_CONV64", "1")[:1] != "0"
@@ -241,27 +441,34 @@ def main():
         avg_launch_s = conv_ms.value * 1e-3 / max(conv_n.value, 1)
         achieved = flops_per_launch / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
         peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
+        traffic, traffic_note = pmc_traffic(a.dtype, B)
         out = {
-            "metric": "training images/sec (VGG16+LSTM, COCO, batch 256) at 1/2/4/8 MI355X",
+            "metric": metric_name(a),
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_step, "ms_per_step_median": median_ms,
-            "ms_per_step_first8": [round(x, 3) for x in step_ms_seq[:8]], "ms_per_step_last": round(step_ms_seq[-1], 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "ms_per_step_first8": [round(x, 3) for x in step_ms_seq[:8]], "ms_per_step_last": round(step_ms_seq[-1], 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": "%s: VGG-16 -> fc7 fwd + %s LSTM "
                                    "E=H=%d V=%d T=%d fwd/bwd + Adam, global batch %d, dp%d, dropout %.1f; synthetic uint8 "
                                    "224x224 crops, He-normal VGG weights"
-                                   % ("BASELINE.json configs[3] (C4), MS-COCO-shaped" if (a.layers == 2 and a.dtype == "bf16" and Bg == 256 and H == 1000)
-                                      else ("BASELINE.json configs[1] (C2), Flickr8k-shaped" if (a.layers == 1 and a.dtype == "f32" and Bg == 32 and H == 512)
-                                            else "custom"),
-                                      "LRCN-2f (2-layer)" if a.layers == 2 else "LRCN-1f (1-layer)", H, V, T, Bg, world, a.pdrop),
+                                   % (workload_name(a), "LRCN-2f (2-layer)" if a.layers == 2 else "LRCN-1f (1-layer)", H, V, T, Bg,
+                                      world, a.pdrop),
                        "global_batch": Bg, "per_gpu_batch": B, "seq_len": T + 1, "parallelism": "dp%d" % world,
-                       "last_loss": loss},
+                       "last_loss": loss,
+                       "setup_spinup": "%d untimed VGG forwards (%.0f ms) before the warm-up steps; not training steps" % (spun, a.spinup_ms)},
+            "rccl": {"world": world, "backend": ("none (one rank: no collective)" if world == 1 else trainer.backend),
+                     "launched_by": "bench.py" if os.environ.get("LRCN_BENCH_LAUNCHED") else ("torch.distributed.run" if world > 1 else "direct")},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": pmc_traffic(a.dtype, B),
+                         "traffic": traffic, "traffic_source": traffic_note,
                          "kernel": "conv64_kernel (conv1_1+conv1_2 fused, conv2_1) + gemm8p_kernel<*,CONV3,*> (conv2_2..conv5_3): 12 launches/step"
                                    if a.dtype == "bf16" else "gemm_glds_kernel<float,*,CONV3,*> v_mfma_f32_32x32x2_f32 (conv1_2..conv5_3)",
                          "avg_launch_ms": 1e3 * avg_launch_s, "flops_per_launch": flops_per_launch},
         }
+        if a.emulate_world > 1:
+            out["config"]["emulate_world"] = a.emulate_world
+            out["config"]["note"] = ("value = this ONE rank's rows per second; an N-rank job adds the gradient exchange (DESIGN 5) and "
+                                     "finishes when its slowest rank does")
         if world == 1 and not a.no_cpu_baseline:
             host_w = ([L.from_jl(w) for w in vgg_w[0]], [b.cpu().numpy() for b in vgg_w[1]],
                       (L.from_jl(vgg_w[2][0]), vgg_w[2][1].cpu().numpy()), (L.from_jl(vgg_w[3][0]), vgg_w[3][1].cpu().numpy()))
@@ -271,7 +478,19 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def caption_main(a, argv):
+    """--config c5: BASELINE.json configs[4], captions/sec of fp8 VGG + bf16 LSTM beam-5 generation.  The loop lives in
+    tools/caption_bench.py (replicas only: no collective on the data path); N > 1 is self-launched the same way as training."""
+    import runpy
+    if a.gpus > 1 and os.environ.get("WORLD_SIZE") is None:
+        return launch(a, argv)
+    sys.argv = [os.path.join(ROOT, "tools", "caption_bench.py"), "--images", "1024", "--chunk", "1024", "--iters", str(max(2, a.steps // 10))]
+    runpy.run_path(sys.argv[0], run_name="__main__")
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

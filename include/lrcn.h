@@ -78,6 +78,26 @@ int lrcn_free(void *dev_ptr);
 int lrcn_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
 int lrcn_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
 const char *lrcn_version(void);
+/* ABI revision of this header.  It changes whenever a struct layout or an existing signature changes (lrcn_config gained its trailing
+ * n_layers field at revision 2; revision 3 added the entry points marked "rev 3").  A binding compiled against another revision must
+ * refuse to run: lrcn_create reads sizeof(lrcn_config) bytes of the caller's struct. */
+#define LRCN_ABI_VERSION 3
+int lrcn_abi_version(void);
+/* Options (rev 3).  Returns LRCN_EINVAL for an unknown option or a value outside its range.
+ *   LRCN_OPT_FUSED_UPDATE (0 | 1, default 0): lrcn_train_step / lrcn_train_step_dp write the NEXT step's K-contiguous shadow weights
+ *     (the bf16 / f32, direct and transposed copies every lossgradient otherwise makes from the f32 parameters first) from inside the Adam
+ *     kernel, into a second set of shadow buffers, and the next loss / lossgradient / train step with the SAME nine parameter pointers
+ *     skips its shadow pass.  Contract: between those two calls the caller does not write the parameter arrays except through this
+ *     library (lrcn_init_weights, lrcn_adam_update* invalidate the shadows themselves) -- or says so with lrcn_params_touched().
+ *   LRCN_OPT_DETERMINISTIC (0 | 1, default 0): every floating-point sum on the lossgradient route is taken in a fixed order (the
+ *     embedding-gradient scatter, the bias column sums, the split-K contractions and the loss accumulator use ordered partial sums
+ *     instead of float atomics): two calls on the same inputs give bit-identical gradients.  Slower.
+ *   LRCN_OPT_CONV_CHUNK_BYTES (development knob; 0 = default 0xF0000000): input bytes above which a convolution is cut into launches of
+ *     whole images (the direct-to-LDS kernels address their input with 32-bit offsets). */
+enum { LRCN_OPT_FUSED_UPDATE = 1, LRCN_OPT_DETERMINISTIC = 2, LRCN_OPT_CONV_CHUNK_BYTES = 3 };
+int lrcn_set_option(lrcn_ctx *ctx, int option, int64_t value);
+/* The caller wrote parameter arrays itself (loaded a checkpoint, clipped, ...): the next call makes its shadow weights afresh (rev 3). */
+int lrcn_params_touched(lrcn_ctx *ctx);
 
 /* ---- model ---- */
 /* Element counts of the 9 tensors (two-layer model), and for a given lrcn_config.n_layers (0 for the slots a model lacks). */
@@ -158,6 +178,10 @@ int lrcn_train_step(lrcn_ctx *ctx, float *const params[9], float *const grads[9]
 #define LRCN_UNIQUE_ID_BYTES 128
 /* Rank 0 creates the id (host buffer of LRCN_UNIQUE_ID_BYTES); the host program hands it to the other ranks by any channel. */
 int lrcn_comm_unique_id(void *id_out);
+/* LOCAL, non-collective check that lrcn_comm_init can be entered on this rank: librccl is loadable, every entry point resolves, the
+ * context has no communicator yet (rev 3).  lrcn_comm_init is a collective: a rank that fails BEFORE entering it would leave the others
+ * blocked inside it, so a host program probes on every rank first, agrees on the result, and only then calls lrcn_comm_init. */
+int lrcn_comm_probe(lrcn_ctx *ctx);
 /* Collective over the `world` contexts: binds ctx to rank `rank` of the communicator named by the id. */
 int lrcn_comm_init(lrcn_ctx *ctx, int world, int rank, const void *unique_id);
 int lrcn_comm_destroy(lrcn_ctx *ctx);

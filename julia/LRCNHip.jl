@@ -8,6 +8,11 @@
 module LRCNHip
 
 const lib = get(ENV, "LRCN_HIP_LIB", "liblrcn_hip.so")
+const ABI_VERSION = 3   # include/lrcn.h LRCN_ABI_VERSION: the revision the struct layouts below were written against
+function __init__()
+    v = ccall((:lrcn_abi_version, lib), Cint, ())
+    v == ABI_VERSION || error("liblrcn_hip implements ABI revision $v, LRCNHip.jl was written against $ABI_VERSION")
+end
 
 struct Config
     device::Cint; E::Cint; H1::Cint; H2::Cint; V::Cint
@@ -145,6 +150,10 @@ function comm_unique_id()
     rc == 0 || check(nothing, rc)
     id
 end
+# local (non-collective) check; every rank probes, the ranks agree, and only then enter the collective comm_init
+comm_probe(ctx) = ccall((:lrcn_comm_probe, lib), Cint, (Ptr{Cvoid},), ctx.h) == 0
+set_option(ctx, option::Integer, value::Integer) = check(ctx, ccall((:lrcn_set_option, lib), Cint, (Ptr{Cvoid}, Cint, Int64), ctx.h, option, value))
+params_touched(ctx) = check(ctx, ccall((:lrcn_params_touched, lib), Cint, (Ptr{Cvoid},), ctx.h))
 comm_init(ctx, world, rank, id::Vector{UInt8}) = check(ctx, ccall((:lrcn_comm_init, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{UInt8}), ctx.h, world, rank, id))
 allreduce_grads(ctx, grads; group = -1) = check(ctx, ccall((:lrcn_allreduce_grads, lib), Cint, (Ptr{Cvoid}, Ptr{Ptr{Cfloat}}, Cint), ctx.h, ptrs(grads), group))
 comm_join(ctx) = check(ctx, ccall((:lrcn_comm_join, lib), Cint, (Ptr{Cvoid},), ctx.h))

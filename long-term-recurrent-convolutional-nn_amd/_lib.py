@@ -13,6 +13,8 @@ LIB_PATH = os.environ.get("LRCN_HIP_LIB") or os.path.join(CSRC, "liblrcn_hip.so"
 HEADER = os.path.normpath(os.path.join(HERE, "..", "include", "lrcn.h"))
 
 LRCN_F32, LRCN_BF16, LRCN_FP8 = 0, 1, 2
+LRCN_ABI_VERSION = 3   # include/lrcn.h: the revision this binding's struct layouts and signatures were written against
+LRCN_OPT_FUSED_UPDATE, LRCN_OPT_DETERMINISTIC, LRCN_OPT_CONV_CHUNK_BYTES = 1, 2, 3
 EOS, BOS, UNK = 0, 1, 2
 CNNOUT = 4096
 MAX_T = 28
@@ -48,6 +50,10 @@ SIGNATURES = {
     "lrcn_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "lrcn_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "lrcn_version": (C.c_char_p, []),
+    "lrcn_abi_version": (C.c_int, []),
+    "lrcn_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int64]),
+    "lrcn_params_touched": (C.c_int, [C.c_void_p]),
+    "lrcn_comm_probe": (C.c_int, [C.c_void_p]),
     "lrcn_param_sizes": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
     "lrcn_param_sizes_n": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
     "lrcn_init_weights": (C.c_int, [C.c_void_p, P9, C.c_uint64]),
@@ -128,6 +134,9 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        if L.lrcn_abi_version() != LRCN_ABI_VERSION:
+            raise LrcnError("%s implements ABI revision %d, this binding was written against %d (lrcn_config's layout differs)"
+                            % (LIB_PATH, L.lrcn_abi_version(), LRCN_ABI_VERSION))
         _LIB = L
     return _LIB
 

@@ -11,6 +11,8 @@ struct LrcnComm;  // opaque: RCCL communicator + the entry points resolved from 
 LrcnComm *comm_create(int world, int rank, const void *unique_id128, char *err, size_t errn);
 void comm_destroy(LrcnComm *c);
 int comm_world(const LrcnComm *c);
+// local check: librccl can be opened and every entry point used here resolves; 0 = yes
+int comm_available(char *err, size_t errn);
 // 128-byte RCCL unique id (host buffer); 0 on success
 int comm_unique_id(void *out128, char *err, size_t errn);
 // in-place all-reduce(SUM) of `count` floats on `stream`; several calls may be bracketed by comm_group_begin / _end

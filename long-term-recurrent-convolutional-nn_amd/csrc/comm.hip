@@ -63,6 +63,15 @@ struct LrcnComm {
     int world = 1, rank = 0;
 };
 
+int comm_available(char *err, size_t errn) {
+    Api &a = api();
+    if (!a.ok) {
+        snprintf(err, errn, "%s", a.why);
+        return -1;
+    }
+    return 0;
+}
+
 int comm_unique_id(void *out128, char *err, size_t errn) {
     Api &a = api();
     if (!a.ok) {

@@ -68,9 +68,12 @@ void k_transpose_f32(hipStream_t st, const float *in, int64_t ld_in, int R, int 
 // One launch for all shadow weights: parameter memory image src[R][C] (f32, C contiguous) -> direct copies split at column cs
 // (dA[r][c] | dB[r][c - cs]) and transposed copies (tA[c][r] | tB[c - cs][r]) in T; NULL destinations are skipped.  Padding
 // columns of the destinations are left as they are (zero since allocation).
-#define PREP_MAX 8
+#define PREP_MAX 12
 struct PrepDesc {
     const float *src;
+    // k_adam_shadows only: the tensor's gradient and Adam moments (memory images like src, which is then also written)
+    const float *g;
+    float *m, *v;
     int R, C, cs;
     void *dA, *dB, *tA, *tB;
     int64_t ldA, ldB, ldtA, ldtB;
@@ -84,8 +87,13 @@ struct PrepDesc {
 struct PrepPlan {
     PrepDesc d[PREP_MAX];
     int n;
+    float lr, b1, b2, eps, c1, c2;  // k_adam_shadows
 };
 void k_prepare_weights(hipStream_t st, int dtype, PrepPlan &plan);
+// update! (lrcn.jl:394) and the NEXT step's shadow weights in one pass over the parameters: every descriptor's src / g / m / v are
+// updated exactly as k_adam does (same arithmetic, element by element) and the new values are written to the descriptor's shadow
+// destinations.  Descriptors without destinations (the biases: R = 1) are plain Adam.
+void k_adam_shadows(hipStream_t st, int dtype, PrepPlan &plan, int step, float lr, float b1, float b2, float eps);
 // out[r][c] = (T) in[r*ld_in + c]  (f32 -> T copy of a sub-matrix; pads [C, ld_out) with zeros)
 void k_cast_rows(hipStream_t st, int dtype, const float *in, int64_t ld_in, int R, int C, void *out, int64_t ld_out);
 // out[r][c] = (T) act(in[r][c] + bias[c])  (epilogue of a split-K GEMM whose partial sums were combined in f32)

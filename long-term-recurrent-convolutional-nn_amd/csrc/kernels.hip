@@ -318,7 +318,7 @@ __global__ void transpose_kernel(const Tin *in, int64_t ld_in, int R, int C, Tou
 // All shadow weights of one model in ONE launch (was 8 cast_rows + 9 transpose launches per step): for every 32 x 32 tile of
 // a parameter's memory image [R][C] (f32) write the direct copy split at column `cs` (dA[r][c], dB[r][c - cs]) and / or the
 // transposed copy (tA[c][r], tB[c - cs][r]) in T.  Padding columns of the destinations are never touched (zero since allocation).
-template <typename T> __global__ __launch_bounds__(256) void prepare_weights_kernel(const PrepPlan plan) {
+template <typename T, bool ADAM = false> __global__ __launch_bounds__(256) void prepare_weights_kernel(const PrepPlan plan) {
     // 64 x 64 tiles, 16 bytes in / 8 bytes out per thread access (bf16); generic element-wise path for f32 shadows and edges
     __shared__ float tile[64][65];
     int d = 0;
@@ -345,6 +345,38 @@ template <typename T> __global__ __launch_bounds__(256) void prepare_weights_ker
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     if (c + k < P.C) v[k] = P.src[(int64_t)r * P.C + c + k];
+            }
+            if constexpr (ADAM) {  // update! on the loaded values (the arithmetic of adam_kernel), written back before the shadows are made
+                const int64_t o = (int64_t)r * P.C + c;
+                float gg[4] = {0.f, 0.f, 0.f, 0.f}, mm[4] = {0.f, 0.f, 0.f, 0.f}, vv[4] = {0.f, 0.f, 0.f, 0.f};
+                const bool v4 = vec && c + 3 < P.C;
+                if (v4) {
+                    const float4 a = *reinterpret_cast<const float4 *>(P.g + o), b = *reinterpret_cast<const float4 *>(P.m + o),
+                                 d4 = *reinterpret_cast<const float4 *>(P.v + o);
+                    gg[0] = a.x; gg[1] = a.y; gg[2] = a.z; gg[3] = a.w;
+                    mm[0] = b.x; mm[1] = b.y; mm[2] = b.z; mm[3] = b.w;
+                    vv[0] = d4.x; vv[1] = d4.y; vv[2] = d4.z; vv[3] = d4.w;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (c + k < P.C) { gg[k] = P.g[o + k]; mm[k] = P.m[o + k]; vv[k] = P.v[o + k]; }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    mm[k] = plan.b1 * mm[k] + (1.0f - plan.b1) * gg[k];
+                    vv[k] = plan.b2 * vv[k] + (1.0f - plan.b2) * gg[k] * gg[k];
+                    v[k] -= plan.lr * (mm[k] / plan.c1) / (sqrtf(vv[k] / plan.c2) + plan.eps);
+                }
+                float *w = const_cast<float *>(P.src);
+                if (v4) {
+                    *reinterpret_cast<float4 *>(P.m + o) = make_float4(mm[0], mm[1], mm[2], mm[3]);
+                    *reinterpret_cast<float4 *>(P.v + o) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                    *reinterpret_cast<float4 *>(w + o) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (c + k < P.C) { P.m[o + k] = mm[k]; P.v[o + k] = vv[k]; w[o + k] = v[k]; }
+                }
             }
             if (P.dG) {  // gate-interleaved rows of the B side (element-wise: the destination is written once per step, 8 MB)
                 const int rg = (r % P.giH) * 4 + r / P.giH;
@@ -1105,6 +1137,18 @@ void k_prepare_weights(hipStream_t st, int dtype, PrepPlan &plan) {
     }
     if (tiles == 0) return;
     DISPATCH_T(dtype, hipLaunchKernelGGL(prepare_weights_kernel<T>, dim3(tiles), dim3(256), 0, st, plan));
+}
+void k_adam_shadows(hipStream_t st, int dtype, PrepPlan &plan, int step, float lr, float b1, float b2, float eps) {
+    int tiles = 0;
+    for (int k = 0; k < plan.n; ++k) {
+        plan.d[k].tile0 = tiles;
+        tiles += cdiv(plan.d[k].R, 64) * cdiv(plan.d[k].C, 64);
+    }
+    if (tiles == 0) return;
+    plan.lr = lr; plan.b1 = b1; plan.b2 = b2; plan.eps = eps;
+    plan.c1 = (float)(1.0 - pow((double)b1, (double)step));
+    plan.c2 = (float)(1.0 - pow((double)b2, (double)step));
+    DISPATCH_T(dtype, hipLaunchKernelGGL((prepare_weights_kernel<T, true>), dim3(tiles), dim3(256), 0, st, plan));
 }
 void k_cast_rows(hipStream_t st, int dtype, const float *in, int64_t ld_in, int R, int C, void *out, int64_t ld_out) {
     const dim3 grid(cdiv(ld_out, 256) > 64 ? 64 : cdiv(ld_out, 256), R);

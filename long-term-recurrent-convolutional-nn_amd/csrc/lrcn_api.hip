@@ -60,6 +60,16 @@ struct lrcn_ctx {
     void *W2x = nullptr, *W2h = nullptr, *W2xT = nullptr, *W2hT = nullptr;
     void *W1h_gi = nullptr, *W2h_gi = nullptr;  // recurrent weights with (unit, gate)-interleaved rows (gemm_8p.hip LSTM_FWD epilogue), lazily
     void *Wpd = nullptr, *WpT = nullptr, *Wcd = nullptr, *WeT = nullptr, *Wod = nullptr, *WoT = nullptr;
+    // LRCN_OPT_FUSED_UPDATE: the second set of the 14 training shadows above.  The Adam kernel of a train step writes the NEXT step's
+    // shadows into it while (per-group pipeline) the backward pass may still be reading the current set; then the two sets swap roles.
+    void *alt[14] = {};
+    bool opt_fused = false, opt_det = false;
+    int64_t conv_chunk_bytes = 0;           // LRCN_OPT_CONV_CHUNK_BYTES (0 = default)
+    unsigned fused_groups = 0;              // gradient groups whose fused Adam has been issued in the current step (bit per group)
+    bool shadow_valid = false;              // the current set holds the shadows (direct AND transposed) of the parameters at shadow_p
+    const float *shadow_p[9] = {};
+    float *dWe_rm = nullptr;                // [V][ldE] f32, all zero between calls: row-major staging of the embedding gradient
+    double *logp_rows = nullptr;            // [maxS * maxB] per-row log p(target): the ordered loss sum of LRCN_OPT_DETERMINISTIC
     // activations
     int32_t *tok = nullptr, *tok_in = nullptr, *tok_tgt = nullptr;
     void *F = nullptr, *FT = nullptr;
@@ -262,49 +272,132 @@ DropSpec make_drop(const lrcn_dropout *d, int which) {
     return s;
 }
 
-// f32 column-major params -> K-contiguous shadows in T (direct and transposed).  See DESIGN.md "shadow weights".
-int prepare_weights(lrcn_ctx *c, const float *const p[9], bool need_bwd, bool cat = false, bool gi = false) {
-    const int dt = c->dt, E = c->E, H1 = c->H1, H2 = c->H2, h = c->h, V = c->V;
-    if (!p[0] || !p[1] || !p[5] || !p[6] || !p[7] || !p[8] || (c->nl == 2 && (!p[2] || !p[3] || !p[4]))) FAIL(c, LRCN_EINVAL, "null parameter tensor");
-    hipStream_t st = c->stream;
-    PrepPlan plan{};
-    auto add = [&](const float *src, int R, int C, int cs, void *dA, int64_t ldA, void *dB, int64_t ldB, void *tA, int64_t ldtA, void *tB,
-                   int64_t ldtB) {
+void ctx_sizes(const lrcn_ctx *c, int64_t sz[9]);
+// the 14 training shadows as an array, in a fixed order (lrcn_ctx::alt mirrors it)
+struct ShadowSet {
+    void *W1x, *W1h, *W1xT, *W1hT, *W2x, *W2h, *W2xT, *W2hT, *Wpd, *WpT, *Wcd, *WeT, *Wod, *WoT;
+};
+ShadowSet cur_shadows(const lrcn_ctx *c) {
+    return ShadowSet{c->W1x, c->W1h, c->W1xT, c->W1hT, c->W2x, c->W2h, c->W2xT, c->W2hT, c->Wpd, c->WpT, c->Wcd, c->WeT, c->Wod, c->WoT};
+}
+ShadowSet alt_shadows(const lrcn_ctx *c) {
+    void *const *a = c->alt;
+    return ShadowSet{a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], a[10], a[11], a[12], a[13]};
+}
+void swap_shadow_sets(lrcn_ctx *c) {
+    void **cur[14] = {&c->W1x, &c->W1h, &c->W1xT, &c->W1hT, &c->W2x, &c->W2h, &c->W2xT, &c->W2hT, &c->Wpd, &c->WpT, &c->Wcd, &c->WeT, &c->Wod, &c->WoT};
+    for (int i = 0; i < 14; ++i) std::swap(*cur[i], c->alt[i]);
+}
+int ensure_alt_shadows(lrcn_ctx *c) {
+    if (c->alt[0]) return LRCN_OK;
+    const size_t es = c->esz;
+    const int E = c->E, H1 = c->H1, H2 = c->H2, h = c->h, V = c->V, X1 = c->X1;
+    const size_t bytes[14] = {es * 4 * H1 * c->ldX1, es * 4 * H1 * c->ldH1, es * X1 * c->ld4H1, es * H1 * c->ld4H1,
+                              es * 4 * H2 * c->ldH2, es * 4 * H2 * c->ldH2, es * H2 * c->ld4H2, es * H2 * c->ld4H2,
+                              es * h * c->ldH1, es * H1 * c->ldh, es * h * LRCN_CNNOUT, es * V * c->ldE, es * V * c->ldH2, es * H2 * c->ldV};
+    (void)E;
+    for (int i = 0; i < 14; ++i) DALLOC(c, c->alt[i], bytes[i]);  // zero-filled: the K padding must hold zeros
+    return LRCN_OK;
+}
+
+// the six parameter matrices of the model -> descriptors of their shadows in `w` (memory images: see the comments per line)
+void plan_matrices(const lrcn_ctx *c, const float *const p[9], const ShadowSet &w, bool b, PrepPlan &plan, int only_a = -1, int only_b = -1) {
+    const int E = c->E, H1 = c->H1, H2 = c->H2, h = c->h, V = c->V, X1 = c->X1;
+    const bool two = c->nl == 2;
+    auto add = [&](int k, int R, int C, int cs, void *dA, int64_t ldA, void *dB, int64_t ldB, void *tA, int64_t ldtA, void *tB, int64_t ldtB) {
+        if (only_a >= 0 && k != only_a && k != only_b) return;
         PrepDesc &d = plan.d[plan.n++];
-        d.src = src; d.R = R; d.C = C; d.cs = cs;
+        d = PrepDesc{};
+        d.src = p[k]; d.R = R; d.C = C; d.cs = cs;
         d.dA = dA; d.ldA = ldA; d.dB = dB; d.ldB = ldB;
         d.tA = tA; d.ldtA = ldtA; d.tB = tB; d.ldtB = ldtB;
     };
-    const bool b = need_bwd, two = c->nl == 2;
-    const int X1 = c->X1;
+    (void)E;
     // W1: memory [4H1][X1 + H1] -> W1x | W1h (and their transposes [X1][ld4H1] | [H1][ld4H1] for the backward dX GEMMs)
+    add(0, 4 * H1, X1 + H1, X1, w.W1x, c->ldX1, w.W1h, c->ldH1, b ? w.W1xT : nullptr, c->ld4H1, b ? w.W1hT : nullptr, c->ld4H1);
+    if (two) {
+        add(2, 4 * H2, 2 * H2, H2, w.W2x, c->ldH2, w.W2h, c->ldH2, b ? w.W2xT : nullptr, c->ld4H2, b ? w.W2hT : nullptr, c->ld4H2);
+        add(4, h, H1, H1, w.Wpd, c->ldH1, nullptr, 0, b ? w.WpT : nullptr, c->ldh, nullptr, 0);  // Wproj (H1 x h): memory [h][H1]
+    }
+    add(5, h, LRCN_CNNOUT, LRCN_CNNOUT, w.Wcd, LRCN_CNNOUT, nullptr, 0, nullptr, 0, nullptr, 0);   // Wcnn: memory [h][4096]
+    add(6, E, V, V, nullptr, 0, nullptr, 0, w.WeT, c->ldE, nullptr, 0);                          // Wembed (V x E): memory [E][V] -> [V][ldE]
+    add(7, V, H2, H2, w.Wod, c->ldH2, nullptr, 0, b ? w.WoT : nullptr, c->ldV, nullptr, 0);   // Wout (H2 x V): memory [V][H2]
+}
+
+// f32 column-major params -> K-contiguous shadows in T (direct and transposed).  See DESIGN.md "shadow weights".
+int prepare_weights(lrcn_ctx *c, const float *const p[9], bool need_bwd, bool cat = false, bool gi = false) {
+    const int dt = c->dt, H1 = c->H1, H2 = c->H2, X1 = c->X1;
+    if (!p[0] || !p[1] || !p[5] || !p[6] || !p[7] || !p[8] || (c->nl == 2 && (!p[2] || !p[3] || !p[4]))) FAIL(c, LRCN_EINVAL, "null parameter tensor");
+    hipStream_t st = c->stream;
+    const bool two = c->nl == 2;
+    // LRCN_OPT_FUSED_UPDATE: the previous train step's Adam kernel already wrote this set from these very parameters
+    if (c->opt_fused && c->shadow_valid && !cat && !gi) {
+        bool same = true;
+        for (int k = 0; k < 9; ++k) same = same && c->shadow_p[k] == p[k];
+        if (same) return LRCN_OK;
+    }
+    c->shadow_valid = false;
+    PrepPlan plan{};
     if (gi) {
         if (!c->W1h_gi) DALLOC(c, c->W1h_gi, c->esz * 4 * H1 * c->ldH1);
         if (two && !c->W2h_gi) DALLOC(c, c->W2h_gi, c->esz * 4 * H2 * c->ldH2);
     }
-    add(p[0], 4 * H1, X1 + H1, X1, c->W1x, c->ldX1, c->W1h, c->ldH1, b ? c->W1xT : nullptr, c->ld4H1, b ? c->W1hT : nullptr, c->ld4H1);
+    plan_matrices(c, p, cur_shadows(c), need_bwd, plan);
     if (gi) {
-        PrepDesc &d = plan.d[plan.n - 1];
+        PrepDesc &d = plan.d[0];
         d.dG = c->W1h_gi; d.ldG = c->ldH1; d.giH = H1;
-    }
-    if (two) {
-        add(p[2], 4 * H2, 2 * H2, H2, c->W2x, c->ldH2, c->W2h, c->ldH2, b ? c->W2xT : nullptr, c->ld4H2, b ? c->W2hT : nullptr, c->ld4H2);
-        if (gi) {
-            PrepDesc &d = plan.d[plan.n - 1];
-            d.dG = c->W2h_gi; d.ldG = c->ldH2; d.giH = H2;
+        if (two) {
+            PrepDesc &d2 = plan.d[1];
+            d2.dG = c->W2h_gi; d2.ldG = c->ldH2; d2.giH = H2;
         }
-        add(p[4], h, H1, H1, c->Wpd, c->ldH1, nullptr, 0, b ? c->WpT : nullptr, c->ldh, nullptr, 0);  // Wproj (H1 x h): memory [h][H1]
     }
-    add(p[5], h, LRCN_CNNOUT, LRCN_CNNOUT, c->Wcd, LRCN_CNNOUT, nullptr, 0, nullptr, 0, nullptr, 0);   // Wcnn: memory [h][4096]
-    add(p[6], E, V, V, nullptr, 0, nullptr, 0, c->WeT, c->ldE, nullptr, 0);                          // Wembed (V x E): memory [E][V] -> [V][ldE]
-    add(p[7], V, H2, H2, c->Wod, c->ldH2, nullptr, 0, b ? c->WoT : nullptr, c->ldV, nullptr, 0);   // Wout (H2 x V): memory [V][H2]
     if (cat) {  // batched decode: W1 / W2 with the x and h column blocks each padded to whole K-steps, side by side
-        add(p[0], 4 * H1, X1 + H1, X1, c->W1cat, c->ldXH1, boff(c->W1cat, c->ldX1, c->esz), c->ldXH1, nullptr, 0, nullptr, 0);
-        if (two) add(p[2], 4 * H2, 2 * H2, H2, c->W2cat, c->ldXH2, boff(c->W2cat, c->ldH2, c->esz), c->ldXH2, nullptr, 0, nullptr, 0);
+        auto add = [&](const float *src, int R, int C, int cs, void *dA, int64_t ldA, void *dB, int64_t ldB) {
+            PrepDesc &d = plan.d[plan.n++];
+            d = PrepDesc{};
+            d.src = src; d.R = R; d.C = C; d.cs = cs; d.dA = dA; d.ldA = ldA; d.dB = dB; d.ldB = ldB;
+        };
+        add(p[0], 4 * H1, X1 + H1, X1, c->W1cat, c->ldXH1, boff(c->W1cat, c->ldX1, c->esz), c->ldXH1);
+        if (two) add(p[2], 4 * H2, 2 * H2, H2, c->W2cat, c->ldXH2, boff(c->W2cat, c->ldH2, c->esz), c->ldXH2);
     }
     k_prepare_weights(st, dt, plan);
     KCHK(c, "prepare_weights");
     return LRCN_OK;
+}
+
+// update! (lrcn.jl:394) of the tensors of gradient group `group` (-1: all nine) fused with the NEXT step's shadow pass (LRCN_OPT_FUSED_UPDATE):
+// the kernel writes the not-current shadow set; the caller swaps the sets once every group has been issued.
+int adam_fused(lrcn_ctx *c, float *const p[9], const float *const g[9], float *const m[9], float *const v[9], int group, int step, float lr,
+               float b1, float b2, float eps, hipStream_t st) {
+    static const int kGroup[LRCN_GRAD_GROUPS][2] = {{7, 8}, {2, 3}, {4, 5}, {0, 1}, {6, 6}};
+    int r = ensure_alt_shadows(c);
+    if (r) return r;
+    int64_t sz[9];
+    ctx_sizes(c, sz);
+    PrepPlan plan{};
+    const int ka = group < 0 ? -1 : kGroup[group][0], kb = group < 0 ? -1 : kGroup[group][1];
+    plan_matrices(c, p, alt_shadows(c), true, plan, ka, kb);
+    for (int i = 0; i < plan.n; ++i) {
+        PrepDesc &d = plan.d[i];
+        int k = 0;
+        while (k < 9 && p[k] != d.src) ++k;
+        d.g = g[k]; d.m = m[k]; d.v = v[k];
+    }
+    for (int k : {1, 3, 8}) {  // the biases: plain Adam, one "row" of n elements
+        if (sz[k] == 0 || (group >= 0 && k != ka && k != kb)) continue;
+        PrepDesc &d = plan.d[plan.n++];
+        d = PrepDesc{};
+        d.src = p[k]; d.g = g[k]; d.m = m[k]; d.v = v[k];
+        d.R = 1; d.C = (int)sz[k]; d.cs = (int)sz[k];
+    }
+    k_adam_shadows(st, c->dt, plan, step, lr, b1, b2, eps);
+    KCHK(c, "adam (fused with the shadow pass)");
+    return LRCN_OK;
+}
+void fused_update_done(lrcn_ctx *c, float *const p[9]) {  // every tensor's Adam has been issued: the written set becomes the current one
+    swap_shadow_sets(c);
+    for (int k = 0; k < 9; ++k) c->shadow_p[k] = p[k];
+    c->shadow_valid = true;
 }
 
 // One LSTM layer over all S steps.  Gx f32 [M][4H] holds the input-side pre-activations (+bias) on entry and the full
@@ -684,7 +777,36 @@ void ctx_sizes(const lrcn_ctx *c, int64_t sz[9]) { lrcn_param_sizes_n(c->nl, c->
 // =====================================================================================================
 extern "C" {
 
-const char *lrcn_version(void) { return "lrcn-hip 0.1 (gfx950)"; }
+const char *lrcn_version(void) { return "lrcn-hip 0.3 (gfx950)"; }
+int lrcn_abi_version(void) { return LRCN_ABI_VERSION; }
+
+int lrcn_set_option(lrcn_ctx *c, int option, int64_t value) {
+    if (!c) return LRCN_EINVAL;
+    switch (option) {
+    case LRCN_OPT_FUSED_UPDATE:
+        if (value != 0 && value != 1) FAIL(c, LRCN_EINVAL, "LRCN_OPT_FUSED_UPDATE takes 0 or 1");
+        c->opt_fused = value != 0;
+        c->shadow_valid = false;
+        c->fused_groups = 0;
+        return LRCN_OK;
+    case LRCN_OPT_DETERMINISTIC:
+        if (value != 0 && value != 1) FAIL(c, LRCN_EINVAL, "LRCN_OPT_DETERMINISTIC takes 0 or 1");
+        c->opt_det = value != 0;
+        return LRCN_OK;
+    case LRCN_OPT_CONV_CHUNK_BYTES:
+        if (value < 0) FAIL(c, LRCN_EINVAL, "LRCN_OPT_CONV_CHUNK_BYTES must be >= 0");
+        c->conv_chunk_bytes = value;
+        return LRCN_OK;
+    default:
+        FAIL(c, LRCN_EINVAL, "unknown option %d", option);
+    }
+}
+
+int lrcn_params_touched(lrcn_ctx *c) {
+    if (!c) return LRCN_EINVAL;
+    c->shadow_valid = false;
+    return LRCN_OK;
+}
 
 const char *lrcn_last_error(const lrcn_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
@@ -913,6 +1035,7 @@ int lrcn_init_weights(lrcn_ctx *c, float *const p[9], uint64_t seed) {
         }
     }
     KCHK(c, "init_weights");
+    c->shadow_valid = false;
     return LRCN_OK;
 }
 
@@ -958,6 +1081,13 @@ int lrcn_adam_update(lrcn_ctx *c, float *const p[9], const float *const g[9], fl
                      float lr, float b1, float b2, float eps) {
     DeviceGuard dg(c);
     if (!c || !p || !g || !m || !v || step < 1) return LRCN_EINVAL;
+    if (c->opt_fused) {  // LRCN_OPT_FUSED_UPDATE: the same update, and the next step's shadow weights in the same pass
+        int r = adam_fused(c, p, g, m, v, -1, step, lr, b1, b2, eps, c->stream);
+        if (r) return r;
+        fused_update_done(c, p);
+        return LRCN_OK;
+    }
+    c->shadow_valid = false;
     AdamTensors t;
     int64_t sz[9];
     ctx_sizes(c, sz);
@@ -979,6 +1109,20 @@ int lrcn_adam_update_group(lrcn_ctx *c, float *const p[9], const float *const g[
     if (!c || !p || !g || !m || !v || step < 1) return LRCN_EINVAL;
     if (group < 0 || group >= LRCN_GRAD_GROUPS) FAIL(c, LRCN_EINVAL, "group=%d outside [0,%d)", group, LRCN_GRAD_GROUPS);
     static const int kGroup[LRCN_GRAD_GROUPS][2] = {{7, 8}, {2, 3}, {4, 5}, {0, 1}, {6, 6}};  // order of the grad_ev records
+    if (c->opt_fused) {
+        // fused with the shadow pass; the written set becomes current once all five groups of this step have been issued (they are
+        // issued in any order, each exactly once per step, with the same `step`)
+        int r = adam_fused(c, p, g, m, v, group, step, lr, b1, b2, eps, stream ? reinterpret_cast<hipStream_t>(stream) : c->stream);
+        if (r) return r;
+        c->fused_groups |= 1u << group;
+        c->shadow_valid = false;
+        if (c->fused_groups == (1u << LRCN_GRAD_GROUPS) - 1) {
+            c->fused_groups = 0;
+            fused_update_done(c, p);
+        }
+        return LRCN_OK;
+    }
+    c->shadow_valid = false;
     AdamTensors t;
     int64_t sz[9];
     ctx_sizes(c, sz);
@@ -1082,6 +1226,14 @@ int lrcn_comm_unique_id(void *id_out) {
     return LRCN_OK;
 }
 
+int lrcn_comm_probe(lrcn_ctx *c) {
+    if (!c) return LRCN_EINVAL;
+    if (c->comm) FAIL(c, LRCN_ESTATE, "the context already has a communicator");
+    char err[256] = "";
+    if (comm_available(err, sizeof(err))) FAIL(c, LRCN_EHIP, "%s", err);
+    return LRCN_OK;
+}
+
 int lrcn_comm_init(lrcn_ctx *c, int world, int rank, const void *unique_id) {
     DeviceGuard dg(c);
     if (!c) return LRCN_EINVAL;
@@ -1139,6 +1291,7 @@ int lrcn_lstm(lrcn_ctx *c, const float *W, const float *b, int X, int H, int B, 
     hipStream_t st = c->stream;
     const int64_t ldX = ld8(X), ldH = ld8(H);
     // shadows of this W: memory [4H][X+H]
+    c->shadow_valid = false;
     k_cast_rows(st, dt, W, X + H, 4 * H, X, Wx, ldX);
     k_cast_rows(st, dt, W + X, X + H, 4 * H, H, Wh, ldH);
     // x (B x X column-major = memory [X][B]) -> [B][ldX] T ; h likewise ; c -> f32 row-major

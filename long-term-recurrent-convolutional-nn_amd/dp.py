@@ -101,8 +101,15 @@ class HipOps:
             main.wait_stream(s)  # the next step's shadow-weight pass reads the updated parameters
 
     # the C-ABI backend: RCCL inside liblrcn_hip (lrcn_comm_init / lrcn_train_step_dp)
+    def comm_probe(self):
+        return L.comm_probe(self.ctx)
+
     def comm_init(self, world, rank, unique_id):
         L.comm_init(self.ctx, world, rank, unique_id)
+
+    def set_fused_update(self, on):
+        """LRCN_OPT_FUSED_UPDATE: Adam writes the next step's shadow weights; the trainer owns the parameters between steps."""
+        self.ctx.set_option(L._lib.LRCN_OPT_FUSED_UPDATE, 1 if on else 0)
 
     def comm_destroy(self):
         try:
@@ -119,52 +126,29 @@ class DataParallelTrainer:
     `ops` defaults to the HIP operations; tests of the collective logic on CPU (gloo) inject their own."""
 
     def __init__(self, ctx, param, optim, B_global, world=1, rank=0, pdrop=0.4, seed=0, group=None, ops=None, backend=None):
-        """backend (world > 1): "abi" = RCCL inside liblrcn_hip (lrcn_comm_init + lrcn_train_step_dp: one C call per step, what a
-        Julia host would drive; the unique id travels over torch.distributed's group) -- the default with the HIP ops;
-        "torch" = torch.distributed all-reduces issued from here (LRCN_DP_BACKEND overrides)."""
+        """backend (world > 1): "torch" (default) = the per-group all-reduces are issued from here through torch.distributed's RCCL
+        process group; "abi" = RCCL inside liblrcn_hip (lrcn_comm_init + lrcn_train_step_dp: one C call per step, what a Julia host
+        would drive; the unique id travels over torch.distributed's group).  LRCN_DP_BACKEND overrides.  "abi" stays opt-in until a
+        multi-GPU run has compared it with "torch" step for step: it has only ever met one rank."""
         self.ops = ops if ops is not None else HipOps(ctx)
         self.ctx, self.param, self.optim = ctx, param, optim
         self.B_global, self.world, self.rank = B_global, world, rank
         self.pdrop, self.seed = pdrop, seed
         self.group = group
-        backend = os.environ.get("LRCN_DP_BACKEND") or backend
-        if backend is None:
-            backend = "abi" if (world > 1 and hasattr(self.ops, "train_step_dp") and param[0].is_cuda) else "torch"
+        backend = os.environ.get("LRCN_DP_BACKEND") or backend or "torch"
+        if backend == "auto":
+            backend = "torch"
         if backend not in ("abi", "torch"):
             raise L.LrcnError("unknown data-parallel backend %r" % (backend,))
+        if backend == "abi" and not hasattr(self.ops, "train_step_dp"):
+            backend = "torch"
         self.backend = backend
+        self.backend_note = ""
         if backend == "abi" and world > 1:
-            # the RCCL unique id travels over torch.distributed's group; byte 128 = rank 0 could make one.  If the library's own
-            # communicator cannot be set up on EVERY rank (librccl not loadable from liblrcn_hip, init error), all ranks agree to use
-            # the torch.distributed collectives instead -- still RCCL over xGMI, issued from Python -- and rank 0 says so.
-            uid = torch.zeros(129, dtype=torch.uint8, device=param[0].device)
-            why = ""
-            if rank == 0:
-                try:
-                    uid[:128].copy_(torch.frombuffer(bytearray(L.comm_unique_id()), dtype=torch.uint8))
-                    uid[128] = 1
-                except L.LrcnError as e:
-                    why = str(e)
-            dist.broadcast(uid, 0, group=group)
-            ok = torch.ones(1, dtype=torch.int32, device=param[0].device)
-            host = uid.cpu().numpy()
-            if host[128]:
-                try:
-                    self.ops.comm_init(world, rank, bytes(host[:128].tobytes()))
-                except L.LrcnError as e:
-                    why = str(e)
-                    ok.zero_()
-            else:
-                ok.zero_()
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
-            if int(ok.item()) == 0:
-                if hasattr(self.ops, "comm_destroy"):
-                    self.ops.comm_destroy()
-                self.backend = "torch"
-                if rank == 0:
-                    import sys
-                    print("lrcn_amd.dp: C-ABI communicator unavailable (%s); using torch.distributed collectives" % (why or "another rank failed"),
-                          file=sys.stderr)
+            self._init_abi_comm(world, rank, group, param[0].device)
+        fused = os.environ.get("LRCN_FUSED_UPDATE", "1")[:1] != "0" and hasattr(self.ops, "set_fused_update")
+        if fused:
+            self.ops.set_fused_update(True)
         self.flat_grads, self.grads = flat_model_like([tuple(t.shape) for t in param], device=param[0].device)
         self.step_no = 0
         self._feats_next = None
@@ -176,6 +160,41 @@ class DataParallelTrainer:
         self._vgg_done = None    # event: the side stream finished the VGG forward whose output is _feats_next
         self._feats_buf = [None, None]  # ping-pong outputs of the side-stream VGG
         self._bucket_streams = None
+
+    def _init_abi_comm(self, world, rank, group, device):
+        """Two phases, so that no rank can be left alone inside the collective lrcn_comm_init (= ncclCommInitRank):
+        1. every rank probes LOCALLY (librccl loadable from liblrcn_hip, every symbol resolved, no communicator on the context; rank 0
+           also makes the unique id) and the ranks all-reduce(MIN) the outcome;
+        2. only if every rank passed: the id is broadcast and every rank enters lrcn_comm_init; its outcome is agreed the same way.
+        Any failure -> ALL ranks use the torch.distributed collectives instead (still RCCL over xGMI, issued from Python)."""
+        ok_local, why = self.ops.comm_probe() if hasattr(self.ops, "comm_probe") else (True, "")
+        uid_bytes = None
+        if ok_local and rank == 0:
+            try:
+                uid_bytes = L.comm_unique_id()
+            except L.LrcnError as e:
+                ok_local, why = False, str(e)
+        ok = torch.tensor([1 if ok_local else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok.item()) == 1:
+            uid = torch.zeros(128, dtype=torch.uint8, device=device)
+            if rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(uid_bytes), dtype=torch.uint8))
+            dist.broadcast(uid, 0, group=group)
+            try:
+                self.ops.comm_init(world, rank, bytes(uid.cpu().numpy().tobytes()))   # the collective: every rank is here
+            except L.LrcnError as e:
+                ok_local, why = False, str(e)
+            ok = torch.tensor([1 if ok_local else 0], dtype=torch.int32, device=device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok.item()) == 0:
+            if hasattr(self.ops, "comm_destroy"):
+                self.ops.comm_destroy()
+            self.backend = "torch"
+            self.backend_note = "C-ABI communicator unavailable (%s)" % (why or "another rank failed")
+            if rank == 0:
+                import sys
+                print("lrcn_amd.dp: %s; using torch.distributed collectives" % self.backend_note, file=sys.stderr)
 
     def _group_slices(self):
         """Flat-buffer ranges of the gradient groups, in the order lossgradient finalises them."""

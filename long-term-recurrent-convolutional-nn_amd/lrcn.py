@@ -112,6 +112,14 @@ class Context:
     def sync(self):
         _lib.check(self._h, _lib.lib().lrcn_sync(self._h))
 
+    def set_option(self, option, value):
+        """lrcn_set_option: _lib.LRCN_OPT_FUSED_UPDATE / LRCN_OPT_DETERMINISTIC / LRCN_OPT_CONV_CHUNK_BYTES (include/lrcn.h)."""
+        self._call("lrcn_set_option", int(option), int(value))
+
+    def params_touched(self):
+        """The caller wrote parameter arrays itself (checkpoint load, clipping ...): required under LRCN_OPT_FUSED_UPDATE."""
+        self._call("lrcn_params_touched")
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             _lib.lib().lrcn_destroy(self._h)
@@ -292,6 +300,16 @@ def comm_unique_id():
     buf = (C.c_char * 128)()
     _lib.check(None, _lib.lib().lrcn_comm_unique_id(buf))
     return bytes(buf)
+
+
+def comm_probe(ctx):
+    """LOCAL check that comm_init can be entered on this rank (librccl loadable, symbols resolved, no communicator yet): lrcn_comm_probe.
+    -> (ok, message)"""
+    try:
+        ctx._call("lrcn_comm_probe")
+        return True, ""
+    except LrcnError as e:
+        return False, str(e)
 
 
 def comm_init(ctx, world, rank, unique_id):

@@ -49,7 +49,16 @@ static orc_model model_of(const lrcn_ctx *c, float *const p[9]) {
 static void sizes_of(const lrcn_ctx *c, int64_t s[9]) { lrcn_param_sizes_n(c->nl, c->cfg.E, c->cfg.H1, c->cfg.H2, c->cfg.V, s); }
 
 /* ---- lifetime / plumbing ---- */
-const char *lrcn_version(void) { return "lrcn-cpu 0.2 (oracle)"; }
+const char *lrcn_version(void) { return "lrcn-cpu 0.3 (oracle)"; }
+int lrcn_abi_version(void) { return LRCN_ABI_VERSION; }
+/* options: the host twin always makes its weights afresh and sums in a fixed order -- every valid option is accepted as a no-op */
+int lrcn_set_option(lrcn_ctx *c, int option, int64_t value) {
+    if (!c) return LRCN_EINVAL;
+    if (option == LRCN_OPT_FUSED_UPDATE || option == LRCN_OPT_DETERMINISTIC) return (value == 0 || value == 1) ? LRCN_OK : LRCN_EINVAL;
+    if (option == LRCN_OPT_CONV_CHUNK_BYTES) return value >= 0 ? LRCN_OK : LRCN_EINVAL;
+    return LRCN_EINVAL;
+}
+int lrcn_params_touched(lrcn_ctx *c) { return c ? LRCN_OK : LRCN_EINVAL; }
 const char *lrcn_last_error(const lrcn_ctx *c) { return c ? c->err : g_create_err; }
 int lrcn_param_sizes_n(int nl, int E, int H1, int H2, int V, int64_t s[9]) {
     if (E < 1 || H1 < 1 || H2 < 2 || (H2 & 1) || V < 3 || !s || (nl != 0 && nl != 1 && nl != 2)) return LRCN_EINVAL;
@@ -211,6 +220,7 @@ int lrcn_train_step(lrcn_ctx *c, float *const p[9], float *const g[9], float *co
 
 /* ---- data parallelism: one host "rank" only ---- */
 int lrcn_comm_unique_id(void *id) { if (!id) return LRCN_EINVAL; memset(id, 0, LRCN_UNIQUE_ID_BYTES); return LRCN_OK; }
+int lrcn_comm_probe(lrcn_ctx *c) { return c ? LRCN_OK : LRCN_EINVAL; }
 int lrcn_comm_init(lrcn_ctx *c, int world, int rank, const void *id) {
     if (!c || !id) return LRCN_EINVAL;
     if (world != 1 || rank != 0) FAIL(c, LRCN_ESTATE, "liblrcn_cpu has no transport: world must be 1");

@@ -12,72 +12,7 @@ import torch.multiprocessing as mp
 from oracle import oracle as orc
 
 
-class OracleOps:
-    def __init__(self, dims):
-        self.dims = dims
-        self._loss = 0.0
-
-    def _model(self, param):
-        E, H1, H2, V = self.dims
-        return orc.Model(E, H1, H2, V, {n: p.numpy() for n, p in zip(orc.PARAM_NAMES, param)})
-
-    def vgg(self, img):
-        raise AssertionError("features are given in this test")
-
-    def lossgradient(self, param, feats, tokens, norm_B, pdrop, seed, grads):
-        val, g = orc.loss(self._model(param), feats.numpy(), tokens, norm_B=norm_B, want_grad=True)
-        self._loss = val
-        for n, t in zip(orc.PARAM_NAMES, grads):
-            t.copy_(torch.as_tensor(g.p[n]))
-
-    def update(self, param, grads, optim):
-        optim.t += 1
-        for p, g, m, v in zip(param, grads, optim.m, optim.v):
-            w, mm, vv = (np.asfortranarray(a.numpy()) for a in (p, m, v))
-            orc.adam(w, np.asfortranarray(g.numpy()), mm, vv, optim.t)
-            p.copy_(torch.as_tensor(w)); m.copy_(torch.as_tensor(mm)); v.copy_(torch.as_tensor(vv))
-
-    def last_loss(self):
-        return self._loss
-
-
-class OracleGroupOps(OracleOps):
-    """The same, plus the CPU stand-ins of what the per-group [all-reduce -> Adam] pipeline needs (dp.py
-    _reduce_and_update_groups / the bucketed _allreduce_async): "streams" are labels, the gradient-ready "events" are already
-    complete (lossgradient is synchronous here), and every call is logged so the test can check the ORDER the trainer drives."""
-
-    def __init__(self, dims):
-        super().__init__(dims)
-        self.log = []
-
-    def make_streams(self, n):
-        self.log.append(("make_streams", n))
-        return ["bucket%d" % k for k in range(n)]
-
-    def stream_ctx(self, stream):
-        import contextlib
-        return contextlib.nullcontext()
-
-    def grad_group_wait(self, group, stream):
-        self.log.append(("wait", group, stream))
-
-    def update_group(self, param, grads, optim, group, stream):
-        from lrcn_amd import dp
-        self.log.append(("adam", group, stream, optim.t))
-        for k in dp.GRAD_GROUPS[group]:
-            w, mm, vv = (np.asfortranarray(a.numpy()) for a in (param[k], optim.m[k], optim.v[k]))
-            orc.adam(w, np.asfortranarray(grads[k].numpy()), mm, vv, optim.t)
-            param[k].copy_(torch.as_tensor(w)); optim.m[k].copy_(torch.as_tensor(mm)); optim.v[k].copy_(torch.as_tensor(vv))
-
-    def join(self, streams):
-        self.log.append(("join", len(streams)))
-
-
-class HostAdam:
-    def __init__(self, param):
-        self.t = 0
-        self.m = [torch.zeros_like(p) for p in param]
-        self.v = [torch.zeros_like(p) for p in param]
+from dp_oracle_ops import HostAdam, OracleGroupOps, OracleOps  # noqa: E402,F401
 
 
 def _worker(rank, world, port, golden, out, mode="plain"):
@@ -92,20 +27,28 @@ def _worker(rank, world, port, golden, out, mode="plain"):
     param = [torch.as_tensor(np.array(z["p_" + n])) for n in orc.PARAM_NAMES]
     Bg = z["feats"].shape[0]
     rows = dp.shard_rows(Bg, world, rank)
-    if mode == "abi_fallback":
-        # the C-ABI communicator cannot be set up (here: on rank 1 only): every rank must agree to fall back to torch.distributed
+    if mode in ("abi_probe_fail", "abi_init_fail"):
+        # the C-ABI communicator cannot be set up: every rank must agree to fall back to torch.distributed, and -- lrcn_comm_init being
+        # a collective (ncclCommInitRank) -- no rank may ENTER it unless every rank's local probe passed (a lone rank would block forever)
         from lrcn_amd import lrcn as L
 
         class FailingAbiOps(OracleOps):
             destroyed = False
+            entered_init = False
 
             def train_step_dp(self, *a, **k):
                 raise AssertionError("the fallback must not take the C-ABI step")
 
+            def comm_probe(self):
+                if mode == "abi_probe_fail" and rank == 1:
+                    return False, "simulated: librccl not loadable"
+                return True, ""
+
             def comm_init(self, world_, rank_, uid):
-                assert len(uid) == 128
-                if rank_ == 1:
-                    raise L.LrcnError("simulated: librccl not loadable")
+                assert mode == "abi_init_fail", "entered the collective although a rank's probe failed: the other ranks would hang"
+                assert len(uid) == 128 and uid == bytes(range(128))
+                self.entered_init = True
+                raise L.LrcnError("simulated: ncclCommInitRank failed on every rank")   # a symmetric failure inside the collective
 
             def comm_destroy(self):
                 self.destroyed = True
@@ -114,7 +57,8 @@ def _worker(rank, world, port, golden, out, mode="plain"):
         ops = FailingAbiOps(dims)
         with mock.patch.object(L, "comm_unique_id", lambda: bytes(range(128))):
             tr = dp.DataParallelTrainer(None, param, HostAdam(param), Bg, world, rank, pdrop=0.0, ops=ops, backend="abi")
-        assert tr.backend == "torch" and ops.destroyed
+        assert tr.backend == "torch" and ops.destroyed and tr.backend_note
+        assert ops.entered_init == (mode == "abi_init_fail")
     else:
         ops = OracleOps(dims) if mode == "plain" else OracleGroupOps(dims)
         tr = dp.DataParallelTrainer(None, param, HostAdam(param), Bg, world, rank, pdrop=0.0, ops=ops)
@@ -144,11 +88,11 @@ def _worker(rank, world, port, golden, out, mode="plain"):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["plain", "group_pipeline", "bucket_one_adam", "abi_fallback"])
+@pytest.mark.parametrize("mode", ["plain", "group_pipeline", "bucket_one_adam", "abi_probe_fail", "abi_init_fail"])
 def test_two_rank_step_equals_full_batch(golden_dir, tmp_path, mode):
     golden = os.path.join(golden_dir, "lstm_mid.npz")
     out = str(tmp_path / "dp.npz")
-    port = 29500 + (os.getpid() % 2000) + {"plain": 0, "group_pipeline": 1, "bucket_one_adam": 2, "abi_fallback": 3}[mode]
+    port = 29500 + (os.getpid() % 2000) + {"plain": 0, "group_pipeline": 1, "bucket_one_adam": 2, "abi_probe_fail": 3, "abi_init_fail": 4}[mode]
     mp.spawn(_worker, args=(2, port, golden, out, mode), nprocs=2, join=True)
     got = np.load(out)
     # single-process reference: two full-batch steps with the oracle
