@@ -393,7 +393,7 @@ int choose_cfg(const GemmArgs &g, int64_t *blocks_out) {
 // Split-K for skinny problems (few output tiles, long K): enough slices to give every CU a workgroup, each slice at
 // least 4 K-steps.  Needs an f32 PLAIN output without ReLU; C is zeroed first unless the call accumulates (beta).
 int choose_splitk(const GemmArgs &g, int64_t blocks) {
-    if (!g.c_f32 || g.out_mode != GEMM_OUT_PLAIN || g.relu || g.a_mode != GEMM_A_PLAIN) return 1;
+    if (!g.c_f32 || g.out_mode != GEMM_OUT_PLAIN || g.relu || g.a_mode != GEMM_A_PLAIN || g.deterministic) return 1;
     if (!g.beta && g.ldc != g.N) return 1;
     if (g.dtype != GEMM_T_BF16) return 1;
     const int kt = g.K / 64;

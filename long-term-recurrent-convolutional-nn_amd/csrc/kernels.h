@@ -21,6 +21,13 @@ void k_embed_gather(hipStream_t st, int dtype, const void *wembT, int64_t ld_w, 
 void k_embed_scatter(hipStream_t st, const float *dxemb, int64_t ld_dx, const int32_t *tok_in, int S, int B, int E,
                      int V, DropSpec d, float *dwembed);
 
+// The same through an E-contiguous staging array stage[V][ld_s] (f32, all zero on entry and on exit): coalesced atomics per token row,
+// then one dense transpose that writes EVERY element of dwembed (no memset needed).  sort_keys != NULL ((T+1)*B <= 8192 keys of scratch):
+// the rows of a token are added in row order by plain stores instead -- a fixed summation order (LRCN_OPT_DETERMINISTIC); false = too
+// many rows for the one-workgroup sort, nothing was launched.
+bool k_embed_scatter_rm(hipStream_t st, const float *dxemb, int64_t ld_dx, const int32_t *tok_in, int S, int B, int E, int V, DropSpec d,
+                        float *stage, int64_t ld_s, float *dwembed, unsigned long long *sort_keys);
+
 // LSTM cell, one timestep (lrcn.jl:531-536).  G f32 [B][4H] = pre-activations incl. bias; c_prev f32 [B][H] or NULL.
 // Writes activated gates [f|i|o|g] (T), c_new (f32), h_new (T) and optionally h_new as f32.
 void k_lstm_fwd(hipStream_t st, int dtype, const float *G, int64_t ld_g, const float *c_prev, int B, int H, void *acts,
@@ -54,8 +61,10 @@ void k_dx2_mask_reduce(hipStream_t st, int dtype, void *dx2, int64_t ld, int S, 
 
 // Row-wise log-softmax + target pick + (optional) dlogits = (softmax - onehot) * scale   (lrcn.jl:562-567 and dual).
 // logits f32 [M][ld_l]; accumulates sum of log p(target) into *logp_sum (double).  dlog (T) may be NULL.
+// logp_rows != NULL (LRCN_OPT_DETERMINISTIC): each row's term goes to logp_rows[m] and one workgroup adds them to *logp_sum in a
+// fixed order, instead of M double atomics.
 void k_softmax_xent(hipStream_t st, int dtype, const float *logits, int64_t ld_l, const int32_t *tgt, int M, int V,
-                    float scale, double *logp_sum, void *dlog, int64_t ld_d);
+                    float scale, double *logp_sum, void *dlog, int64_t ld_d, double *logp_rows = nullptr);
 // prob[v] = exp(logp) for one row each (beam search, lrcn.jl:652).
 void k_softmax_rows(hipStream_t st, const float *logits, int64_t ld_l, int M, int V, float *prob, int64_t ld_p);
 
@@ -103,7 +112,8 @@ void k_bias_act_cast(hipStream_t st, int dtype, const float *in, int64_t ld_in, 
 void k_uncast_rows(hipStream_t st, int dtype, const void *in, int64_t ld_in, int R, int C, float *out, int64_t ld_out);
 
 // db[n] = sum_m Z[m][n]   (Z is T [M][ld]); f32 output, overwritten.
-void k_colsum(hipStream_t st, int dtype, const void *z, int64_t ld, int M, int N, float *out);
+// deterministic: one slab of rows per column block (no atomics between slabs)
+void k_colsum(hipStream_t st, int dtype, const void *z, int64_t ld, int M, int N, float *out, bool deterministic = false);
 // Several T -> T transposes in one launch: dst[c][shift + r] = src[r][c]; columns [0, shift) and [R + shift, ld_dst) of every
 // destination row are written as zeros (K padding of the GEMM that consumes it).  R == 0 zero-fills the C destination rows.
 #define TR_MAX 4

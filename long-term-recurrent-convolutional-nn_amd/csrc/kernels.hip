@@ -81,6 +81,124 @@ __global__ void embed_scatter_kernel(const float *dxemb, int64_t ld_dx, const in
     }
 }
 
+// ---- embedding gradient, E-contiguous form (dual of the gather, lrcn.jl:556/569 under AutoGrad) ----
+// The Wembed gradient of the ABI is V x E column-major (memory [E][V]): a row of dXemb scattered straight into it touches E different
+// cache lines per token (64 lanes -> 64 lines per wave instruction).  Instead: (1) rows are summed per token into a ROW-MAJOR f32
+// staging array stage[V][ld] -- lanes run along e, 256-byte coalesced atomics (or ordered sums, below) -- and (2) one dense transpose
+// writes every element of the column-major gradient (no memset) and puts the zeros back into the staging rows it found non-zero.
+__global__ __launch_bounds__(256) void embed_scatter_rm_kernel(const float *dxemb, int64_t ld_dx, const int32_t *tok_in, int S, int B, int E,
+                                                               DropSpec d, float *stage, int64_t ld_s) {
+    const int m = blockIdx.x;
+    const int s = m / B, b = m - s * B;
+    float *dst = stage + (int64_t)tok_in[m] * ld_s;
+    const float *src = dxemb + (int64_t)m * ld_dx;
+    for (int e = threadIdx.x; e < E; e += blockDim.x) {
+        const float v = src[e] * drop_mult(d, s, b, e, B, E);
+        if (v != 0.0f) atomicAdd(dst + e, v);
+    }
+}
+// LRCN_OPT_DETERMINISTIC: keys (token, row) sorted by ONE workgroup (bitonic network in LDS, n <= 8192 padded to a power of two), so
+// that the rows of a token are consecutive and in row order ...
+__global__ __launch_bounds__(1024) void sort_token_rows_kernel(const int32_t *tok_in, int M, int P2, unsigned long long *keys_out) {
+    extern __shared__ unsigned long long sk[];
+    for (int i = threadIdx.x; i < P2; i += blockDim.x)
+        sk[i] = i < M ? (((unsigned long long)(unsigned)tok_in[i] << 32) | (unsigned)i) : ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= P2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < P2; i += blockDim.x) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const unsigned long long a = sk[i], b = sk[l];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { sk[i] = b; sk[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = threadIdx.x; i < M; i += blockDim.x) keys_out[i] = sk[i];
+}
+// ... and one wave per (segment head, 256-column slice) adds the segment's rows in that order: plain stores, a fixed summation order.
+__global__ __launch_bounds__(64) void embed_segsum_kernel(const float *dxemb, int64_t ld_dx, const unsigned long long *keys, int M, int B, int E,
+                                                          DropSpec d, float *stage, int64_t ld_s) {
+    const int i = blockIdx.x;
+    const unsigned tok = (unsigned)(keys[i] >> 32);
+    if (i > 0 && (unsigned)(keys[i - 1] >> 32) == tok) return;  // not the first row of its token
+    const int e0 = blockIdx.y * 256 + threadIdx.x * 4;
+    if (e0 >= E) return;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int j = i; j < M && (unsigned)(keys[j] >> 32) == tok; ++j) {
+        const int m = (int)(unsigned)keys[j];
+        const int s = m / B, b = m - s * B;
+        const float *src = dxemb + (int64_t)m * ld_dx;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (e0 + k < E) acc[k] += src[e0 + k] * drop_mult(d, s, b, e0 + k, B, E);
+    }
+    float *dst = stage + (int64_t)tok * ld_s;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (e0 + k < E) dst[e0 + k] = acc[k];
+}
+// stage[V][ld_s] (row-major, f32) -> dwembed (V x E column-major: [E][V]); every element of dwembed is written; non-zero staging
+// values are replaced by zeros, so the staging array is all-zero again when the kernel ends.  64 x 64 tiles through LDS.
+__global__ __launch_bounds__(256) void embed_stage_to_grad_kernel(float *stage, int64_t ld_s, int V, int E, float *dwembed) {
+    __shared__ float tile[64][65];
+    const int tv = (V + 63) / 64;
+    const int v0 = (blockIdx.x % tv) * 64, e0 = (blockIdx.x / tv) * 64;
+    const int q = threadIdx.x & 15, rr = threadIdx.x >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int v = v0 + rr + 16 * i, e = e0 + 4 * q;
+        float x[4] = {0.f, 0.f, 0.f, 0.f};
+        if (v < V) {
+            float *src = stage + (int64_t)v * ld_s + e;
+            if (e + 3 < E && (ld_s % 4) == 0) {
+                const float4 f = *reinterpret_cast<const float4 *>(src);
+                x[0] = f.x; x[1] = f.y; x[2] = f.z; x[3] = f.w;
+                if (f.x != 0.f || f.y != 0.f || f.z != 0.f || f.w != 0.f) *reinterpret_cast<float4 *>(src) = make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (e + k < E) {
+                        x[k] = src[k];
+                        if (x[k] != 0.f) src[k] = 0.f;
+                    }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tile[rr + 16 * i][4 * q + k] = x[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = e0 + rr + 16 * i, v = v0 + 4 * q;
+        if (e >= E) continue;
+        float *dst = dwembed + (int64_t)e * V + v;
+        if (v + 3 < V && (V % 4) == 0) {
+            *reinterpret_cast<float4 *>(dst) = make_float4(tile[4 * q][rr + 16 * i], tile[4 * q + 1][rr + 16 * i], tile[4 * q + 2][rr + 16 * i],
+                                                           tile[4 * q + 3][rr + 16 * i]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (v + k < V) dst[k] = tile[4 * q + k][rr + 16 * i];
+        }
+    }
+}
+// LRCN_OPT_DETERMINISTIC: the loss is the sum of the per-row log p(target) taken by one workgroup in a fixed order
+__global__ __launch_bounds__(256) void sum_rows_f64_kernel(const double *rows, int M, double *out) {
+    __shared__ double sh[256];
+    double a = 0.0;
+    for (int i = threadIdx.x; i < M; i += 256) a += rows[i];
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out += sh[0];
+}
+
 template <typename T>
 __global__ void lstm_fwd_kernel(const float *G, int64_t ld_g, const float *c_prev, int B, int H, T *acts, int64_t ld_a,
                                 float *c_new, T *h_new, int64_t ld_h, float *h_new_f32) {
@@ -183,7 +301,7 @@ __device__ __forceinline__ float block_sum(float v, float *sh) {
 
 template <typename T>
 __global__ __launch_bounds__(256) void softmax_xent_kernel(const float *logits, int64_t ld_l, const int32_t *tgt, int M,
-                                                           int V, float scale, double *logp_sum, T *dlog, int64_t ld_d) {
+                                                           int V, float scale, double *logp_sum, T *dlog, int64_t ld_d, double *logp_rows) {
     __shared__ float sh[8];
     const int m = blockIdx.x;
     const float *row = logits + (int64_t)m * ld_l;
@@ -195,7 +313,10 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel(const float *logits, 
     se = block_sum(se, sh);
     const float lse = mx + logf(se);
     const int t = tgt[m];
-    if (threadIdx.x == 0) atomicAdd(logp_sum, (double)(row[t] - lse));
+    if (threadIdx.x == 0) {
+        if (logp_rows) logp_rows[m] = (double)(row[t] - lse);
+        else atomicAdd(logp_sum, (double)(row[t] - lse));
+    }
     if (dlog) {
         T *drow = dlog + (int64_t)m * ld_d;
         for (int v = threadIdx.x; v < V; v += blockDim.x) {
@@ -217,7 +338,7 @@ template <typename T> __device__ __forceinline__ void store4(T *p, const float *
 // two, 16-byte loads; the log-likelihood term is unchanged (x[t] - (max + logf(sum))).
 template <typename T, int Q>
 __global__ __launch_bounds__(256) void softmax_xent_reg_kernel(const float *logits, int64_t ld_l, const int32_t *tgt, int M, int V,
-                                                               float scale, double *logp_sum, T *dlog, int64_t ld_d) {
+                                                               float scale, double *logp_sum, T *dlog, int64_t ld_d, double *logp_rows) {
     __shared__ float sh[8];
     const int m = blockIdx.x;
     const float *row = logits + (int64_t)m * ld_l;  // ld_l % 4 == 0, 16-byte aligned rows
@@ -248,7 +369,10 @@ __global__ __launch_bounds__(256) void softmax_xent_reg_kernel(const float *logi
         }
     se = block_sum(se, sh);
     const int t = tgt[m];
-    if (threadIdx.x == 0) atomicAdd(logp_sum, (double)(row[t] - (mx + logf(se))));
+    if (threadIdx.x == 0) {
+        if (logp_rows) logp_rows[m] = (double)(row[t] - (mx + logf(se)));
+        else atomicAdd(logp_sum, (double)(row[t] - (mx + logf(se))));
+    }
     if (dlog) {
         T *drow = dlog + (int64_t)m * ld_d;
         const float inv = 1.0f / se;
@@ -1070,6 +1194,21 @@ void k_embed_scatter(hipStream_t st, const float *dxemb, int64_t ld_dx, const in
                      DropSpec d, float *dwembed) {
     hipLaunchKernelGGL(embed_scatter_kernel, dim3(S * B), dim3(256), 0, st, dxemb, ld_dx, tok_in, S, B, E, V, d, dwembed);
 }
+bool k_embed_scatter_rm(hipStream_t st, const float *dxemb, int64_t ld_dx, const int32_t *tok_in, int S, int B, int E, int V, DropSpec d,
+                        float *stage, int64_t ld_s, float *dwembed, unsigned long long *sort_keys) {
+    const int M = S * B;
+    if (sort_keys) {  // ordered sums
+        int P2 = 1;
+        while (P2 < M) P2 <<= 1;
+        if (P2 > 8192) return false;
+        hipLaunchKernelGGL(sort_token_rows_kernel, dim3(1), dim3(1024), sizeof(unsigned long long) * (size_t)P2, st, tok_in, M, P2, sort_keys);
+        hipLaunchKernelGGL(embed_segsum_kernel, dim3(M, cdiv(E, 256)), dim3(64), 0, st, dxemb, ld_dx, sort_keys, M, B, E, d, stage, ld_s);
+    } else {
+        hipLaunchKernelGGL(embed_scatter_rm_kernel, dim3(M), dim3(256), 0, st, dxemb, ld_dx, tok_in, S, B, E, d, stage, ld_s);
+    }
+    hipLaunchKernelGGL(embed_stage_to_grad_kernel, dim3(cdiv(V, 64) * cdiv(E, 64)), dim3(256), 0, st, stage, ld_s, V, E, dwembed);
+    return true;
+}
 void k_lstm_fwd(hipStream_t st, int dtype, const float *G, int64_t ld_g, const float *c_prev, int B, int H, void *acts,
                 int64_t ld_a, float *c_new, void *h_new, int64_t ld_h, float *h_new_f32) {
     DISPATCH_T(dtype, hipLaunchKernelGGL(lstm_fwd_kernel<T>, dim3(cdiv(H, 256), B), dim3(256), 0, st, G, ld_g, c_prev, B, H,
@@ -1091,24 +1230,25 @@ void k_dx2_mask_reduce(hipStream_t st, int dtype, void *dx2, int64_t ld, int S, 
                                          nr, d, dxcnn, ld_dxc));
 }
 void k_softmax_xent(hipStream_t st, int dtype, const float *logits, int64_t ld_l, const int32_t *tgt, int M, int V,
-                    float scale, double *logp_sum, void *dlog, int64_t ld_d) {
+                    float scale, double *logp_sum, void *dlog, int64_t ld_d, double *logp_rows) {
     const bool reg = V <= 16384 && (ld_l % 4) == 0 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0 &&
                      (reinterpret_cast<uintptr_t>(dlog) & 15) == 0;
     if (reg) {
         const int q = (V + 1023) / 1024;
 #define SX_LAUNCH(QQ)                                                                                                              \
     DISPATCH_T(dtype, hipLaunchKernelGGL((softmax_xent_reg_kernel<T, QQ>), dim3(M), dim3(256), 0, st, logits, ld_l, tgt, M, V, scale, \
-                                         logp_sum, (T *)dlog, ld_d))
+                                         logp_sum, (T *)dlog, ld_d, logp_rows))
         if (q <= 2) SX_LAUNCH(2);
         else if (q <= 4) SX_LAUNCH(4);
         else if (q <= 8) SX_LAUNCH(8);
         else if (q <= 12) SX_LAUNCH(12);
         else SX_LAUNCH(16);
 #undef SX_LAUNCH
-        return;
+    } else {
+        DISPATCH_T(dtype, hipLaunchKernelGGL(softmax_xent_kernel<T>, dim3(M), dim3(256), 0, st, logits, ld_l, tgt, M, V, scale,
+                                             logp_sum, (T *)dlog, ld_d, logp_rows));
     }
-    DISPATCH_T(dtype, hipLaunchKernelGGL(softmax_xent_kernel<T>, dim3(M), dim3(256), 0, st, logits, ld_l, tgt, M, V, scale,
-                                         logp_sum, (T *)dlog, ld_d));
+    if (logp_rows) hipLaunchKernelGGL(sum_rows_f64_kernel, dim3(1), dim3(256), 0, st, logp_rows, M, logp_sum);
 }
 void k_softmax_rows(hipStream_t st, const float *logits, int64_t ld_l, int M, int V, float *prob, int64_t ld_p) {
     hipLaunchKernelGGL(softmax_rows_kernel, dim3(M), dim3(256), 0, st, logits, ld_l, M, V, prob, ld_p);
@@ -1164,10 +1304,10 @@ void k_uncast_rows(hipStream_t st, int dtype, const void *in, int64_t ld_in, int
     DISPATCH_T(dtype, hipLaunchKernelGGL(uncast_rows_kernel<T>, grid, dim3(256), 0, st, (const T *)in, ld_in, R, C, out,
                                          ld_out));
 }
-void k_colsum(hipStream_t st, int dtype, const void *z, int64_t ld, int M, int N, float *out) {
+void k_colsum(hipStream_t st, int dtype, const void *z, int64_t ld, int M, int N, float *out, bool deterministic) {
     // enough slabs of rows to give the chip ~2 blocks per CU; a single slab needs no zeroing and no atomics
     const int cb = cdiv(N, 64);
-    int slabs = M <= 512 ? 1 : cdiv(512, cb);  // few rows: one pass, no memset launch (the step is launch-bound there)
+    int slabs = (M <= 512 || deterministic) ? 1 : cdiv(512, cb);  // few rows: one pass, no memset launch (the step is launch-bound there)
     if (slabs > cdiv(M, 64)) slabs = cdiv(M, 64);
     if (slabs < 1) slabs = 1;
     const int rows = cdiv(cdiv(M, slabs), 16) * 16;

@@ -69,6 +69,7 @@ struct lrcn_ctx {
     bool shadow_valid = false;              // the current set holds the shadows (direct AND transposed) of the parameters at shadow_p
     const float *shadow_p[9] = {};
     float *dWe_rm = nullptr;                // [V][ldE] f32, all zero between calls: row-major staging of the embedding gradient
+    unsigned long long *sort_keys = nullptr;  // [maxS * maxB] (token, row) keys of the ordered embedding-gradient sums
     double *logp_rows = nullptr;            // [maxS * maxB] per-row log p(target): the ordered loss sum of LRCN_OPT_DETERMINISTIC
     // activations
     int32_t *tok = nullptr, *tok_in = nullptr, *tok_tgt = nullptr;
@@ -230,6 +231,7 @@ int gemm(lrcn_ctx *c, int dtype, const void *A, int64_t lda, const void *B, int6
     g.a_mode = GEMM_A_PLAIN;
     g.out_mode = GEMM_OUT_PLAIN;
     g.zero_page = c->zero_page;
+    g.deterministic = c->opt_det;
     g.ws = on_wg_stream ? c->wg_ws : c->gemm_ws;  // one split-K workspace per stream
     g.ws_bytes = c->gemm_ws_bytes;
     {   // the LSTM GEMMs of a two-stream training step run beside the capped convolution grids (LRCN_BG_ROUTE=0 turns the hint off)
@@ -579,7 +581,8 @@ int loss_impl(lrcn_ctx *c, const float *const p[9], const float *feats, const in
             k_transpose_f32(st, c->Logits + (int64_t)s * B * c->ldV, c->ldV, B, V, logits_out + (int64_t)s * B * V, B);
     }
     const float scale = (float)(1.0 / ((double)norm_B * (double)S));
-    k_softmax_xent(st, dt, c->Logits, c->ldV, c->tok_tgt, M, V, scale, c->logp, bwd ? c->dLog : nullptr, c->ldV);
+    if (c->opt_det && !c->logp_rows) DALLOC(c, c->logp_rows, sizeof(double) * (size_t)c->maxS * c->maxB);
+    k_softmax_xent(st, dt, c->Logits, c->ldV, c->tok_tgt, M, V, scale, c->logp, bwd ? c->dLog : nullptr, c->ldV, c->opt_det ? c->logp_rows : nullptr);
     c->last_norm = norm_B;
     c->last_S = S;
     KCHK(c, "forward");
@@ -619,84 +622,114 @@ int loss_impl(lrcn_ctx *c, const float *const p[9], const float *feats, const in
         int _r = fork();        \
         if (_r) return _r;      \
     } while (0)
+    // Everything from the first fork on runs inside one scope whose every exit -- the normal one and each early error return --
+    // is followed by the join below: an error after a fork must not leave the weight-gradient stream writing the caller's grads[]
+    // (and reading the caller's feats) after the call has returned.
+    auto backward = [&]() -> int {
     // ---- logits layer: dWout, dbout (sw) | dH2 (main) ----
-    FORK();
-    {
-        TrPlan pl{};
-        tr(pl, c->dLog, c->ldV, M, V, c->TA, 0);      // dLog^T [V][ldM]
-        tr(pl, Htop, c->ldH2, M, H2, c->TB, 0);       // H2all^T [H2][ldM]
-        k_transpose_multi(sw, dt, pl);
-    }
-    GEMM(c, dt, c->TA, ldM, c->TB, ldM, grads[7], H2, V, H2, M, nullptr, true, false, false, false, par);
-    k_colsum(sw, dt, c->dLog, c->ldV, M, V, grads[8]);
-    HIPCHK(c, hipEventRecord(c->grad_ev[0], sw));  // group 0: Wout, bout
-    GEMM(c, dt, c->dLog, c->ldV, c->WoT, c->ldV, two ? c->dH2all : c->dH1all, H2, M, H2, V, nullptr, true);
-    if (two) {
-        // ---- LSTM 2 ----
-        r = lstm_layer_bwd(c, S, B, H2, c->ld4H2, c->A2, c->C2, c->dH2all, c->W2hT, c->dZ2);
+        FORK();
+        {
+            TrPlan pl{};
+            tr(pl, c->dLog, c->ldV, M, V, c->TA, 0);      // dLog^T [V][ldM]
+            tr(pl, Htop, c->ldH2, M, H2, c->TB, 0);       // H2all^T [H2][ldM]
+            k_transpose_multi(sw, dt, pl);
+        }
+        GEMM(c, dt, c->TA, ldM, c->TB, ldM, grads[7], H2, V, H2, M, nullptr, true, false, false, false, par);
+        k_colsum(sw, dt, c->dLog, c->ldV, M, V, grads[8], c->opt_det);
+        HIPCHK(c, hipEventRecord(c->grad_ev[0], sw));  // group 0: Wout, bout
+        GEMM(c, dt, c->dLog, c->ldV, c->WoT, c->ldV, two ? c->dH2all : c->dH1all, H2, M, H2, V, nullptr, true);
+        if (two) {
+            // ---- LSTM 2 ----
+            r = lstm_layer_bwd(c, S, B, H2, c->ld4H2, c->A2, c->C2, c->dH2all, c->W2hT, c->dZ2);
+            if (r) return r;
+            FORK();
+            {
+                TrPlan pl{};
+                tr(pl, c->dZ2, c->ld4H2, M, 4 * H2, c->TA, 0);                              // dZ2^T [4H2][ldM]
+                tr(pl, c->X2, c->ldH2, M, H2, c->TB, 0);                                     // X2^T [2h][ldM]
+                tr(pl, c->H2all, c->ldH2, M - B, H2, boff(c->TB, (int64_t)H2 * ldM, es), M > B ? B : 0);  // h2_prev^T (one step later)
+                k_transpose_multi(sw, dt, pl);
+            }
+            GEMM(c, dt, c->TA, ldM, c->TB, ldM, grads[2], 2 * H2, 4 * H2, 2 * H2, M, nullptr, true, false, false, false, par);
+            k_colsum(sw, dt, c->dZ2, c->ld4H2, M, 4 * H2, grads[3], c->opt_det);
+        }
+        HIPCHK(c, hipEventRecord(c->grad_ev[1], sw));  // group 1: W2, b2
+        if (two) {
+            GEMM(c, dt, c->dZ2, c->ld4H2, c->W2xT, c->ld4H2, c->dX2, c->ldH2, M, H2, 4 * H2, nullptr, false);
+            k_dx2_mask_reduce(st, dt, c->dX2, c->ldH2, S, B, h, h, d2, c->dxcnn, c->ldh);
+            // ---- projection and image embedding: dWproj, dWcnn (sw) | dH1 (main) ----
+            FORK();
+            {
+                TrPlan pl{};
+                tr(pl, c->dX2, c->ldH2, M, h, c->TA, 0);      // dP^T [h][ldM]
+                tr(pl, c->H1all, c->ldH1, M, H1, c->TB, 0);   // H1all^T [H1][ldM]
+                k_transpose_multi(sw, dt, pl);
+            }
+            GEMM(c, dt, c->TA, ldM, c->TB, ldM, grads[4], H1, h, H1, M, nullptr, true, false, false, false, par);
+            GEMM(c, dt, c->dX2, c->ldH2, c->WpT, c->ldh, c->dH1all, H1, M, H1, h, nullptr, true);
+            k_transpose(sw, dt, 1, c->dxcnn, c->ldh, B, h, c->dxcT, ldB, 0);     // dxcnn^T [h][ldB]
+            k_cast_rows(sw, dt, feats, B, LRCN_CNNOUT, B, c->FT, ldB);           // feats^T [4096][ldB] (it already is, in memory)
+            GEMM(c, dt, c->dxcT, ldB, c->FT, ldB, grads[5], LRCN_CNNOUT, h, LRCN_CNNOUT, B, nullptr, true, false, false, false, par);
+            HIPCHK(c, hipEventRecord(c->grad_ev[2], sw));  // group 2: Wproj, Wcnn
+        }
+        // ---- LSTM 1 ----
+        r = lstm_layer_bwd(c, S, B, H1, c->ld4H1, c->A1, c->C1, c->dH1all, c->W1hT, c->dZ1);
         if (r) return r;
         FORK();
         {
             TrPlan pl{};
-            tr(pl, c->dZ2, c->ld4H2, M, 4 * H2, c->TA, 0);                              // dZ2^T [4H2][ldM]
-            tr(pl, c->X2, c->ldH2, M, H2, c->TB, 0);                                     // X2^T [2h][ldM]
-            tr(pl, c->H2all, c->ldH2, M - B, H2, boff(c->TB, (int64_t)H2 * ldM, es), M > B ? B : 0);  // h2_prev^T (one step later)
+            tr(pl, c->dZ1, c->ld4H1, M, 4 * H1, c->TA, 0);
+            tr(pl, c->Xemb, c->ldX1, M, X1, c->TB, 0);
+            tr(pl, c->H1all, c->ldH1, M - B, H1, boff(c->TB, (int64_t)X1 * ldM, es), M > B ? B : 0);
             k_transpose_multi(sw, dt, pl);
         }
-        GEMM(c, dt, c->TA, ldM, c->TB, ldM, grads[2], 2 * H2, 4 * H2, 2 * H2, M, nullptr, true, false, false, false, par);
-        k_colsum(sw, dt, c->dZ2, c->ld4H2, M, 4 * H2, grads[3]);
-    }
-    HIPCHK(c, hipEventRecord(c->grad_ev[1], sw));  // group 1: W2, b2
-    if (two) {
-        GEMM(c, dt, c->dZ2, c->ld4H2, c->W2xT, c->ld4H2, c->dX2, c->ldH2, M, H2, 4 * H2, nullptr, false);
-        k_dx2_mask_reduce(st, dt, c->dX2, c->ldH2, S, B, h, h, d2, c->dxcnn, c->ldh);
-        // ---- projection and image embedding: dWproj, dWcnn (sw) | dH1 (main) ----
-        FORK();
+        GEMM(c, dt, c->TA, ldM, c->TB, ldM, grads[0], X1 + H1, 4 * H1, X1 + H1, M, nullptr, true, false, false, false, par);
+        k_colsum(sw, dt, c->dZ1, c->ld4H1, M, 4 * H1, grads[1], c->opt_det);
+        HIPCHK(c, hipEventRecord(c->grad_ev[3], sw));  // group 3: W1, b1
+        GEMM(c, dt, c->dZ1, c->ld4H1, c->W1xT, c->ld4H1, c->dXemb, c->ldX1, M, X1, 4 * H1, nullptr, true);
+        if (!two) {
+            // LRCN-1f: d[embedding | x_cnn] -- mask all E + h columns in place, sum the right h columns over the steps -> d x_cnn,
+            // then the image-embedding gradient exactly as in the two-layer model (on sw, after the dW1 GEMM that shares its scratch)
+            k_dx2_mask_reduce(st, GEMM_T_F32, c->dXemb, c->ldX1, S, B, E, h, d1, c->dxcnn, c->ldh);
+            FORK();
+            k_transpose(sw, dt, 1, c->dxcnn, c->ldh, B, h, c->dxcT, ldB, 0);
+            k_cast_rows(sw, dt, feats, B, LRCN_CNNOUT, B, c->FT, ldB);
+            GEMM(c, dt, c->dxcT, ldB, c->FT, ldB, grads[5], LRCN_CNNOUT, h, LRCN_CNNOUT, B, nullptr, true, false, false, false, par);
+            HIPCHK(c, hipEventRecord(c->grad_ev[2], sw));  // group 2: Wcnn
+        }
         {
-            TrPlan pl{};
-            tr(pl, c->dX2, c->ldH2, M, h, c->TA, 0);      // dP^T [h][ldM]
-            tr(pl, c->H1all, c->ldH1, M, H1, c->TB, 0);   // H1all^T [H1][ldM]
-            k_transpose_multi(sw, dt, pl);
+            // dWembed: per-token sums in an E-contiguous staging array, then one transpose into the column-major gradient (kernels.hip).
+            // LRCN_EMBED_SCATTER=0: the direct scatter (one float atomic per element, 64 cache lines per wave instruction: 99 vs ~25 us).
+            static const char *ks = getenv("LRCN_EMBED_SCATTER");
+            bool done = false;
+            if (!(ks && ks[0] == '0')) {
+                if (!c->dWe_rm) DALLOC(c, c->dWe_rm, sizeof(float) * (size_t)V * c->ldE);
+                unsigned long long *keys = nullptr;
+                if (c->opt_det) {
+                    if (!c->sort_keys) DALLOC(c, c->sort_keys, sizeof(unsigned long long) * (size_t)c->maxS * c->maxB);
+                    keys = c->sort_keys;
+                }
+                done = k_embed_scatter_rm(st, c->dXemb, c->ldX1, c->tok_in, S, B, E, V, two ? d1 : none, c->dWe_rm, c->ldE, grads[6], keys);
+                if (!done && c->opt_det) FAIL(c, LRCN_EINVAL, "LRCN_OPT_DETERMINISTIC supports (T+1)*B <= 8192 rows per call (got %d)", M);
+            }
+            if (!done) {
+                HIPCHK(c, hipMemsetAsync(grads[6], 0, sizeof(float) * (size_t)V * E, st));
+                k_embed_scatter(st, c->dXemb, c->ldX1, c->tok_in, S, B, E, V, two ? d1 : none, grads[6]);
+            }
         }
-        GEMM(c, dt, c->TA, ldM, c->TB, ldM, grads[4], H1, h, H1, M, nullptr, true, false, false, false, par);
-        GEMM(c, dt, c->dX2, c->ldH2, c->WpT, c->ldh, c->dH1all, H1, M, H1, h, nullptr, true);
-        k_transpose(sw, dt, 1, c->dxcnn, c->ldh, B, h, c->dxcT, ldB, 0);     // dxcnn^T [h][ldB]
-        k_cast_rows(sw, dt, feats, B, LRCN_CNNOUT, B, c->FT, ldB);           // feats^T [4096][ldB] (it already is, in memory)
-        GEMM(c, dt, c->dxcT, ldB, c->FT, ldB, grads[5], LRCN_CNNOUT, h, LRCN_CNNOUT, B, nullptr, true, false, false, false, par);
-        HIPCHK(c, hipEventRecord(c->grad_ev[2], sw));  // group 2: Wproj, Wcnn
+        HIPCHK(c, hipEventRecord(c->grad_ev[4], st));  // group 4: Wembed
+        return LRCN_OK;
+    };
+    r = backward();
+    if (par && nfork > 0) {  // join: whatever follows on the main stream (update!, the next call's scratch reuse) comes after the weight gradients
+        const hipError_t e1 = hipEventRecord(c->wg_done, sw);
+        const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(st, c->wg_done, 0) : e1;
+        if (e2 != hipSuccess) {
+            (void)hipStreamSynchronize(sw);  // the event path failed: fall back to a host-side join rather than return unjoined
+            if (!r) FAIL(c, LRCN_EHIP, "joining the weight-gradient stream: %s", hipGetErrorString(e2));
+        }
     }
-    // ---- LSTM 1 ----
-    r = lstm_layer_bwd(c, S, B, H1, c->ld4H1, c->A1, c->C1, c->dH1all, c->W1hT, c->dZ1);
     if (r) return r;
-    FORK();
-    {
-        TrPlan pl{};
-        tr(pl, c->dZ1, c->ld4H1, M, 4 * H1, c->TA, 0);
-        tr(pl, c->Xemb, c->ldX1, M, X1, c->TB, 0);
-        tr(pl, c->H1all, c->ldH1, M - B, H1, boff(c->TB, (int64_t)X1 * ldM, es), M > B ? B : 0);
-        k_transpose_multi(sw, dt, pl);
-    }
-    GEMM(c, dt, c->TA, ldM, c->TB, ldM, grads[0], X1 + H1, 4 * H1, X1 + H1, M, nullptr, true, false, false, false, par);
-    k_colsum(sw, dt, c->dZ1, c->ld4H1, M, 4 * H1, grads[1]);
-    HIPCHK(c, hipEventRecord(c->grad_ev[3], sw));  // group 3: W1, b1
-    GEMM(c, dt, c->dZ1, c->ld4H1, c->W1xT, c->ld4H1, c->dXemb, c->ldX1, M, X1, 4 * H1, nullptr, true);
-    if (!two) {
-        // LRCN-1f: d[embedding | x_cnn] -- mask all E + h columns in place, sum the right h columns over the steps -> d x_cnn,
-        // then the image-embedding gradient exactly as in the two-layer model (on sw, after the dW1 GEMM that shares its scratch)
-        k_dx2_mask_reduce(st, GEMM_T_F32, c->dXemb, c->ldX1, S, B, E, h, d1, c->dxcnn, c->ldh);
-        FORK();
-        k_transpose(sw, dt, 1, c->dxcnn, c->ldh, B, h, c->dxcT, ldB, 0);
-        k_cast_rows(sw, dt, feats, B, LRCN_CNNOUT, B, c->FT, ldB);
-        GEMM(c, dt, c->dxcT, ldB, c->FT, ldB, grads[5], LRCN_CNNOUT, h, LRCN_CNNOUT, B, nullptr, true, false, false, false, par);
-        HIPCHK(c, hipEventRecord(c->grad_ev[2], sw));  // group 2: Wcnn
-    }
-    HIPCHK(c, hipMemsetAsync(grads[6], 0, sizeof(float) * (size_t)V * E, st));
-    k_embed_scatter(st, c->dXemb, c->ldX1, c->tok_in, S, B, E, V, two ? d1 : none, grads[6]);
-    HIPCHK(c, hipEventRecord(c->grad_ev[4], st));  // group 4: Wembed
-    if (par) {  // join: whatever follows on the main stream (update!, the next call's scratch reuse) comes after the weight gradients
-        HIPCHK(c, hipEventRecord(c->wg_done, sw));
-        HIPCHK(c, hipStreamWaitEvent(st, c->wg_done, 0));
-    }
 #undef FORK
     KCHK(c, "backward");
     return LRCN_OK;
@@ -893,6 +926,10 @@ int lrcn_create(const lrcn_config *cfg, lrcn_ctx **out) {
             delete c;
             return LRCN_EHIP;
         }
+    }
+    {   // environment defaults of the options (lrcn_set_option overrides): LRCN_DETERMINISTIC=1
+        const char *kd = getenv("LRCN_DETERMINISTIC");
+        c->opt_det = kd && kd[0] == '1';
     }
     c->dt = cfg->lstm_dtype == LRCN_BF16 ? GEMM_T_BF16 : GEMM_T_F32;
     c->vdt = cfg->vgg_dtype == LRCN_F32 ? GEMM_T_F32 : GEMM_T_BF16;  // LRCN_FP8: bf16 everywhere outside conv2_2..conv5_3

@@ -146,8 +146,13 @@ class DataParallelTrainer:
         self.backend_note = ""
         if backend == "abi" and world > 1:
             self._init_abi_comm(world, rank, group, param[0].device)
-        fused = os.environ.get("LRCN_FUSED_UPDATE", "1")[:1] != "0" and hasattr(self.ops, "set_fused_update")
-        if fused:
+        # LRCN_OPT_FUSED_UPDATE below 256 rows per rank: there the LSTM chain is on the critical path and losing the separate shadow pass
+        # shortens it (emulated rank of 8, 32 rows: 1.549 -> 1.510 ms/step, two same-box pairs).  From 256 rows the chain is hidden behind
+        # the convolutions and the fused kernel -- whose transposes need LDS, which a CU holding a convolution workgroup does not have, so
+        # ALL of the update then queues for the 32 free CUs -- measured 7.19 -> 7.29 ms/step.  LRCN_FUSED_UPDATE=0 / 1 forces it.
+        env = os.environ.get("LRCN_FUSED_UPDATE")
+        fused = (env[:1] != "0") if env else (B_global // max(world, 1) < 256)
+        if fused and hasattr(self.ops, "set_fused_update"):
             self.ops.set_fused_update(True)
         self.flat_grads, self.grads = flat_model_like([tuple(t.shape) for t in param], device=param[0].device)
         self.step_no = 0
