@@ -447,6 +447,7 @@ def main(argv=None):
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_step, "ms_per_step_median": median_ms,
             "ms_per_step_first8": [round(x, 3) for x in step_ms_seq[:8]], "ms_per_step_last": round(step_ms_seq[-1], 3),
+            **({"ms_per_step_all": [round(x, 3) for x in step_ms_seq]} if os.environ.get("LRCN_BENCH_ALL_STEPS") else {}),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": "%s: VGG-16 -> fc7 fwd + %s LSTM "

@@ -247,8 +247,8 @@ int gemm(lrcn_ctx *c, int dtype, const void *A, int64_t lda, const void *B, int6
             g.bg_cus = ncu - c->vgg_wg_cap > 0 ? ncu - c->vgg_wg_cap : 0;
             // ... and the large time-batched GEMMs walk their tiles persistently on that many workgroups instead of queueing hundreds
             // of them: they get the same CUs either way, but no longer take a convolution workgroup's CU at a kernel boundary
-            static const char *kc = getenv("LRCN_BG_CAP");  // workgroups per free CU (0 = uncapped); 2 measured best (1: the LSTM chain
-            const int capmul = kc ? atoi(kc) : 2;           // becomes the critical path, 4+: the convolutions lose what they gained)
+            static const char *kc = getenv("LRCN_BG_CAP");  // workgroups per free CU (0 = uncapped).  Round 3, three same-box rounds of
+            const int capmul = kc ? atoi(kc) : 4;           // 2 / 4 / 6 / 8: 7.56 / 7.44 / 7.45 / 7.48 ms per step (round 2 had 2 ahead)
             if (capmul > 0 && g.bg_cus >= 8) g.wg_cap = g.bg_cus * capmul;
         }
     }
