@@ -1611,9 +1611,11 @@ constexpr int kTileCtrStride = 8 + 2 * 512;  // ints per layer: 8 queue heads + 
 // of whole images whose input stays below the 4 GiB that the direct-to-LDS kernels address with 32-bit offsets (bf16 conv2_2 from
 // 1171 images, conv3_1 from 5349; images are independent, so the cut costs nothing but the tail of one more launch).
 // Without it a larger batch fell through to the register-staged kernel: 2048 images 72.8 ms per forward, 28 k images/s.
-hipError_t launch_conv_chunked(hipStream_t st, const GemmArgs &g0, int N, int es) {
+hipError_t launch_conv_chunked(hipStream_t st, const GemmArgs &g0, int N, int es, int64_t limit_bytes = 0) {
     const int64_t per_img = (int64_t)g0.H * g0.W * g0.Cin * es;
-    const int64_t cap = (0xF0000000ll - (int64_t)(g0.W + 1) * g0.Cin * es) / per_img;
+    // limit_bytes: LRCN_OPT_CONV_CHUNK_BYTES (tests force several chunks at a handful of images; at least one image per launch)
+    int64_t cap = ((limit_bytes > 0 ? limit_bytes : 0xF0000000ll) - (limit_bytes > 0 ? 0 : (int64_t)(g0.W + 1) * g0.Cin * es)) / per_img;
+    if (limit_bytes > 0 && cap < 1) cap = 1;
     if (N <= cap || cap < 1) return launch_gemm(st, g0);
     const int nch = (int)((N + cap - 1) / cap), per = (N + nch - 1) / nch;
     const int64_t out_img = (int64_t)(g0.out_mode == GEMM_OUT_POOL ? (g0.H / 2) * (g0.W / 2) : g0.H * g0.W) * g0.ldc * es;
@@ -1669,7 +1671,7 @@ int conv_layer(lrcn_ctx *c, int dtype, const void *in, const VggLayer &L, int N,
         }
         g.stamps = c->stamps;
     }
-    hipError_t e = launch_conv_chunked(c->stream, g, N, dtype == GEMM_T_BF16 ? 2 : 4);
+    hipError_t e = launch_conv_chunked(c->stream, g, N, dtype == GEMM_T_BF16 ? 2 : 4, c->conv_chunk_bytes);
     if (e != hipSuccess) FAIL(c, LRCN_EHIP, "conv layer S=%d Cin=%d Cout=%d: %s", L.S, L.Cin, L.Cout, hipGetErrorString(e));
     return LRCN_OK;
 }
@@ -1696,7 +1698,7 @@ int conv_layer_fp8(lrcn_ctx *c, const void *in, const VggLayer &L, int N, void *
     g.zero_page = c->zero_page;
     g.wg_cap = c->vgg_wg_cap;
     g.tile_ctr = (c->vgg_wg_cap >= 8 && c->vgg_wg_cap <= 512) ? tile_ctr : nullptr;
-    hipError_t e = launch_conv_chunked(c->stream, g, N, 1);
+    hipError_t e = launch_conv_chunked(c->stream, g, N, 1, c->conv_chunk_bytes);
     if (e != hipSuccess) FAIL(c, LRCN_EHIP, "fp8 conv layer S=%d Cin=%d Cout=%d: %s", L.S, L.Cin, L.Cout, hipGetErrorString(e));
     return LRCN_OK;
 }

@@ -151,3 +151,59 @@ def test_beam_width_one_is_greedy_decoding():
                 alive[n] = False
         tok = nxt
     ctx.close()
+
+
+def test_config5_batched_beam5_at_full_size():
+    """BASELINE configs[4] shape (what tools/caption_bench.py and `bench.py --config c5` time): lrcn_beam_search_batch at E = H = 1000,
+    V = 10640, K = 5, nword 30, bf16, against (1) lrcn_beam_search image by image -- the reference's own control flow (lrcn.jl:644-678), whose
+    step runs on other GEMM routes, so bf16 summation order differs and near-tied beams may legitimately swap: exact agreement is required of
+    most images and every disagreement must be a near-tie in probability -- and (2) itself: the probability it returns must be the product of
+    the softmax probabilities of the tokens it returns, recomputed step by step through lrcn() (lrcn.jl:651-652, 658)."""
+    V, N, K, nword = 10640, 16, 5, 30
+    ctx = L.Context(1000, 1000, 1000, V, max_B=N * K, max_T=1, lstm_dtype=lrcn_amd.LRCN_BF16)
+    param = L.initweights(ctx, seed=7)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    # Freshly initialised weights give near-uniform word distributions: a 31-word product of ~1e-4 underflows float32 (the reference
+    # multiplies probabilities in linear float32 space, lrcn.jl:658) and every beam ties at 0.  Scale the model into a regime with
+    # decisive, state-dependent distributions: active gates, logits of a few units, a peaked word prior with eos near its top.
+    param[6].mul_(50.0)
+    for k in (0, 2, 4, 5):
+        param[k].mul_(5.0)
+    param[7].mul_(16.0)
+    param[8].copy_(torch.randn(param[8].shape, device="cuda", generator=g) * 6.0)
+    param[8][0, L.EOS] = param[8].max() - 1.0
+    feats = (np.random.default_rng(1).standard_normal((N, 4096)) * 0.05).astype(np.float32)
+    batch = L.beam_search_batch(ctx, param, L.to_jl(feats), K, nword)
+    single = [L.beam_search(ctx, param, L.to_jl(feats[n:n + 1]), K, nword) for n in range(N)]
+    same = 0
+    for n in range(N):
+        (tb, pb), (ts, ps) = batch[n], single[n]
+        assert tb[0] == L.BOS and len(tb) <= nword + 2 and pb > 0
+        if tb == ts:
+            same += 1
+            assert abs(pb - ps) <= 3e-2 * ps, (n, pb, ps)
+        else:
+            assert abs(np.log(pb) - np.log(ps)) < 0.2, (n, tb, ts, pb, ps)  # a different path is only acceptable as a near-tie
+    assert same >= (3 * N) // 4, same
+    # (2) self-consistency of (tokens, probability), all images stepped together through lrcn()
+    state = L.initstate(ctx, N)
+    xc = torch.mm(torch.as_tensor(feats).cuda(), param[5])
+    xcnn = L.jl_empty(*xc.shape)
+    xcnn.copy_(xc)
+    logp = np.zeros(N)
+    maxlen = max(len(t) for t, _ in batch)
+    tok = np.full(N, L.BOS, np.int64)
+    for s in range(maxlen - 1):
+        x_lstm = L.jl_empty(N, 1000)
+        x_lstm.copy_(param[6][torch.as_tensor(tok).cuda()])
+        logits = L.from_jl(L.lrcn(ctx, param, state, xcnn, x_lstm)).astype(np.float64)
+        lse = np.log(np.exp(logits - logits.max(axis=1, keepdims=True)).sum(axis=1)) + logits.max(axis=1)
+        for n in range(N):
+            toks = batch[n][0]
+            if s + 1 < len(toks):
+                logp[n] += logits[n, toks[s + 1]] - lse[n]
+                tok[n] = toks[s + 1]
+    for n in range(N):
+        assert abs(logp[n] - np.log(batch[n][1])) < 0.05 + 0.01 * len(batch[n][0]), (n, logp[n], np.log(batch[n][1]))
+    ctx.close()

@@ -1,5 +1,5 @@
 import sys, numpy as np, torch
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import lrcn_amd
 from lrcn_amd import lrcn as L
 N = int(sys.argv[1])
