@@ -77,6 +77,10 @@ struct Conv64Args {
     const bf16_t *w11;
     const float *b11;
     float f8_inv_scale;  // > 0 (non-pool, non-fused kernel only): write OCP e4m3(relu(acc + b) * f8_inv_scale), 8 bytes per lane
+    // kernel development (LRCN_STAMPS=1, tools/conv64_stamps.py): 8 x uint64 per (tile, wave group): shader clock at [0] patch start,
+    // [1] first half-taps done, [2] mid barrier passed, [3] second half-taps done, [4] epilogue (+ producer) done, [5] end barrier passed;
+    // [6] / [7] the 100 MHz wall counter at the end / start.  NULL = off.
+    unsigned long long *stamps;
 };
 
 template <int I, int N, class F> __device__ __forceinline__ void static_for(F &&f) {
@@ -114,7 +118,10 @@ template <bool POOL, bool FUSE> __global__ __launch_bounds__(512) void conv64_ke
 #ifndef CONV64_FUSE_SPLIT
 #define CONV64_FUSE_SPLIT 18
 #endif
-    constexpr int SPLIT = FUSE ? CONV64_FUSE_SPLIT : 9;  // global stores per wave per epilogue (the counted vmcnt below depends on it)
+#ifndef CONV64_SPLIT
+#define CONV64_SPLIT 15  // half-taps before the mid-patch barrier: 9 | 9 left the group that has no epilogue waiting at the barrier (tools/conv64_stamps.py); same-box cycles per patch 9 / 11 / 13 / 15: conv2_1 8072 / 7808 / 7532 / 7224, conv1_2 6856 / 6712 / 6616 / 6464
+#endif
+    constexpr int SPLIT = FUSE ? CONV64_FUSE_SPLIT : CONV64_SPLIT;
     extern __shared__ __attribute__((aligned(128))) unsigned char smem[];  // K-half select is address ^ 64
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -255,6 +262,8 @@ template <bool POOL, bool FUSE> __global__ __launch_bounds__(512) void conv64_ke
             : "v"(rbs[0]), "v"(rbs[1]), "v"(rbs[2]), "v"(rbl[0]), "v"(rbl[1]), "v"(rbl[2]), "v"(wfa), "v"(bba)
             : "memory");
         __builtin_amdgcn_sched_barrier(0);
+        if (a.stamps && (tid & 255) == 0 && tile >= 2 * (int)gridDim.x)  // the patch being multiplied is two walks back (not in the prologue)
+            a.stamps[((size_t)(tile - 2 * (int)gridDim.x) * 2 + wq) * 8 + 7] = __builtin_amdgcn_s_memtime();
         static_for<0, 3>([&](auto sc) {
             constexpr int sl = decltype(sc)::value;
             if (sl < 2 || three) {
@@ -270,10 +279,17 @@ template <bool POOL, bool FUSE> __global__ __launch_bounds__(512) void conv64_ke
                 const int gsw = (((px >> 1) & 3) << 1) | (py & 1);
                 const unsigned pmask = pv ? 0xFFFFFFFFu : 0u;
                 const unsigned wdst = pat + q * 128 + (lqv & 1) * 8;
+                // the four channel blocks of an m-tile: all four MFMAs first (independent), then the conversions -- issued one by one, every
+                // conversion waited out its own MFMA's latency (tools/conv64_stamps.py: 3600 of the producer's 5000 cycles were this chain)
+                f32x4v dd[4];
                 static_for<0, 4>([&](auto nc) {
                     constexpr int nn = decltype(nc)::value;
-                    f32x4v d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[nn]), av,
-                                                                       __builtin_bit_cast(f32x4v, bq[nn]), 0, 0, 0);
+                    dd[nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[nn]), av, __builtin_bit_cast(f32x4v, bq[nn]), 0, 0, 0);
+                });
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<0, 4>([&](auto nc) {
+                    constexpr int nn = decltype(nc)::value;
+                    const f32x4v d = dd[nn];
                     bf16x4 o;
 #pragma unroll
                     for (int r2 = 0; r2 < 4; ++r2) o[r2] = (bf16_t)d[r2];
@@ -326,6 +342,12 @@ template <bool POOL, bool FUSE> __global__ __launch_bounds__(512) void conv64_ke
     for (int j = 0; j < my_tiles; ++j) {
         const int buf = j % 3;
         const unsigned boff = buf * PB;
+        auto stamp = [&](int k) {
+            if (a.stamps && (tid & 255) == 0)
+                a.stamps[((size_t)(b0 + j * G) * 2 + wq) * 8 + k] = (k >= 6 && !FUSE) ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();
+        };
+        if (!FUSE) stamp(7);
+        stamp(0);
         unsigned ar[2][3][2];
 #pragma unroll
         for (int yp = 0; yp < 2; ++yp)
@@ -385,11 +407,23 @@ template <bool POOL, bool FUSE> __global__ __launch_bounds__(512) void conv64_ke
         read_half(std::integral_constant<int, 0>{});
         run_halves(std::integral_constant<int, 0>{}, std::integral_constant<int, SPLIT>{});
         if (!FUSE && wq == 1) wait_vmcnt<NPIECE + NST>();  // retires this wave's pieces of patch j+1
-        __builtin_amdgcn_s_barrier();
+        stamp(1);
+#ifndef CONV64_FUSE_EPI_FIRST
+#define CONV64_FUSE_EPI_FIRST 1
+#endif
+        // FUSE: the mid-patch barrier comes AFTER the epilogue (below) -- a patch is [18 half-taps + epilogue | barrier | producer | barrier]:
+        // the epilogue touches no patch or raw-window buffer (registers -> global), so it may run on either side of the barrier, and the
+        // two sides are then 3450 + 1100 and 4400 cycles instead of 3450 and 5600 (tools/conv64_stamps.py): the groups alternate sides,
+        // so a patch costs twice the longer one
+        if (!(FUSE && CONV64_FUSE_EPI_FIRST)) {
+            __builtin_amdgcn_s_barrier();
+            stamp(2);
+        }
         // ---------------- second half ----------------
         if (!FUSE && wq == 0) issue_patch(tile_at(j + 2), (j + 2) % 3);
         run_halves(std::integral_constant<int, SPLIT>{}, std::integral_constant<int, 18>{});
         if (!FUSE && wq == 0) wait_vmcnt<NPIECE + NST>();
+        if (!FUSE) stamp(3);
 
         // ---------------- epilogue: bias, ReLU, (pool), store ----------------
         {
@@ -479,13 +513,22 @@ template <bool POOL, bool FUSE> __global__ __launch_bounds__(512) void conv64_ke
             }
         }
         if constexpr (FUSE) {
+            stamp(3);
+            if (CONV64_FUSE_EPI_FIRST) {
+                __builtin_amdgcn_s_barrier();
+                stamp(2);
+            }
             // vm-op order of a wave: ... raw(j+3), stores(j), [here], raw(j+4) ...: vmcnt(NST) retires raw window j+3 (used by
             // the NEXT iteration's producer, after this iteration's barrier made every wave's piece visible)
             wait_vmcnt<NST>();
+            stamp(6);
             produce(tile_at(j + 2), (j + 2) % 3, (j + 2) & 3);
             issue_raw(tile_at(j + 4), (j + 4) & 3);
         }
+        stamp(4);
         __builtin_amdgcn_s_barrier();
+        stamp(5);
+        if (!FUSE) stamp(6);
     }
     if (wq == 0) __builtin_amdgcn_s_barrier();  // un-stagger
     wait_vmcnt<0>();
@@ -498,7 +541,7 @@ bool conv64_eligible(int dtype, int Cin, int Cout, int H, int W) {
 }
 
 hipError_t launch_conv64(hipStream_t stream, const void *in, const void *w, const float *bias, void *out, int N, int H, int W, int Cout,
-                         int relu, int pool, const void *zero_page, float f8_inv_scale, int wg_cap) {
+                         int relu, int pool, const void *zero_page, float f8_inv_scale, int wg_cap, unsigned long long *stamps) {
     if (f8_inv_scale > 0.0f && (pool || !relu)) return hipErrorInvalidValue;  // e4m3 output: the non-pool ReLU epilogue only
     if (!conv64_eligible(GEMM_T_BF16, 64, Cout, H, W) || !in || !w || !out || !zero_page || N < 1) return hipErrorInvalidValue;
     if ((int64_t)N * H * W * 64 >= (1ll << 31)) return hipErrorInvalidValue;  // 32-bit element offsets into the input
@@ -510,6 +553,7 @@ hipError_t launch_conv64(hipStream_t stream, const void *in, const void *w, cons
     a.zero_page = zero_page;
     a.N = N; a.H = H; a.W = W; a.Cout = Cout; a.relu = relu;
     a.f8_inv_scale = f8_inv_scale;
+    a.stamps = stamps;
     a.tiles_y = H / 16; a.tiles_x = W / 16; a.ntiles = N * a.tiles_y * a.tiles_x;
     const int chunks = Cout / 64;
     int gx = (wg_cap >= 8 ? wg_cap : 256) / chunks;  // one workgroup per CU (all of LDS); capped: leaves CUs to the other stream
@@ -527,7 +571,7 @@ hipError_t launch_conv64(hipStream_t stream, const void *in, const void *w, cons
 // FUSE note at the top.  w11 = conv1_1 weights [64][32] in
 // the k' order (k_repack_conv11_w_fused), S = crop size (multiple of 16), out = pooled NHWC [N][S/2][S/2][64].
 hipError_t launch_conv64_fused11(hipStream_t stream, const void *img16, const void *w11, const float *b11, const void *w,
-                                 const float *bias, void *out, int N, int S, const void *zero_page, int wg_cap) {
+                                 const float *bias, void *out, int N, int S, const void *zero_page, int wg_cap, unsigned long long *stamps) {
     if (!img16 || !w11 || !b11 || !w || !out || !zero_page || N < 1 || S < 16 || (S % 16)) return hipErrorInvalidValue;
     if ((int64_t)N * S * S * 3 >= (1ll << 31)) return hipErrorInvalidValue;
     Conv64Args a{};
@@ -540,6 +584,7 @@ hipError_t launch_conv64_fused11(hipStream_t stream, const void *img16, const vo
     a.img16 = reinterpret_cast<const bf16_t *>(img16);
     a.w11 = reinterpret_cast<const bf16_t *>(w11);
     a.b11 = b11;
+    a.stamps = stamps;
     int gx = wg_cap >= 8 ? wg_cap : 256;
     if (gx > a.ntiles) gx = a.ntiles;
     static LdsAttrMask attr_done{0};

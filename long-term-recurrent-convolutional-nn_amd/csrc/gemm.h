@@ -94,7 +94,7 @@ hipError_t launch_gemm_skinny(hipStream_t stream, const GemmArgs &g);
 bool conv64_eligible(int dtype, int Cin, int Cout, int H, int W);
 // f8_inv_scale > 0 (ReLU, no pool): the output is OCP e4m3(relu(.) * f8_inv_scale) instead of bf16
 hipError_t launch_conv64(hipStream_t stream, const void *in, const void *w, const float *bias, void *out, int N, int H, int W, int Cout,
-                         int relu, int pool, const void *zero_page, float f8_inv_scale = 0.0f, int wg_cap = 0);
+                         int relu, int pool, const void *zero_page, float f8_inv_scale = 0.0f, int wg_cap = 0, unsigned long long *stamps = nullptr);
 // conv1_1 + conv1_2 (+ pool) fused, from mean-subtracted bf16 crops (conv64.hip FUSE): w11 from k_repack_conv11_w_fused
 hipError_t launch_conv64_fused11(hipStream_t stream, const void *img16, const void *w11, const float *b11, const void *w,
-                                 const float *bias, void *out, int N, int S, const void *zero_page, int wg_cap = 0);
+                                 const float *bias, void *out, int N, int S, const void *zero_page, int wg_cap = 0, unsigned long long *stamps = nullptr);

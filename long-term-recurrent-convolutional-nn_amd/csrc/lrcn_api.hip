@@ -1637,7 +1637,17 @@ int conv_layer(lrcn_ctx *c, int dtype, const void *in, const VggLayer &L, int N,
     if (conv64_enabled() && conv64_eligible(dtype, L.Cin, L.Cout, L.S, L.S)) {
         const bool f8 = f8_inv_scale > 0.0f && !L.pool;
         if (wrote_f8) *wrote_f8 = f8;
-        hipError_t e = launch_conv64(c->stream, in, L.w, L.b, out, N, L.S, L.S, L.Cout, 1, L.pool, c->zero_page, f8 ? f8_inv_scale : 0.0f, c->vgg_wg_cap);
+        unsigned long long *stamps = nullptr;
+        if (getenv("LRCN_STAMPS")) {  // kernel development (tools/conv64_stamps.py): 16 stamps per 16 x 16 tile per 64-channel chunk 0
+            const int64_t need = (int64_t)N * (L.S / 16) * (L.S / 16) * 16;
+            if (need > c->stamps_n) {
+                c->stamps = nullptr;
+                DALLOC(c, c->stamps, sizeof(unsigned long long) * (size_t)need);
+                c->stamps_n = need;
+            }
+            stamps = c->stamps;
+        }
+        hipError_t e = launch_conv64(c->stream, in, L.w, L.b, out, N, L.S, L.S, L.Cout, 1, L.pool, c->zero_page, f8 ? f8_inv_scale : 0.0f, c->vgg_wg_cap, stamps);
         if (e != hipSuccess) FAIL(c, LRCN_EHIP, "conv64 layer S=%d Cout=%d: %s", L.S, L.Cout, hipGetErrorString(e));
         return LRCN_OK;
     }
@@ -1786,8 +1796,18 @@ int vgg_body(lrcn_ctx *c, int N, const void *src, bool src_u8, const float *mean
     }
     int l0 = 1;
     if (fuse11) {  // conv1_1 + conv1_2 + pool1 in one launch, straight from the uint8 crops: actA is never written
+        unsigned long long *stamps = nullptr;
+        if (getenv("LRCN_STAMPS") && getenv("LRCN_STAMPS")[0] == 'f') {  // LRCN_STAMPS=f: stamp the fused conv1 kernel of a VGG forward
+            const int64_t need = (int64_t)N * 14 * 14 * 16;
+            if (need > c->stamps_n) {
+                c->stamps = nullptr;
+                DALLOC(c, c->stamps, sizeof(unsigned long long) * (size_t)need);
+                c->stamps_n = need;
+            }
+            stamps = c->stamps;
+        }
         hipError_t e = launch_conv64_fused11(c->stream, c->img16, c->conv[0].w_fused, c->conv[0].b, c->conv[1].w, c->conv[1].b, nxt, N, 224,
-                                             c->zero_page, c->vgg_wg_cap);
+                                             c->zero_page, c->vgg_wg_cap, stamps);
         if (e != hipSuccess) FAIL(c, LRCN_EHIP, "fused conv1_1+conv1_2: %s", hipGetErrorString(e));
         note(gemm_debug_last_route());
         std::swap(cur, nxt);
