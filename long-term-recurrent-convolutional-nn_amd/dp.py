@@ -163,9 +163,7 @@ class DataParallelTrainer:
             cap = int(env) if env is not None else vgg_wg_cap_for(param[0].device)
             self.ops.set_vgg_wg_cap(cap)
         self._vgg_done = None    # event: the side stream finished the VGG forward whose output is _feats_next
-        self._feats_buf = [None, None, None]  # rotating outputs of the side-stream VGG
-        self._step_end = {}             # step number -> event recorded on the main stream when that step's work has been issued
-        self._decouple = os.environ.get("LRCN_DP_DECOUPLE", "0")[:1] == "1"
+        self._feats_buf = [None, None]  # ping-pong outputs of the side-stream VGG
         self._bucket_streams = None
 
     def _init_abi_comm(self, world, rank, group, device):
@@ -241,17 +239,13 @@ class DataParallelTrainer:
         """Issue VGG(img) on the side stream into a ping-pong buffer; the main stream waits on the event only when it
         consumes the features (next step)."""
         main = torch.cuda.current_stream(self.ctx.device)
-        k = self.step_no % 3 if self._decouple else self.step_no & 1
+        k = self.step_no & 1
         if self._feats_buf[k] is None or self._feats_buf[k].shape[0] != img_u8.shape[0]:
             self._feats_buf[k] = L.jl_empty(img_u8.shape[0], L.CNNOUT)
-        if self._decouple:
-            # three feature buffers: the one written now was last read by the LSTM step three batches back, i.e. two steps before
-            # the one being issued -- the side stream waits for THAT step's end only, not for the step in flight on the main stream
-            ev = self._step_end.pop(self.step_no - 2, None)
-            if ev is not None:
-                self._side.wait_event(ev)
-        else:
-            self._side.wait_stream(main)  # the crops (and the previous consumer of this buffer) are ordered before it
+        # The crops (and the previous consumer of this buffer) are ordered before the forward.  Measured and not kept (round 3): three
+        # rotating buffers with the side stream waiting only for the step TWO back, so that the VGG forward may run a step ahead of the
+        # LSTM chain -- 7.115 / 7.117 -> 7.122 / 7.132 ms per step: both chains are as long as each other at 256 rows, nothing to run ahead of.
+        self._side.wait_stream(main)
         self.ctx.use_stream(self._side)
         try:
             feats = self.ops.vgg(img_u8, feats=self._feats_buf[k])
@@ -266,13 +260,6 @@ class DataParallelTrainer:
         return feats
 
     def step(self, img_u8, tokens, next_img_u8=None, feats=None):
-        self._step_impl(img_u8, tokens, next_img_u8, feats)
-        if self._decouple and self._side is not None:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.ctx.device))
-            self._step_end[self.step_no] = ev
-
-    def _step_impl(self, img_u8, tokens, next_img_u8=None, feats=None):
         """One synchronous-SGD step on this rank's shard.  img_u8: this rank's uint8 crops (or feats given);
         next_img_u8: the NEXT step's crops, whose VGG forward runs beside this step's LSTM work and all-reduce.
         img_u8 is IGNORED when the previous step() prefetched this batch's features through its next_img_u8."""

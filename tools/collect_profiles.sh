@@ -9,14 +9,26 @@ out=$root/gpurun_out/profiles_$tag
 rm -rf "$out"; mkdir -p "$out"
 cd "$root"
 python3 bench.py > "$out/bench_line.json" 2> "$out/bench.err" || { tail "$out/bench.err"; exit 1; }
+# the driver's own shape (5 warm-up + 20 timed steps) and the other BASELINE configs, one line each
+python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > "$out/bench_line_driver_shape.json" 2>> "$out/bench.err"
+python3 bench.py --emulate-world 8 --steps 100 --warmup 20 --no-cpu-baseline > "$out/bench_line_emulated_rank_of_8.json" 2>> "$out/bench.err"
+python3 bench.py --config c2 --no-cpu-baseline > "$out/bench_line_c2.json" 2>> "$out/bench.err"
+python3 bench.py --config c3 --no-cpu-baseline > "$out/bench_line_c3.json" 2>> "$out/bench.err"
+python3 bench.py --config c5 > "$out/bench_line_c5.json" 2>> "$out/bench.err"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o p -- python3 "$root/bench.py" --steps 25 --warmup 5 --no-cpu-baseline > "$out/bench_under_rocprof.json" 2> "$out/stats.log"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/fetch" -o p -- python3 "$root/bench.py" --steps 8 --warmup 2 --no-cpu-baseline > /dev/null 2> "$out/fetch.log"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/write" -o p -- python3 "$root/bench.py" --steps 8 --warmup 2 --no-cpu-baseline > /dev/null 2> "$out/write.log"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats32" -o p -- python3 "$root/bench.py" --emulate-world 8 --steps 50 --warmup 10 --no-cpu-baseline > "$out/bench_under_rocprof_b32.json" 2> "$out/stats32.log"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/statsc2" -o p -- python3 "$root/bench.py" --config c2 --steps 20 --warmup 5 --no-cpu-baseline > "$out/bench_under_rocprof_c2.json" 2> "$out/statsc2.log"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/statsc5" -o p -- python3 "$root/bench.py" --config c5 --steps 30 > "$out/bench_under_rocprof_c5.json" 2> "$out/statsc5.log"
 cd "$root"
 cp "$out"/stats/p_kernel_stats.csv "$out/kernel_stats.csv"
+cp "$out"/stats32/p_kernel_stats.csv "$out/kernel_stats_b32.csv"
+cp "$out"/statsc2/p_kernel_stats.csv "$out/kernel_stats_c2.csv"
+cp "$out"/statsc5/p_kernel_stats.csv "$out/kernel_stats_c5.csv"
 python3 tools/pmc_traffic.py "$out"/fetch/p_counter_collection.csv "$out"/write/p_counter_collection.csv "$out/pmc_traffic.json" > /dev/null
-rm -rf "$out/stats" "$out/fetch" "$out/write"   # the raw traces are tens of MB; the summaries are what is kept
+rm -rf "$out/stats" "$out/stats32" "$out/statsc2" "$out/statsc5" "$out/fetch" "$out/write"   # the raw traces are tens of MB; the summaries are what is kept
 tail -c 1200 "$out/bench_line.json"; echo; python3 - <<PY
 import csv
 rows=list(csv.DictReader(open("$out/kernel_stats.csv")))

@@ -51,6 +51,11 @@ def main():
     res["per_kernel"] = {k[:90]: {"n": len(fe[k]), "fetch_kib_avg": sum(fe[k]) / len(fe[k]),
                                   "write_kib_avg": sum(wr.get(k, [0])) / max(1, len(wr.get(k, [0])))}
                          for k in sorted(fe, key=lambda k: -sum(fe[k]))[:16]}
+    # bench.py quotes this file only while the kernel sources are the ones it was measured on (the number went stale silently)
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    res["csrc_digest"] = bench.csrc_digest()
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps({k: v for k, v in res.items() if k != "per_kernel"}, indent=1))
 
