@@ -57,12 +57,14 @@ constexpr int LDS_BYTES = BIAS_OFF + 64 * 4;
 // FUSE layout: 21 m-tiles (336 pixel rows) per patch, 4 raw-window buffers, conv1_1 weights and both bias vectors
 constexpr int F_PATCH = 21 * 2048;
 constexpr int F_RAW_OFF = 3 * F_PATCH;
-constexpr int F_RAW = 4096;  // 24 window rows (20 real) at a pitch of F_RAW_ROW bytes, 120 used per row
-constexpr int F_RAW_ROW = 144;
+constexpr int F_RAW_ROW = 144;                // pitch of a window row (128 bytes written, 120 + 2 read back)
+constexpr int F_RAWB = 24 * F_RAW_ROW;        // the second copy of the window, shifted by one element (see issue_raw)
+constexpr int F_RAW = 2 * F_RAWB;             // 24 window rows (20 real) x 2 copies per raw buffer
 constexpr int F_W11_OFF = F_RAW_OFF + 4 * F_RAW;
 constexpr int F_B11_OFF = F_W11_OFF + 64 * 64;
 constexpr int F_BIAS_OFF = F_B11_OFF + 256;
 constexpr int F_LDS_BYTES = F_BIAS_OFF + 256;
+static_assert(F_LDS_BYTES <= 160 * 1024, "the fused kernel's LDS image must fit the 160 KiB of a gfx950 CU");
 
 struct Conv64Args {
     const bf16_t *in;   // NHWC [N][H][W][64]
@@ -72,7 +74,8 @@ struct Conv64Args {
     const void *zero_page;
     int N, H, W, Cout, relu;
     int tiles_y, tiles_x, ntiles;
-    // FUSE only: mean-subtracted crops img16[n][row = x][col = y][3] bf16 (H = W = S), conv1_1 weights [64][32] in k' order, bias
+    // FUSE only: mean-subtracted crops in a 2-pixel zero frame img16[n][S + 4][S + 4][3] bf16 (k_img_u8_to_bf16; [x + 2][y + 2] = pixel
+    // (row x, col y)), conv1_1 weights [64][32] in k' order, bias
     const bf16_t *img16;
     const bf16_t *w11;
     const float *b11;
@@ -189,28 +192,33 @@ template <bool POOL, bool FUSE> __global__ __launch_bounds__(512) void conv64_ke
 
     // ================= FUSE: raw-window DMA and the conv1_1 patch producer =================
     auto issue_raw = [&](int tile, int rbuf) {
-        // three 128-byte DMAs per wave, lanes 0..31 only: window row wrow = wave + 8 k (rows 20..23 are dummies that keep the
-        // per-wave count uniform); lane i < 30 -> dword i of the row; the window starts at element (16 ty - 2) * 3 of image row
-        // 16 tx - 2 + wrow: dword-aligned, and so is every pixel edge.  LDS rows are F_RAW_ROW = 144 bytes apart: the producer's 16
-        // lanes of a group read 16 CONSECUTIVE window rows at one byte offset, and 16 x 144 B covers all sixteen 16-byte bank
-        // slots of the 256-byte LDS line once (at the former 128-byte pitch they fell on two: SQ_LDS_BANK_CONFLICT was 39 % of the
-        // kernel's LDS cycles, profiles/r02_pmc_sq_counters_conv64.json).
+        // six 128-byte DMAs per wave, lanes 0..31 only, one dword per lane: window row wrow = wave + 8 k (rows 20..23 are dummies that
+        // keep the per-wave count uniform), each row TWICE: copy A = elements [E, E + 64) of the framed image row, copy B = [E + 1, E + 65),
+        // i.e. the same data shifted by one bf16.  A pixel's 9-value run starts at element 3 py: on a dword boundary in copy A for even
+        // py, in copy B for odd py -- so the producer reads it with ds_read2_b32 (4-byte alignment) instead of a 2-byte-aligned
+        // ds_read_b128, which the LDS executes as a slow unaligned access: that cost 450 of the producer's 1330 read cycles AND 530
+        // cycles of the partner wave's MFMA phase, whose fragment reads queue behind it (tools/conv64_stamps.py, round 3).
+        // The crops carry a 2-pixel zero frame (k_img_u8_to_bf16), so conv1_1's zero padding is read as data: no in-image tests, and
+        // no dword of either copy straddles the image edge.  Only elements < E + 61 are ever read back.
+        // LDS rows are F_RAW_ROW = 144 bytes apart: the producer's 16 lanes of a group read 16 CONSECUTIVE window rows at one byte
+        // offset, and 16 x 144 B covers all sixteen 16-byte bank slots of the 256-byte LDS line once.
         const bool live = tile >= 0;
         const int t = live ? tile : 0;
         const int per_img = a.tiles_y * a.tiles_x;
         const int n = t / per_img, r = t - n * per_img;
         const int ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
-        const int S = H;
-        const int i = lane;
-        const int e0 = (16 * ty - 2) * 3 + 2 * i;  // first of the lane's two elements inside the image row
+        const int SP = H + 4;
         if (lane < 32) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const int wrow = wave + 8 * k;
-                const int xr = 16 * tx - 2 + wrow;
-                const bool ok = live && i < 30 && wrow < 20 && (unsigned)xr < (unsigned)S && e0 >= 0 && e0 + 2 <= 3 * S;
-                const bf16_t *src = ok ? a.img16 + ((size_t)(n * S + xr) * S * 3 + e0) : reinterpret_cast<const bf16_t *>(a.zero_page);
-                __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(smem + F_RAW_OFF + rbuf * F_RAW + wrow * F_RAW_ROW), 4, 0, 0);
+                const bool ok = live && wrow < 20;
+                // image row 16 tx - 2 + wrow = framed row 16 tx + wrow; image column 16 ty - 2 = framed column 16 ty
+                const bf16_t *srcA = a.img16 + (((size_t)(n * SP + 16 * tx + wrow) * SP + 16 * ty) * 3 + 2 * lane);
+                const bf16_t *z = reinterpret_cast<const bf16_t *>(a.zero_page);
+                __builtin_amdgcn_global_load_lds((glb_void *)(ok ? srcA : z), (lds_void *)(smem + F_RAW_OFF + rbuf * F_RAW + wrow * F_RAW_ROW), 4, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_void *)(ok ? srcA + 1 : z), (lds_void *)(smem + F_RAW_OFF + rbuf * F_RAW + F_RAWB + wrow * F_RAW_ROW),
+                                                 4, 0, 0);
             }
         }
     };
@@ -236,7 +244,8 @@ template <bool POOL, bool FUSE> __global__ __launch_bounds__(512) void conv64_ke
         // (With separate statements it folded `phi(n9, 0) << 16` into the block that issues the read and consumed the
         // register before the data had landed.)  Waves 5..7 own two m-tiles; their third read set hits in-bounds garbage.
         const bool three = wave + 16 < 21;  // wave-uniform
-        uint4 run[3], wf[4], bq[4];
+        uint2 runl[3], runh[3];
+        uint4 wf[4], bq[4];
         unsigned n9[3][3];
         int qv[3];
         unsigned rbs[3], rbl[3];
@@ -245,21 +254,25 @@ template <bool POOL, bool FUSE> __global__ __launch_bounds__(512) void conv64_ke
             const int q = (wave + 8 * sl) * 16 + l15v;
             const int py = q / 18, px = q - 18 * py;
             qv[sl] = q;
-            // run kw of pixel (py, px): window row px + kw, 9 bf16 from byte 6 py  (2-byte aligned 16-byte read: replayed, correct)
-            rbl[sl] = raw + px * F_RAW_ROW + 6 * py;
-            rbs[sl] = rbl[sl] + lsel * F_RAW_ROW;
+            // run kw of pixel (py, px): window row px + kw, 9 bf16 from byte 6 py of copy A = byte 6 py - 2 of copy B
+            rbl[sl] = raw + px * F_RAW_ROW + 6 * py;                                    // copy A, 2-byte aligned: the ds_read_u16 of the 9th values
+            rbs[sl] = rbl[sl] + lsel * F_RAW_ROW + ((py & 1) ? F_RAWB - 2 : 0);          // dword-aligned start of the run's first 8 values
         }
         asm volatile(
-            "ds_read_b128 %0, %20\n\tds_read_u16 %3, %23 offset:16\n\tds_read_u16 %4, %23 offset:160\n\tds_read_u16 %5, %23 offset:304\n\t"
-            "ds_read_b128 %1, %21\n\tds_read_u16 %6, %24 offset:16\n\tds_read_u16 %7, %24 offset:160\n\tds_read_u16 %8, %24 offset:304\n\t"
-            "ds_read_b128 %2, %22\n\tds_read_u16 %9, %25 offset:16\n\tds_read_u16 %10, %25 offset:160\n\tds_read_u16 %11, %25 offset:304\n\t"
-            "ds_read_b128 %12, %26\n\tds_read_b128 %13, %26 offset:1024\n\tds_read_b128 %14, %26 offset:2048\n\tds_read_b128 %15, %26 offset:3072\n\t"
-            "ds_read_b128 %16, %27\n\tds_read_b128 %17, %27 offset:64\n\tds_read_b128 %18, %27 offset:128\n\tds_read_b128 %19, %27 offset:192\n\t"
+            "ds_read2_b32 %[l0], %[s0] offset1:1\n\tds_read2_b32 %[h0], %[s0] offset0:2 offset1:3\n\t"
+            "ds_read_u16 %[a0], %[b0] offset:16\n\tds_read_u16 %[a1], %[b0] offset:160\n\tds_read_u16 %[a2], %[b0] offset:304\n\t"
+            "ds_read2_b32 %[l1], %[s1] offset1:1\n\tds_read2_b32 %[h1], %[s1] offset0:2 offset1:3\n\t"
+            "ds_read_u16 %[c0], %[b1] offset:16\n\tds_read_u16 %[c1], %[b1] offset:160\n\tds_read_u16 %[c2], %[b1] offset:304\n\t"
+            "ds_read2_b32 %[l2], %[s2] offset1:1\n\tds_read2_b32 %[h2], %[s2] offset0:2 offset1:3\n\t"
+            "ds_read_u16 %[d0], %[b2] offset:16\n\tds_read_u16 %[d1], %[b2] offset:160\n\tds_read_u16 %[d2], %[b2] offset:304\n\t"
+            "ds_read_b128 %[w0], %[wa]\n\tds_read_b128 %[w1], %[wa] offset:1024\n\tds_read_b128 %[w2], %[wa] offset:2048\n\tds_read_b128 %[w3], %[wa] offset:3072\n\t"
+            "ds_read_b128 %[q0], %[ba]\n\tds_read_b128 %[q1], %[ba] offset:64\n\tds_read_b128 %[q2], %[ba] offset:128\n\tds_read_b128 %[q3], %[ba] offset:192\n\t"
             "s_waitcnt lgkmcnt(0)"
-            : "=&v"(run[0]), "=&v"(run[1]), "=&v"(run[2]), "=&v"(n9[0][0]), "=&v"(n9[0][1]), "=&v"(n9[0][2]), "=&v"(n9[1][0]),
-              "=&v"(n9[1][1]), "=&v"(n9[1][2]), "=&v"(n9[2][0]), "=&v"(n9[2][1]), "=&v"(n9[2][2]), "=&v"(wf[0]), "=&v"(wf[1]),
-              "=&v"(wf[2]), "=&v"(wf[3]), "=&v"(bq[0]), "=&v"(bq[1]), "=&v"(bq[2]), "=&v"(bq[3])
-            : "v"(rbs[0]), "v"(rbs[1]), "v"(rbs[2]), "v"(rbl[0]), "v"(rbl[1]), "v"(rbl[2]), "v"(wfa), "v"(bba)
+            : [l0] "=&v"(runl[0]), [h0] "=&v"(runh[0]), [l1] "=&v"(runl[1]), [h1] "=&v"(runh[1]), [l2] "=&v"(runl[2]), [h2] "=&v"(runh[2]),
+              [a0] "=&v"(n9[0][0]), [a1] "=&v"(n9[0][1]), [a2] "=&v"(n9[0][2]), [c0] "=&v"(n9[1][0]), [c1] "=&v"(n9[1][1]), [c2] "=&v"(n9[1][2]),
+              [d0] "=&v"(n9[2][0]), [d1] "=&v"(n9[2][1]), [d2] "=&v"(n9[2][2]), [w0] "=&v"(wf[0]), [w1] "=&v"(wf[1]), [w2] "=&v"(wf[2]),
+              [w3] "=&v"(wf[3]), [q0] "=&v"(bq[0]), [q1] "=&v"(bq[1]), [q2] "=&v"(bq[2]), [q3] "=&v"(bq[3])
+            : [s0] "v"(rbs[0]), [s1] "v"(rbs[1]), [s2] "v"(rbs[2]), [b0] "v"(rbl[0]), [b1] "v"(rbl[1]), [b2] "v"(rbl[2]), [wa] "v"(wfa), [ba] "v"(bba)
             : "memory");
         __builtin_amdgcn_sched_barrier(0);
         if (a.stamps && (tid & 255) == 0 && tile >= 2 * (int)gridDim.x)  // the patch being multiplied is two walks back (not in the prologue)
@@ -271,10 +284,10 @@ template <bool POOL, bool FUSE> __global__ __launch_bounds__(512) void conv64_ke
                 const int py = q / 18, px = q - 18 * py;
                 const bool pv = (q < 324) & ((unsigned)(16 * ty - 1 + py) < (unsigned)S) & ((unsigned)(16 * tx - 1 + px) < (unsigned)S);
                 uint4 afr;
-                afr.x = last ? (n9[sl][0] | (n9[sl][1] << 16)) : run[sl].x;
-                afr.y = last ? n9[sl][2] : run[sl].y;
-                afr.z = last ? 0u : run[sl].z;
-                afr.w = last ? 0u : run[sl].w;
+                afr.x = last ? (n9[sl][0] | (n9[sl][1] << 16)) : runl[sl].x;
+                afr.y = last ? n9[sl][2] : runl[sl].y;
+                afr.z = last ? 0u : runh[sl].x;
+                afr.w = last ? 0u : runh[sl].y;
                 const bf16x8 av = __builtin_bit_cast(bf16x8, afr);
                 const int gsw = (((px >> 1) & 3) << 1) | (py & 1);
                 const unsigned pmask = pv ? 0xFFFFFFFFu : 0u;
@@ -573,7 +586,7 @@ hipError_t launch_conv64(hipStream_t stream, const void *in, const void *w, cons
 hipError_t launch_conv64_fused11(hipStream_t stream, const void *img16, const void *w11, const float *b11, const void *w,
                                  const float *bias, void *out, int N, int S, const void *zero_page, int wg_cap, unsigned long long *stamps) {
     if (!img16 || !w11 || !b11 || !w || !out || !zero_page || N < 1 || S < 16 || (S % 16)) return hipErrorInvalidValue;
-    if ((int64_t)N * S * S * 3 >= (1ll << 31)) return hipErrorInvalidValue;
+    if ((int64_t)N * (S + 4) * (S + 4) * 3 >= (1ll << 31)) return hipErrorInvalidValue;
     Conv64Args a{};
     a.w = reinterpret_cast<const bf16_t *>(w);
     a.bias = bias;

@@ -147,7 +147,9 @@ void k_fill(hipStream_t st, float *w, int64_t n, float v);
 void k_repack_conv_w(hipStream_t st, int dtype, const float *w, int Cin, int Cout, int Cin_pad, void *out);
 // conv1_1 weight -> [64][ld] T with k = tap*3 + c (27 real, rest zero)
 void k_repack_conv11_w(hipStream_t st, int dtype, const float *w, int Cout, void *out, int64_t ld);
-// out[i] = (bf16)(img[i] - mean[i % 3]) over n = N*S*S*3 bytes: the crop, mean-subtracted, in its own layout (input of conv64 FUSE)
+// out = (bf16)(img - mean[c]) over n = N*S*S*3 bytes, written INSIDE A FRAME of 2 zero pixels: out[n][S+4][S+4][3], pixel (x, y) of the crop at
+// [x+2][y+2]; the frame is never written (the buffer is zero since allocation) -- the input of conv64 FUSE, whose raw-window DMA reads
+// conv1_1's zero padding from it.  Needs (N*(S+4)*(S+4)*3 + 8) elements.
 // avg != NULL: subtract the full averageImage (S,S,3) column-major, avg(col, row, c) from pixel (row, col, c) (lrcn.jl:770-771), instead
 void k_img_u8_to_bf16(hipStream_t st, const uint8_t *img, int64_t n, float m0, float m1, float m2, const float *avg, int S, void *out);
 // batched resize + centre crop + grey -> RGB of variable-size decoded uint8 images (lrcn.jl:755-765): meta = device array of

@@ -731,16 +731,28 @@ __device__ __forceinline__ float avg_at(const float *avg, int64_t i, int S) {
     const int q = (int)(px % S), r = (int)((px / S) % S);
     return avg[q + (int64_t)S * r + (int64_t)S * S * c];
 }
+// PAD = 2: the output is the crop inside a frame of PAD zero pixels on every side, out[n][S + 2 PAD][S + 2 PAD][3] (the frame is zero
+// since allocation and never written): conv64.hip's raw-window DMA then reads conv1_1's zero padding as DATA -- no per-lane in-image tests,
+// and a dword of the window never straddles the image edge (its element-shifted second copy needs that).
+template <int PAD>
 __global__ void img_u8_to_bf16_kernel(const uint8_t *img, int64_t n, float m0, float m1, float m2, const float *avg, int S, bf16_t *out) {
-    // 12 bytes (4 pixels) per thread: channel phase is the same for every thread
+    // 12 bytes (4 pixels) per thread: channel phase is the same for every thread; S % 4 == 0, so the four pixels share an image row
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t i0 = t * 12;
     if (i0 >= n) return;
+    const int SP = S + 2 * PAD;
+    auto opix = [&](int64_t pix) {  // flat pixel index (n, x, y) -> pixel index in the framed output
+        const int64_t row = pix / S;           // n * S + x
+        const int y = (int)(pix - row * S);
+        const int64_t nn = row / S;
+        const int x = (int)(row - nn * S);
+        return ((nn * SP + x + PAD) * SP + y + PAD);
+    };
     if (avg) {
-        for (int64_t i = i0; i < n && i < i0 + 12; ++i) out[i] = (bf16_t)((float)img[i] - avg_at(avg, i, S));
+        for (int64_t i = i0; i < n && i < i0 + 12; ++i) out[opix(i / 3) * 3 + i % 3] = (bf16_t)((float)img[i] - avg_at(avg, i, S));
         return;
     }
-    if (i0 + 12 <= n) {
+    if (i0 + 12 <= n && (S & 3) == 0) {
         const uint32_t *p = reinterpret_cast<const uint32_t *>(img + i0);
         const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
         const float mean[3] = {m0, m1, m2};
@@ -750,11 +762,14 @@ __global__ void img_u8_to_bf16_kernel(const uint8_t *img, int64_t n, float m0, f
             const uint32_t w = k < 4 ? w0 : (k < 8 ? w1 : w2);
             o[k] = (bf16_t)((float)((w >> (8 * (k & 3))) & 0xFFu) - mean[k % 3]);
         }
-        uint2 *q = reinterpret_cast<uint2 *>(out + i0);
-        const uint2 *ov = reinterpret_cast<const uint2 *>(o);
-        q[0] = ov[0]; q[1] = ov[1]; q[2] = ov[2];
+        // 24 bytes at a 4-byte-aligned address (the framed pixel index of a thread's first pixel is even)
+        uint32_t *q = reinterpret_cast<uint32_t *>(out + opix(i0 / 3) * 3);
+        const uint32_t *ov = reinterpret_cast<const uint32_t *>(o);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) q[k] = ov[k];
     } else {
-        for (int64_t i = i0; i < n; ++i) out[i] = (bf16_t)((float)img[i] - (i % 3 == 0 ? m0 : (i % 3 == 1 ? m1 : m2)));
+        for (int64_t i = i0; i < n && i < i0 + 12; ++i)
+            out[opix(i / 3) * 3 + i % 3] = (bf16_t)((float)img[i] - (i % 3 == 0 ? m0 : (i % 3 == 1 ? m1 : m2)));
     }
 }
 // conv1_1 weights for the fused conv1_1+conv1_2 kernel (conv64.hip FUSE): out[co][k'], k' = 8 lq + j:
@@ -1344,7 +1359,7 @@ void k_repack_conv11_w(hipStream_t st, int dtype, const float *w, int Cout, void
 }
 void k_img_u8_to_bf16(hipStream_t st, const uint8_t *img, int64_t n, float m0, float m1, float m2, const float *avg, int S, void *out) {
     const int64_t threads = (n + 11) / 12;
-    hipLaunchKernelGGL(img_u8_to_bf16_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, img, n, m0, m1, m2, avg, S,
+    hipLaunchKernelGGL(img_u8_to_bf16_kernel<2>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, img, n, m0, m1, m2, avg, S,
                        (bf16_t *)out);
 }
 void k_resize_crop_u8(hipStream_t st, const uint8_t *src, const void *meta, int N, int S, uint8_t *out) {

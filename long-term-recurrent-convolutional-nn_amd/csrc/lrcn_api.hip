@@ -1016,7 +1016,7 @@ int lrcn_create(const lrcn_config *cfg, lrcn_ctx **out) {
             const size_t ve = c->vesz;
             if (c->vdt != GEMM_T_BF16) DALLOC(c, c->im2col, ve * N * 224 * 224 * 32);  // bf16 fuses conv1_1's im2col
             DALLOC(c, c->actA, ve * N * 224 * 224 * 64);
-            if (c->vdt == GEMM_T_BF16) DALLOC(c, c->img16, 2 * N * 224 * 224 * 3);  // mean-subtracted crops for the fused conv1_1+conv1_2
+            if (c->vdt == GEMM_T_BF16) DALLOC(c, c->img16, 2 * (N * 228 * 228 * 3 + 8));  // mean-subtracted crops in a 2-pixel zero frame (fused conv1_1+conv1_2)
             DALLOC(c, c->actB, ve * N * 112 * 112 * 128);  // largest tensor ever written to the second buffer (pool1 out = N*112*112*64; conv2_1 out = N*112*112*128)
             DALLOC(c, c->f6, ve * N * 4096);
             DALLOC(c, c->featsRM, sizeof(float) * N * 4096);
