@@ -294,24 +294,29 @@ template <bool POOL, bool FUSE> __global__ __launch_bounds__(512) void conv64_ke
                 const unsigned wdst = pat + q * 128 + (lqv & 1) * 8;
                 // the four channel blocks of an m-tile: all four MFMAs first (independent), then the conversions -- issued one by one, every
                 // conversion waited out its own MFMA's latency (tools/conv64_stamps.py: 3600 of the producer's 5000 cycles were this chain)
-                f32x4v dd[4];
-                static_for<0, 4>([&](auto nc) {
-                    constexpr int nn = decltype(nc)::value;
-                    dd[nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[nn]), av, __builtin_bit_cast(f32x4v, bq[nn]), 0, 0, 0);
-                });
+                const f32x4v d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[0]), av, __builtin_bit_cast(f32x4v, bq[0]), 0, 0, 0);
+                const f32x4v d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[1]), av, __builtin_bit_cast(f32x4v, bq[1]), 0, 0, 0);
+                const f32x4v d2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[2]), av, __builtin_bit_cast(f32x4v, bq[2]), 0, 0, 0);
+                const f32x4v d3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[3]), av, __builtin_bit_cast(f32x4v, bq[3]), 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                static_for<0, 4>([&](auto nc) {
-                    constexpr int nn = decltype(nc)::value;
-                    const f32x4v d = dd[nn];
-                    bf16x4 o;
-#pragma unroll
-                    for (int r2 = 0; r2 < 4; ++r2) o[r2] = (bf16_t)d[r2];
-                    uint2 ov = __builtin_bit_cast(uint2, o);
-                    ov.x = relu_bf16x2(ov.x) & pmask;
-                    ov.y = relu_bf16x2(ov.y) & pmask;
-                    // channels nn*16 + 4 lq .. + 3 of pixel q: chunk nn*2 + (lq >> 1), 8-byte half lq & 1
-                    lds_write8(wdst + (((nn * 2 + (lqv >> 1)) ^ gsw) << 4), ov);
-                });
+                // channels nn*16 + 4 lq .. + 3 of pixel q: chunk nn*2 + (lq >> 1), 8-byte half lq & 1.  (nn*2 + h) ^ gsw = (nn*2) ^ (gsw & 6) with
+                // the low bit h ^ (gsw & 1) folded into the base; a VECTOR float -> bf16 conversion is two v_cvt_pk_bf16_f32 (element by element
+                // hipcc emitted four of them plus two v_perm_b32)
+                const unsigned wbase = wdst + ((((lqv >> 1) ^ gsw) & 1) << 4);
+                const unsigned g6 = (gsw & 6) << 4;
+#define CONV64_PRODUCE_STORE(D, NN)                                                    \
+                {                                                                               \
+                    uint2 ov = __builtin_bit_cast(uint2, __builtin_convertvector(D, bf16x4));   \
+                    asm volatile("" : "+v"(ov.x), "+v"(ov.y)); /* keep the conversion packed */  \
+                    ov.x = relu_bf16x2(ov.x) & pmask;                                           \
+                    ov.y = relu_bf16x2(ov.y) & pmask;                                           \
+                    lds_write8(wbase + (((NN) * 32) ^ g6), ov);                                 \
+                }
+                CONV64_PRODUCE_STORE(d0, 0)
+                CONV64_PRODUCE_STORE(d1, 1)
+                CONV64_PRODUCE_STORE(d2, 2)
+                CONV64_PRODUCE_STORE(d3, 3)
+#undef CONV64_PRODUCE_STORE
             }
         });
         wait_lgkm<0>();
