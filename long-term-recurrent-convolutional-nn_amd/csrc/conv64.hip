@@ -229,6 +229,9 @@ template <bool POOL, bool FUSE> __global__ __launch_bounds__(512) void conv64_ke
         const int ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
         (void)n;
         const int S = H;
+#ifdef CONV64_PRODUCER_PRIO_ALL
+        __builtin_amdgcn_s_setprio(CONV64_PRODUCER_PRIO_ALL);
+#endif
         const unsigned raw = lds0 + F_RAW_OFF + rbuf * F_RAW;
         const unsigned pat = lds0 + pbuf * F_PATCH;
         // everything below depends only on the lane and the tile: keep hipcc from hoisting it out of the patch loop (it would
@@ -294,10 +297,17 @@ template <bool POOL, bool FUSE> __global__ __launch_bounds__(512) void conv64_ke
                 const unsigned wdst = pat + q * 128 + (lqv & 1) * 8;
                 // the four channel blocks of an m-tile: all four MFMAs first (independent), then the conversions -- issued one by one, every
                 // conversion waited out its own MFMA's latency (tools/conv64_stamps.py: 3600 of the producer's 5000 cycles were this chain)
+                // the producer's four MFMAs overtake the partner wave's bursts of eight (priority 1): otherwise each batch queues behind a whole
+                // burst and the conversions wait -- 9260 -> 8628 cycles per patch (priority 3: the same; the whole producer at 2: 8890)
+#ifndef CONV64_PRODUCER_PRIO
+#define CONV64_PRODUCER_PRIO 2
+#endif
+                __builtin_amdgcn_s_setprio(CONV64_PRODUCER_PRIO);
                 const f32x4v d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[0]), av, __builtin_bit_cast(f32x4v, bq[0]), 0, 0, 0);
                 const f32x4v d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[1]), av, __builtin_bit_cast(f32x4v, bq[1]), 0, 0, 0);
                 const f32x4v d2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[2]), av, __builtin_bit_cast(f32x4v, bq[2]), 0, 0, 0);
                 const f32x4v d3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[3]), av, __builtin_bit_cast(f32x4v, bq[3]), 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
                 // channels nn*16 + 4 lq .. + 3 of pixel q: chunk nn*2 + (lq >> 1), 8-byte half lq & 1.  (nn*2 + h) ^ gsw = (nn*2) ^ (gsw & 6) with
                 // the low bit h ^ (gsw & 1) folded into the base; a VECTOR float -> bf16 conversion is two v_cvt_pk_bf16_f32 (element by element
@@ -319,6 +329,9 @@ template <bool POOL, bool FUSE> __global__ __launch_bounds__(512) void conv64_ke
 #undef CONV64_PRODUCE_STORE
             }
         });
+#ifdef CONV64_PRODUCER_PRIO_ALL
+        __builtin_amdgcn_s_setprio(0);
+#endif
         wait_lgkm<0>();
     };
 
