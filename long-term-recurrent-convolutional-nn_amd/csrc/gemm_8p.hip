@@ -611,11 +611,15 @@ __device__ __forceinline__ bool gemm8p_tile(const GemmArgs &g, unsigned char *sm
 #pragma unroll
                         for (int i = 0; i < MT; ++i) {
                             const f32x4v a = acc[mh][i][nh][n];
-                            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
                             typedef short s16x4 __attribute__((ext_vector_type(4)));
-                            const bf16x2 o0 = bf16x2{(bf16_t)a[0], (bf16_t)a[1]}, o1 = bf16x2{(bf16_t)a[2], (bf16_t)a[3]};
-                            const s16x2 r0 = __builtin_elementwise_max(__builtin_bit_cast(s16x2, o0), relu_lo2),
-                                        r1 = __builtin_elementwise_max(__builtin_bit_cast(s16x2, o1), relu_lo2);
+                            // ONE vector conversion = two v_cvt_pk_bf16_f32.  Written element by element hipcc scalarises it into four
+                            // single conversions plus two v_perm_b32 (192 instead of 64 vector-ALU instructions per wave and tile); the
+                            // empty asm keeps the packed pair opaque so that the integer max below cannot pull it apart again.
+                            typedef __bf16 bf16x4c __attribute__((ext_vector_type(4)));
+                            uint2 pk = __builtin_bit_cast(uint2, __builtin_convertvector(a, bf16x4c));
+                            asm volatile("" : "+v"(pk.x), "+v"(pk.y));
+                            const s16x2 r0 = __builtin_elementwise_max(__builtin_bit_cast(s16x2, pk.x), relu_lo2),
+                                        r1 = __builtin_elementwise_max(__builtin_bit_cast(s16x2, pk.y), relu_lo2);
                             const int lrow = wr * WTM + mh * QM + i * 16 + l15;
                             const int pos = ((lcol >> 3) ^ (lrow & 15)) * 16 + (lcol & 7) * 2;
                             *reinterpret_cast<s16x4 *>(cst + lrow * CSTR + pos) = s16x4{r0[0], r0[1], r1[0], r1[1]};
