@@ -160,6 +160,9 @@ def parse_args(argv=None):
                     help="N > 1: 'torch' = per-group all-reduces issued through torch.distributed's RCCL process group (default); 'abi' = RCCL "
                          "inside liblrcn_hip (lrcn_comm_init + lrcn_train_step_dp, one C call per step); 'auto' (self-launched jobs only) = "
                          "try 'abi' under a watchdog, rerun with 'torch' if it fails")
+    ap.add_argument("--shard-adam", action="store_true", default=os.environ.get("LRCN_DP_SHARD_ADAM", "0")[:1] == "1",
+                    help="N > 1, torch backend: reduce-scatter -> Adam on 1/N of the flat parameter buffer -> all-gather instead of all-reduce -> replicated "
+                         "Adam (same wire bytes, 1/N of the update's HBM traffic per rank).  Opt-in: it has never met a second GPU")
     ap.add_argument("--spinup-ms", type=float, default=150.0,
                     help="set-up, before the W warm-up steps: keep the GPU busy with VGG forwards of the benchmark's own crops for this long.  "
                          "The chip needs ~100 ms of load after idle before its clocks settle (measured: steps 1..15 after idle run 7.5 -> 7.0 ms); "
@@ -362,7 +365,8 @@ def main(argv=None):
     param = L.initweights(ctx, seed=42)          # identical on every rank (same seed)
     optim = L.initparams(param)
     backend = a.dp_backend if a.dp_backend != "auto" else "torch"   # 'auto' is resolved by launch(); a torchrun-launched job cannot retry
-    trainer = dp.DataParallelTrainer(ctx, param, optim, Bg, world, rank, pdrop=a.pdrop, seed=7, backend=backend)
+    trainer = dp.DataParallelTrainer(ctx, param, optim, Bg, world, rank, pdrop=a.pdrop, seed=7, backend=backend,
+                                     shard_adam=bool(a.shard_adam) and world > 1)
 
     # synthetic inputs: uint8 crops uniform seed 1234; Zipf(1.0) word ids >= 3, seed 7; one T per batch
     g = torch.Generator(device="cuda")
@@ -459,6 +463,7 @@ def main(argv=None):
                        "last_loss": loss,
                        "setup_spinup": "%d untimed VGG forwards (%.0f ms) before the warm-up steps; not training steps" % (spun, a.spinup_ms)},
             "rccl": {"world": world, "backend": ("none (one rank: no collective)" if world == 1 else trainer.backend),
+                     "update": "sharded (reduce-scatter -> Adam on 1/N -> all-gather)" if trainer.shard else "replicated (all-reduce -> Adam)",
                      "launched_by": "bench.py" if os.environ.get("LRCN_BENCH_LAUNCHED") else ("torch.distributed.run" if world > 1 else "direct")},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": traffic, "traffic_source": traffic_note,

@@ -164,6 +164,13 @@ int lrcn_adam_update_group(lrcn_ctx *ctx, float *const params[9], const float *c
                            float *const var[9], int group, int step, float lr, float beta1, float beta2, float eps,
                            void *hip_stream);
 
+/* The same Adam arithmetic on ONE flat run of n floats (w, g, m, v: device pointers to n elements each), enqueued on `hip_stream` (NULL =
+ * the context's stream) (rev 3).  For a data-parallel host that shards the update over the ranks: reduce-scatter of a gradient group -> this
+ * call on the rank's 1/N slice of the flat parameter buffer (with the rank's own slices of the moments) -> all-gather of the parameters.
+ * Same bytes on the wire as the all-reduce, 1/N of the update's HBM traffic per rank; the moments then exist only rank-sharded. */
+int lrcn_adam_update_flat(lrcn_ctx *ctx, float *w, const float *g, float *m, float *v, int64_t n, int step, float lr, float beta1,
+                          float beta2, float eps, void *hip_stream);
+
 /* Body of train1's loop (lrcn.jl:369-394) on one device: lossgradient + update!.  feats: B x 4096. */
 int lrcn_train_step(lrcn_ctx *ctx, float *const params[9], float *const grads[9], float *const mom[9],
                     float *const var[9], const float *feats, const int32_t *tokens, int T, int B, int norm_B,

@@ -153,6 +153,10 @@ end
 # local (non-collective) check; every rank probes, the ranks agree, and only then enter the collective comm_init
 comm_probe(ctx) = ccall((:lrcn_comm_probe, lib), Cint, (Ptr{Cvoid},), ctx.h) == 0
 set_option(ctx, option::Integer, value::Integer) = check(ctx, ccall((:lrcn_set_option, lib), Cint, (Ptr{Cvoid}, Cint, Int64), ctx.h, option, value))
+# Adam on one flat run of n floats (a rank's 1/N slice under a sharded data-parallel update)
+update_flat!(ctx, w, g, m, v, n, step; lr=1f-3, beta1=0.9f0, beta2=0.999f0, eps=1f-8, stream=C_NULL) =
+    check(ctx, ccall((:lrcn_adam_update_flat, lib), Cint, (Ptr{Cvoid}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Int64, Cint, Cfloat, Cfloat, Cfloat, Cfloat, Ptr{Cvoid}),
+                ctx.h, w, g, m, v, n, step, lr, beta1, beta2, eps, stream))
 params_touched(ctx) = check(ctx, ccall((:lrcn_params_touched, lib), Cint, (Ptr{Cvoid},), ctx.h))
 comm_init(ctx, world, rank, id::Vector{UInt8}) = check(ctx, ccall((:lrcn_comm_init, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{UInt8}), ctx.h, world, rank, id))
 allreduce_grads(ctx, grads; group = -1) = check(ctx, ccall((:lrcn_allreduce_grads, lib), Cint, (Ptr{Cvoid}, Ptr{Ptr{Cfloat}}, Cint), ctx.h, ptrs(grads), group))

@@ -70,6 +70,8 @@ SIGNATURES = {
     "lrcn_adam_update": (C.c_int, [C.c_void_p, P9, P9, P9, P9, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]),
     "lrcn_adam_update_group": (C.c_int, [C.c_void_p, P9, P9, P9, P9, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
                                          C.c_void_p]),
+    "lrcn_adam_update_flat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_float,
+                                        C.c_float, C.c_void_p]),
     "lrcn_train_step": (C.c_int, [C.c_void_p, P9, P9, P9, P9, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                   C.POINTER(Dropout), C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
                                   C.POINTER(C.c_double)]),

@@ -1176,6 +1176,20 @@ int lrcn_adam_update_group(lrcn_ctx *c, float *const p[9], const float *const g[
     return LRCN_OK;
 }
 
+int lrcn_adam_update_flat(lrcn_ctx *c, float *w, const float *g, float *m, float *v, int64_t n, int step, float lr, float b1, float b2,
+                          float eps, void *stream) {
+    DeviceGuard dg(c);
+    if (!c || step < 1 || n < 0) return LRCN_EINVAL;
+    if (n == 0) return LRCN_OK;
+    if (!w || !g || !m || !v) return LRCN_EINVAL;
+    c->shadow_valid = false;  // some parameter changed: the next call makes its shadow weights afresh
+    AdamTensors t{};
+    t.w[0] = w; t.g[0] = g; t.m[0] = m; t.v[0] = v; t.n[0] = n;
+    k_adam(stream ? reinterpret_cast<hipStream_t>(stream) : c->stream, t, step, lr, b1, b2, eps);
+    KCHK(c, "adam (flat)");
+    return LRCN_OK;
+}
+
 int lrcn_train_step(lrcn_ctx *c, float *const p[9], float *const g[9], float *const m[9], float *const v[9], const float *feats,
                     const int32_t *tokens, int T, int B, int norm_B, const lrcn_dropout *drop, int step, float lr, float b1,
                     float b2, float eps, double *loss_host) {

@@ -40,16 +40,30 @@ def vgg_wg_cap_for(device):
 GRAD_GROUPS = [(7, 8), (2, 3), (4, 5), (0, 1), (6,)]
 
 
-def flat_model_like(shapes, device="cuda"):
-    """One flat float32 buffer + 9 column-major views into it (so the gradient all-reduce is one collective)."""
+def flat_model_like(shapes, device="cuda", group_align=0):
+    """One flat float32 buffer + 9 column-major views into it (so the gradient all-reduce is one collective).
+    group_align > 0: every gradient group (GRAD_GROUPS: adjacent tensors) is padded with zeros to a multiple of `group_align` elements, so
+    that a reduce-scatter / all-gather can cut it into equal shards; returns (flat, views, ranges) with ranges[g] = the padded [a, b) of
+    group g in the order of GRAD_GROUPS."""
     sizes = [int(np.prod(s)) for s in shapes]
-    flat = torch.zeros(sum(sizes), device=device, dtype=torch.float32)
-    views, off = [], 0
-    for s, n in zip(shapes, sizes):
-        v = flat[off:off + n].view(*reversed(s)).permute(*reversed(range(len(s))))
-        views.append(v)
+    offs, off = [], 0
+    group_end = {max(g): g for g in GRAD_GROUPS}
+    starts = {}
+    for k, n in enumerate(sizes):
+        if group_align and any(k == min(g) for g in GRAD_GROUPS):
+            starts[[g for g in GRAD_GROUPS if k == min(g)][0]] = off
+        offs.append(off)
         off += n
-    return flat, views
+        if group_align and k in group_end:
+            off = -(-off // group_align) * group_align
+            starts[("end", group_end[k])] = off
+    flat = torch.zeros(off, device=device, dtype=torch.float32)
+    views = []
+    for s, n, o in zip(shapes, sizes, offs):
+        views.append(flat[o:o + n].view(*reversed(s)).permute(*reversed(range(len(s)))))
+    if not group_align:
+        return flat, views
+    return flat, views, [(starts[g], starts[("end", g)]) for g in GRAD_GROUPS]
 
 
 class HipOps:
@@ -80,6 +94,9 @@ class HipOps:
 
     def update_group(self, param, grads, optim, group, stream):
         L.update_group(self.ctx, param, grads, optim, group, stream)
+
+    def update_flat(self, w, g, m, v, optim, stream):
+        L.update_flat(self.ctx, w, g, m, v, optim, stream)
 
     def last_loss(self):
         return L.last_loss(self.ctx)
@@ -125,7 +142,7 @@ class DataParallelTrainer:
     """train1's batch loop body (lrcn.jl:369-394) sharded over ranks. world_size 1 = no collective.
     `ops` defaults to the HIP operations; tests of the collective logic on CPU (gloo) inject their own."""
 
-    def __init__(self, ctx, param, optim, B_global, world=1, rank=0, pdrop=0.4, seed=0, group=None, ops=None, backend=None):
+    def __init__(self, ctx, param, optim, B_global, world=1, rank=0, pdrop=0.4, seed=0, group=None, ops=None, backend=None, shard_adam=None):
         """backend (world > 1): "torch" (default) = the per-group all-reduces are issued from here through torch.distributed's RCCL
         process group; "abi" = RCCL inside liblrcn_hip (lrcn_comm_init + lrcn_train_step_dp: one C call per step, what a Julia host
         would drive; the unique id travels over torch.distributed's group).  LRCN_DP_BACKEND overrides.  "abi" stays opt-in until a
@@ -150,11 +167,33 @@ class DataParallelTrainer:
         # shortens it (emulated rank of 8, 32 rows: 1.549 -> 1.510 ms/step, two same-box pairs).  From 256 rows the chain is hidden behind
         # the convolutions and the fused kernel -- whose transposes need LDS, which a CU holding a convolution workgroup does not have, so
         # ALL of the update then queues for the 32 free CUs -- measured 7.19 -> 7.29 ms/step.  LRCN_FUSED_UPDATE=0 / 1 forces it.
+        # Sharded update (opt-in: shard_adam=True / LRCN_DP_SHARD_ADAM=1; torch backend): per gradient group, reduce-scatter(SUM) -> Adam on
+        # this rank's 1/N slice of the flat parameter buffer -> all-gather of the parameters.  Same bytes on the wire as the all-reduce,
+        # 1/N of update!'s 1.1 GB of HBM traffic per rank (215 -> ~27 us at 8 ranks).  The parameters move into ONE flat buffer (the
+        # caller's list keeps working: its entries are replaced by views of it) and the Adam moments exist only as this rank's slices
+        # (optim.m / optim.v are not used).  Never run on more than one GPU: opt-in until it has been.
+        if shard_adam is None:
+            shard_adam = os.environ.get("LRCN_DP_SHARD_ADAM", "0")[:1] == "1"
+        self.shard = bool(shard_adam) and self.backend == "torch" and hasattr(self.ops, "update_flat") and hasattr(self.ops, "grad_group_wait")
         env = os.environ.get("LRCN_FUSED_UPDATE")
         fused = (env[:1] != "0") if env else (B_global // max(world, 1) < 256)
-        if fused and hasattr(self.ops, "set_fused_update"):
+        if fused and not self.shard and hasattr(self.ops, "set_fused_update"):
             self.ops.set_fused_update(True)
-        self.flat_grads, self.grads = flat_model_like([tuple(t.shape) for t in param], device=param[0].device)
+        shapes = [tuple(t.shape) for t in param]
+        if self.shard:
+            align = 4 * max(world, 1)  # every rank's slice is a whole number of 16-byte chunks
+            dev = param[0].device
+            self.flat_param, pviews, self._ranges = flat_model_like(shapes, device=dev, group_align=align)
+            for k, v in enumerate(pviews):
+                v.copy_(param[k])
+                param[k] = v           # the caller's list now refers to the flat buffer
+            self.flat_grads, self.grads, _ = flat_model_like(shapes, device=dev, group_align=align)
+            n_of = [(b - a) // max(world, 1) for a, b in self._ranges]
+            self._m = [torch.zeros(n, device=dev, dtype=torch.float32) for n in n_of]
+            self._v = [torch.zeros(n, device=dev, dtype=torch.float32) for n in n_of]
+            self._gshard = [torch.zeros(n, device=dev, dtype=torch.float32) for n in n_of]
+        else:
+            self.flat_grads, self.grads = flat_model_like(shapes, device=param[0].device)
         self.step_no = 0
         self._feats_next = None
         self._side = self.ops.side_stream() if hasattr(self.ops, "side_stream") else None
@@ -284,6 +323,11 @@ class DataParallelTrainer:
                 self._feats_next = self.vgg(next_img_u8)
             return
         self.ops.lossgradient(self.param, feats, tokens, self.B_global, self.pdrop, seed, self.grads)
+        if self.shard:
+            self._reduce_scatter_update_gather()
+            if next_img_u8 is not None and self._side is None:
+                self._feats_next = self.vgg(next_img_u8)
+            return
         if self._group_pipeline():
             # per gradient group, on its own stream: [wait for the group's event] -> [all-reduce] -> [Adam of that group], all
             # while the rest of the backward pass runs (it reads the bf16/f32 shadows, never the f32 parameters)
@@ -322,6 +366,44 @@ class DataParallelTrainer:
                 if self.world > 1 and b > a:
                     dist.all_reduce(self.flat_grads[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True).wait()  # s waits for RCCL
                 self.ops.update_group(self.param, self.grads, self.optim, k, s)
+        self.ops.join(self._bucket_streams)
+
+    def _reduce_scatter_update_gather(self):
+        """The sharded form of _reduce_and_update_groups: per group, on its own stream, [wait for the group's gradients] ->
+        [reduce-scatter(SUM)] -> [Adam on this rank's slice] -> [all-gather of the parameters]; then one join."""
+        if self._bucket_streams is None:
+            self._bucket_streams = self.ops.make_streams(len(GRAD_GROUPS))
+        self.optim.t += 1
+        W, r = max(self.world, 1), self.rank
+        # a one-rank process group given explicitly (tests on a one-GPU box): the collectives are issued all the same
+        coll = self.world > 1 or (self.group is not None and dist.is_initialized())
+        nccl = coll and dist.get_backend(self.group) == "nccl"
+        for k, (a, b) in enumerate(self._ranges):
+            s = self._bucket_streams[k]
+            self.ops.grad_group_wait(k, s)
+            if b == a:
+                continue  # LRCN-1f has no W2 / b2 group
+            n = (b - a) // W
+            mine = self.flat_param[a + r * n:a + (r + 1) * n]
+            with self.ops.stream_ctx(s):
+                g_all = self.flat_grads[a:b]
+                if not coll:
+                    self._gshard[k].copy_(g_all)
+                elif nccl:
+                    dist.reduce_scatter_tensor(self._gshard[k], g_all, op=dist.ReduceOp.SUM, group=self.group)
+                else:  # gloo has no reduce-scatter: all-reduce, then keep this rank's slice (CPU tests of the indexing)
+                    tmp = g_all.clone()
+                    dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=self.group)
+                    self._gshard[k].copy_(tmp[r * n:(r + 1) * n])
+                self.ops.update_flat(mine, self._gshard[k], self._m[k], self._v[k], self.optim, s)
+                if coll:
+                    if nccl:
+                        dist.all_gather_into_tensor(self.flat_param[a:b], mine, group=self.group)
+                    else:
+                        parts = [torch.empty_like(mine) for _ in range(W)]
+                        dist.all_gather(parts, mine.clone(), group=self.group)
+                        for i, t in enumerate(parts):
+                            self.flat_param[a + i * n:a + (i + 1) * n].copy_(t)
         self.ops.join(self._bucket_streams)
 
     def loss_value(self):

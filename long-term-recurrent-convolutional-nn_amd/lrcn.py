@@ -281,6 +281,15 @@ def update_group(ctx, param, grads, optim, group, stream=None):
               optim.beta1, optim.beta2, optim.eps, C.c_void_p(stream.cuda_stream) if stream is not None else None)
 
 
+def update_flat(ctx, w, g, m, v, optim, stream=None):
+    """The Adam arithmetic on one flat run of floats (lrcn_adam_update_flat): w, g, m, v are 1-D float32 tensors of equal length; the
+    caller advances optim.t once per step."""
+    n = w.numel()
+    assert g.numel() == n and m.numel() == n and v.numel() == n
+    ctx._call("lrcn_adam_update_flat", C.c_void_p(w.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(m.data_ptr()), C.c_void_p(v.data_ptr()),
+              n, optim.t, optim.lr, optim.beta1, optim.beta2, optim.eps, C.c_void_p(stream.cuda_stream) if stream is not None else None)
+
+
 def train_step(ctx, param, optim, grads, feats, tokens, norm_B=None, pdrop=0.4, seed=0, want_loss=False):
     """Body of train1's batch loop (lrcn.jl:369-394): lossgradient + update!, one C call."""
     tok = _tokens(tokens, feats.device)

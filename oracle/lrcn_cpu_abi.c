@@ -211,6 +211,15 @@ int lrcn_adam_update(lrcn_ctx *c, float *const p[9], const float *const g[9], fl
         if (sz[k] > 0) orc_adam(p[k], g[k], m[k], v[k], sz[k], step, lr, b1, b2, eps);
     return LRCN_OK;
 }
+int lrcn_adam_update_flat(lrcn_ctx *c, float *w, const float *g, float *m, float *v, int64_t n, int step, float lr, float b1, float b2,
+                          float eps, void *stream) {
+    (void)stream;
+    if (!c || step < 1 || n < 0) return LRCN_EINVAL;
+    if (n == 0) return LRCN_OK;
+    if (!w || !g || !m || !v) return LRCN_EINVAL;
+    orc_adam(w, g, m, v, n, step, lr, b1, b2, eps);
+    return LRCN_OK;
+}
 int lrcn_train_step(lrcn_ctx *c, float *const p[9], float *const g[9], float *const m[9], float *const v[9], const float *feats,
                     const int32_t *tokens, int T, int B, int norm_B, const lrcn_dropout *drop, int step, float lr, float b1, float b2,
                     float eps, double *loss_host) {

@@ -66,6 +66,13 @@ class OracleGroupOps(OracleOps):
     def join(self, streams):
         self.log.append(("join", len(streams)))
 
+    def update_flat(self, w, g, m, v, optim, stream):
+        """Adam on one flat run of floats (the sharded update): same arithmetic as orc.adam, on 1-D tensors."""
+        self.log.append(("adam_flat", stream, optim.t, w.numel()))
+        ww, mm, vv = (np.ascontiguousarray(a.numpy()) for a in (w, m, v))
+        orc.adam(ww, np.ascontiguousarray(g.numpy()), mm, vv, optim.t)
+        w.copy_(torch.as_tensor(ww)); m.copy_(torch.as_tensor(mm)); v.copy_(torch.as_tensor(vv))
+
 
 class HostAdam:
     def __init__(self, param):

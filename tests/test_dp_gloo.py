@@ -59,6 +59,15 @@ def _worker(rank, world, port, golden, out, mode="plain"):
             tr = dp.DataParallelTrainer(None, param, HostAdam(param), Bg, world, rank, pdrop=0.0, ops=ops, backend="abi")
         assert tr.backend == "torch" and ops.destroyed and tr.backend_note
         assert ops.entered_init == (mode == "abi_init_fail")
+    elif mode == "shard_adam":
+        # reduce-scatter -> Adam on this rank's slice of the flat parameter buffer -> all-gather (gloo has no reduce-scatter: dp.py falls
+        # back to all-reduce + slice here, which leaves the group padding, the slice arithmetic and the gather to be tested)
+        ops = OracleGroupOps(dims)
+        before = [p.clone() for p in param]
+        tr = dp.DataParallelTrainer(None, param, HostAdam(param), Bg, world, rank, pdrop=0.0, ops=ops, shard_adam=True)
+        assert tr.shard and all(torch.equal(a, b) for a, b in zip(before, param))          # re-homed into the flat buffer, values kept
+        assert all(p.untyped_storage().data_ptr() == tr.flat_param.untyped_storage().data_ptr() for p in param)
+        assert all((b - a) % (4 * world) == 0 for a, b in tr._ranges)
     else:
         ops = OracleOps(dims) if mode == "plain" else OracleGroupOps(dims)
         tr = dp.DataParallelTrainer(None, param, HostAdam(param), Bg, world, rank, pdrop=0.0, ops=ops)
@@ -79,6 +88,11 @@ def _worker(rank, world, port, golden, out, mode="plain"):
             for k in range(5):
                 assert ev[2 * k] == ("wait", k, "bucket%d" % k) and ev[2 * k + 1] == ("adam", k, "bucket%d" % k, step + 1), ev
             assert ev[10] == ("join", 5)
+    elif mode == "shard_adam":
+        flats = [e for e in ops.log if e[0] == "adam_flat"]
+        assert len(flats) == 2 * 5 and [e[2] for e in flats] == [1] * 5 + [2] * 5            # five slices per step, with that step's t
+        assert sum(e[3] for e in flats[:5]) * world == tr.flat_param.numel()                  # the slices tile the padded buffer
+        assert not [e for e in ops.log if e[0] == "adam"]
     elif mode == "bucket_one_adam":
         waits = [e for e in ops.log if e[0] == "wait"]
         assert len(waits) == 2 * 5 and not [e for e in ops.log if e[0] == "adam"]  # bucketed all-reduces, then ONE update
@@ -88,11 +102,11 @@ def _worker(rank, world, port, golden, out, mode="plain"):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["plain", "group_pipeline", "bucket_one_adam", "abi_probe_fail", "abi_init_fail"])
+@pytest.mark.parametrize("mode", ["plain", "group_pipeline", "bucket_one_adam", "abi_probe_fail", "abi_init_fail", "shard_adam"])
 def test_two_rank_step_equals_full_batch(golden_dir, tmp_path, mode):
     golden = os.path.join(golden_dir, "lstm_mid.npz")
     out = str(tmp_path / "dp.npz")
-    port = 29500 + (os.getpid() % 2000) + {"plain": 0, "group_pipeline": 1, "bucket_one_adam": 2, "abi_probe_fail": 3, "abi_init_fail": 4}[mode]
+    port = 29500 + (os.getpid() % 2000) + {"plain": 0, "group_pipeline": 1, "bucket_one_adam": 2, "abi_probe_fail": 3, "abi_init_fail": 4, "shard_adam": 5}[mode]
     mp.spawn(_worker, args=(2, port, golden, out, mode), nprocs=2, join=True)
     got = np.load(out)
     # single-process reference: two full-batch steps with the oracle

@@ -188,3 +188,49 @@ def test_train_step_dp_with_images_equals_separate_calls():
     assert (abs(f64.sum(axis=1) - 1.0) <= 1e-6 * abs(f64).sum(axis=1)).all(), (f64.sum(axis=1), abs(f64).sum(axis=1))
     for a, b in zip(outs[0][2], outs[1][2]):
         np.testing.assert_allclose(a, b, rtol=0, atol=1e-7)
+
+
+def test_sharded_adam_equals_the_replicated_update(monkeypatch):
+    """dp.py's sharded update (reduce-scatter -> lrcn_adam_update_flat on the rank's slice of the flat parameter buffer -> all-gather) on a
+    ONE-rank RCCL process group: the collectives are issued for real (identity on one rank), the parameters are re-homed into the flat,
+    group-padded buffer, the moments live in the trainer -- and the trajectory must be the replicated update's."""
+    import os
+    import socket
+    import torch.distributed as dist
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        E = H = 64
+        V, B, T = 300, 4, 5
+
+        def run(shard, n_layers=2):
+            ctx = L.Context(E, H, H, V, max_B=B, max_T=T, lstm_dtype=lrcn_amd.LRCN_BF16, n_layers=n_layers)
+            param = L.initweights(ctx, seed=42)
+            tr = dp.DataParallelTrainer(ctx, param, L.initparams(param), B, 1, 0, pdrop=0.4, seed=7, group=dist.group.WORLD, backend="torch",
+                                        shard_adam=shard)
+            assert tr.shard == shard
+            rng = np.random.default_rng(3)
+            losses = []
+            for k in range(3):
+                feats = L.to_jl((rng.standard_normal((B, 4096)) * 0.01).astype(np.float32))
+                toks = torch.as_tensor(rng.integers(3, V, size=(T, B)).astype(np.int32)).cuda()
+                tr.step(None, toks, feats=feats)
+                losses.append(tr.loss_value())
+            torch.cuda.synchronize()
+            out = [L.from_jl(p).copy() for p in param]
+            ctx.close()
+            return losses, out
+
+        for nl in (2, 1):
+            la, pa = run(False, nl)
+            lb, pb = run(True, nl)
+            np.testing.assert_allclose(la, lb, rtol=1e-6)
+            for a, b in zip(pa, pb):
+                np.testing.assert_allclose(a, b, rtol=0, atol=1e-6)
+    finally:
+        dist.destroy_process_group()
