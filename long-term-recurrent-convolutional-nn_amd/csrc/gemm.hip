@@ -313,6 +313,14 @@ static hipError_t launch_gemm_routed(hipStream_t stream, const GemmArgs &g, cons
             GemmArgs h = g;
             h.cfg_pref = 2;
             if (gemm_8p_config(h, &blocks) >= 0 && blocks <= 2 * g.bg_cus) {
+                // few tiles and a long K (the backward dh GEMM of the recurrence: 8 tiles x 63 K-tiles): K slices over the free CUs
+                static const int bg_sk = getenv("LRCN_BG_SPLITK") ? atoi(getenv("LRCN_BG_SPLITK")) : 0;  // development knob (0 = off)
+                if (bg_sk > 1 && blocks * bg_sk <= g.bg_cus && g.K >= 64 * 8 * bg_sk && g.c_f32 && !g.beta && !g.relu && g.out_mode == GEMM_OUT_PLAIN &&
+                    g.ws && (size_t)bg_sk * g.M * g.N * sizeof(float) <= g.ws_bytes && (g.ldc % 4) == 0 && (g.N % 4) == 0 && !((uintptr_t)g.C & 15)) {
+                    *route = "8p-bg-splitk";
+                    h.splitk_forced = 1;
+                    return launch_gemm_8p(stream, h, bg_sk);
+                }
                 *route = "8p-bg";
                 return launch_gemm_8p(stream, h);
             }

@@ -1052,7 +1052,9 @@ hipError_t launch_gemm_8p(hipStream_t stream, const GemmArgs &g0, int splitk) {
                                                : launch_one<4, 2, 2, 2, GEMM_A_PLAIN, true, false, GEMM_OUT_LSTM_BWD>(stream, g, 1);
     }
     if (splitk > 1) {
-        if (gemm_8p_splitk(g, &blocks) != splitk) return hipErrorInvalidValue;
+        // the caller's slice count must be the planner's, unless it is the "beside the convolutions" route's own choice (g.splitk_forced:
+        // the planner counts the whole chip's CUs, that route the free ones; its eligibility was checked by the router)
+        if (!g.splitk_forced && gemm_8p_splitk(g, &blocks) != splitk) return hipErrorInvalidValue;
         hipError_t e = g.a_mode == GEMM_A_CONV3 ? dispatch<GEMM_A_CONV3, true>(stream, g, 1, splitk) : dispatch<GEMM_A_PLAIN, true>(stream, g, 1, splitk);
         if (e != hipSuccess) return e;
         return launch_splitk_reduce(stream, g, splitk);
