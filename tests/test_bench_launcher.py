@@ -104,3 +104,20 @@ def test_parent_never_imports_torch():
     r = subprocess.run([sys.executable, "-c", code], env=_env(), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert _one_line(r.stdout)["n_gpus"] == 2
+
+
+def test_pmc_traffic_is_quoted_only_for_the_sources_it_was_measured_on(tmp_path, monkeypatch):
+    """roofline.traffic comes from a committed --pmc pass (a counter pass is its own run): bench.py quotes it only while csrc/'s digest
+    equals the one stamped into the profile file, and says so otherwise (the number went stale silently)."""
+    import importlib
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    val, note = bench.pmc_traffic("f32", 256)
+    assert val is None and "configuration" in note
+    val, note = bench.pmc_traffic("bf16", 32)
+    assert val is None
+    val, note = bench.pmc_traffic("bf16", 256)
+    assert (val is None and "stale" in note) or (val > 1e8 and bench.csrc_digest() in note)
+    monkeypatch.setattr(bench, "csrc_digest", lambda: "0" * 16)    # as if a kernel source had changed since the measurement
+    val, note = bench.pmc_traffic("bf16", 256)
+    assert val is None and "stale" in note
