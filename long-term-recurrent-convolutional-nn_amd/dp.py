@@ -163,10 +163,11 @@ class DataParallelTrainer:
         self.backend_note = ""
         if backend == "abi" and world > 1:
             self._init_abi_comm(world, rank, group, param[0].device)
-        # LRCN_OPT_FUSED_UPDATE below 256 rows per rank: there the LSTM chain is on the critical path and losing the separate shadow pass
-        # shortens it (emulated rank of 8, 32 rows: 1.549 -> 1.510 ms/step, two same-box pairs).  From 256 rows the chain is hidden behind
-        # the convolutions and the fused kernel -- whose transposes need LDS, which a CU holding a convolution workgroup does not have, so
-        # ALL of the update then queues for the 32 free CUs -- measured 7.19 -> 7.29 ms/step.  LRCN_FUSED_UPDATE=0 / 1 forces it.
+        # LRCN_OPT_FUSED_UPDATE: update! writes the next step's shadow weights, the separate shadow pass disappears from the head of the LSTM
+        # chain.  Emulated rank of 8 (32 rows): 1.549 -> 1.510 ms/step (two same-box pairs).  At 256 rows it lost 1.4 % early in round 3
+        # (7.19 -> 7.29 ms: the fused kernel's tile transposes want LDS and all of update! then runs on the 32 CUs the convolutions leave) and
+        # is level since the convolutions got faster (three same-box pairs 6.872 / 6.876 / 6.881 -> 6.869 / 6.854 / 6.842 ms): on everywhere.
+        # LRCN_FUSED_UPDATE=0 / 1 forces it.
         # Sharded update (opt-in: shard_adam=True / LRCN_DP_SHARD_ADAM=1; torch backend): per gradient group, reduce-scatter(SUM) -> Adam on
         # this rank's 1/N slice of the flat parameter buffer -> all-gather of the parameters.  Same bytes on the wire as the all-reduce,
         # 1/N of update!'s 1.1 GB of HBM traffic per rank (215 -> ~27 us at 8 ranks).  The parameters move into ONE flat buffer (the
@@ -176,7 +177,7 @@ class DataParallelTrainer:
             shard_adam = os.environ.get("LRCN_DP_SHARD_ADAM", "0")[:1] == "1"
         self.shard = bool(shard_adam) and self.backend == "torch" and hasattr(self.ops, "update_flat") and hasattr(self.ops, "grad_group_wait")
         env = os.environ.get("LRCN_FUSED_UPDATE")
-        fused = (env[:1] != "0") if env else (B_global // max(world, 1) < 256)
+        fused = (env[:1] != "0") if env else True
         if fused and not self.shard and hasattr(self.ops, "set_fused_update"):
             self.ops.set_fused_update(True)
         shapes = [tuple(t.shape) for t in param]
