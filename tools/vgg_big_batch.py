@@ -1,4 +1,4 @@
-import sys, numpy as np, torch
+import os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import lrcn_amd
 from lrcn_amd import lrcn as L
