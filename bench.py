@@ -348,10 +348,19 @@ def main(argv=None):
     from lrcn_amd import dp
     from lrcn_amd import lrcn as L
 
+    # LRCN_BENCH_FAKE_MULTI=1 (validation on a ONE-GPU box; never a measurement): every rank uses device 0 and the process group is gloo
+    # (RCCL refuses two ranks on one device) -- the N-rank control flow of this file and of dp.py (row shards, global normaliser, per-group
+    # event -> all-reduce -> Adam pipeline, loss reduction, barrier timing) then runs on the REAL kernels, with only the transport swapped.
+    fake_multi = world > 1 and os.environ.get("LRCN_BENCH_FAKE_MULTI", "0")[:1] == "1"
+    if fake_multi:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if fake_multi:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     dt = lrcn_amd.LRCN_BF16 if a.dtype == "bf16" else lrcn_amd.LRCN_F32
     E = H = a.hidden
@@ -462,7 +471,8 @@ def main(argv=None):
                        "global_batch": Bg, "per_gpu_batch": B, "seq_len": T + 1, "parallelism": "dp%d" % world,
                        "last_loss": loss,
                        "setup_spinup": "%d untimed VGG forwards (%.0f ms) before the warm-up steps; not training steps" % (spun, a.spinup_ms)},
-            "rccl": {"world": world, "backend": ("none (one rank: no collective)" if world == 1 else trainer.backend),
+            "rccl": {"world": world, "backend": ("none (one rank: no collective)" if world == 1 else
+                                                 ("gloo on ONE shared GPU (LRCN_BENCH_FAKE_MULTI: validation, not a measurement)" if fake_multi else trainer.backend)),
                      "update": "sharded (reduce-scatter -> Adam on 1/N -> all-gather)" if trainer.shard else "replicated (all-reduce -> Adam)",
                      "launched_by": "bench.py" if os.environ.get("LRCN_BENCH_LAUNCHED") else ("torch.distributed.run" if world > 1 else "direct")},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,

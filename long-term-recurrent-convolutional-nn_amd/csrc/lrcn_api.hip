@@ -188,7 +188,12 @@ template <class P> int dalloc(lrcn_ctx *c, P *&p, size_t bytes) {
     }
     c->allocs.push_back(q);
     p = reinterpret_cast<P *>(q);
-    if (hipMemset(q, 0, bytes) != hipSuccess) {  // K-padding columns must hold zeros (never NaN) from the start
+    // K-padding columns must hold zeros (never NaN) from the start.  The fill runs on the NULL stream and a device-memory hipMemset may
+    // return before it has executed; work that the caller then queues on a NON-BLOCKING stream (torch's side streams, the context's
+    // weight-gradient / group streams) is not ordered behind the null stream -- a buffer allocated lazily inside a step could be
+    // zeroed AFTER its first kernel had written it (found with tools/fake_multi_check.py: the second shadow set, allocated by the
+    // first fused update, lost what the group streams' Adam kernels had just written).  Drain the null stream before handing it out.
+    if (hipMemset(q, 0, bytes) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) {
         c->err = "hipMemset failed";
         return LRCN_EHIP;
     }
@@ -821,6 +826,10 @@ int lrcn_set_option(lrcn_ctx *c, int option, int64_t value) {
         c->opt_fused = value != 0;
         c->shadow_valid = false;
         c->fused_groups = 0;
+        if (c->opt_fused) {  // the second shadow set is allocated here, not inside the first update (no allocation in a step)
+            DeviceGuard dg(c);
+            return ensure_alt_shadows(c);
+        }
         return LRCN_OK;
     case LRCN_OPT_DETERMINISTIC:
         if (value != 0 && value != 1) FAIL(c, LRCN_EINVAL, "LRCN_OPT_DETERMINISTIC takes 0 or 1");
