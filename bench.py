@@ -353,6 +353,8 @@ def main(argv=None):
     # event -> all-reduce -> Adam pipeline, loss reduction, barrier timing) then runs on the REAL kernels, with only the transport swapped.
     fake_multi = world > 1 and os.environ.get("LRCN_BENCH_FAKE_MULTI", "0")[:1] == "1"
     if fake_multi:
+        if world > 4:
+            raise SystemExit("LRCN_BENCH_FAKE_MULTI: at most 4 ranks may share one GPU (the pool's limit is 6 processes per device)")
         local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:

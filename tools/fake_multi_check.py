@@ -19,6 +19,8 @@ from lrcn_amd import lrcn as L  # noqa: E402
 
 world = int(os.environ.get("WORLD_SIZE", "1"))
 rank = int(os.environ.get("RANK", "0"))
+if world > 4:
+    raise SystemExit("at most 4 ranks may share one GPU (the pool's limit is 6 processes per device)")
 torch.cuda.set_device(0)
 if world > 1:
     dist.init_process_group("gloo", rank=rank, world_size=world)
