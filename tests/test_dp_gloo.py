@@ -135,3 +135,17 @@ def test_shard_rows_and_flat_views():
     assert flat.numel() == 17 and views[0].shape == (3, 4) and views[0].stride() == (1, 3)
     views[1][0, 2] = 7.0
     assert flat[12 + 2] == 7.0
+    # group-padded layout of the sharded update: every gradient group (adjacent tensors) starts where the previous one's padding ends, its
+    # padded length is a multiple of the alignment, the views tile the unpadded part without overlap, the padding stays zero
+    shapes = [(5, 8), (1, 8), (4, 8), (1, 8), (3, 2), (7, 2), (9, 3), (3, 9), (1, 9)]
+    for align in (8, 16, 12):
+        flat, views, ranges = dp.flat_model_like(shapes, device="cpu", group_align=align)
+        assert len(ranges) == len(dp.GRAD_GROUPS) and all((b - a) % align == 0 and b > a for a, b in ranges)
+        assert sorted(ranges) == sorted(set(ranges)) and sum(b - a for a, b in ranges) == flat.numel()
+        for k, v in enumerate(views):
+            v.fill_(k + 1)
+        for grp, (a, b) in zip(dp.GRAD_GROUPS, ranges):
+            n = sum(int(np.prod(shapes[k])) for k in grp)
+            seg = flat[a:b]
+            assert set(seg[:n].tolist()) == {float(k + 1) for k in grp} and float(seg[n:].abs().sum()) == 0.0
+            assert views[min(grp)].storage_offset() == a
