@@ -22,6 +22,26 @@ typedef ORC_ACC acc_t;
 
 #define CM(A, ld, i, j) ((A)[(size_t)(i) + (size_t)(j) * (size_t)(ld)])
 
+/* ------------------------------------------------------------------------------------------------
+ * ORC_EMULATE_BF16 (orc_set_emulate_bf16): the SAME restatement with every value rounded to bfloat16 (round to nearest even)
+ * at exactly the points where the HIP library's LRCN_BF16 / vgg bf16 arithmetic stores or feeds a bf16 value (lrcn_oracle.h lists
+ * them); accumulation stays ORC_ACC, cell state / softmax / loss stay as they are.  Off (the default) every rb() is the identity
+ * and the oracle is bit-for-bit the one tests/golden pins.  Emulation exists so that the bf16 kernels can be compared
+ * ELEMENTWISE (what is left is summation order and the rare 1-ulp flip of a rounding) instead of by cosine.
+ * ------------------------------------------------------------------------------------------------ */
+static int g_emu = 0;
+void orc_set_emulate_bf16(int on) { g_emu = on != 0; }
+int orc_get_emulate_bf16(void) { return g_emu; }
+float orc_bf16_round(float x) { /* RNE to 8 significant bits; NaN stays NaN, overflow rounds to inf as the hardware conversion does */
+    union { float f; uint32_t u; } v;
+    v.f = x;
+    if ((v.u & 0x7fffffffu) > 0x7f800000u) return x;
+    v.u += 0x7fffu + ((v.u >> 16) & 1u);
+    v.u &= 0xffff0000u;
+    return v.f;
+}
+static inline float rb(float x) { return g_emu ? orc_bf16_round(x) : x; }
+
 int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();
@@ -54,8 +74,30 @@ static float *fzeros(size_t n) {
  *   tB=0: B is K x N (ldb);  tB=1: B is N x K and op(B)=B'.
  * Stands in for cublasSgemm at the `*` call sites (lrcn.jl:529, 545, 550, 558) and their AutoGrad duals.
  * ------------------------------------------------------------------------------------------------ */
+static void gemm_cm_plain(int tA, int tB, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float beta, float *C,
+                          int ldc);
+static float *rounded_copy(const float *A, int rows, int cols, int ld) {
+    float *r = (float *)malloc(sizeof(float) * (size_t)(rows ? rows : 1) * (size_t)(cols ? cols : 1));
+    if (!r) abort();
+#pragma omp parallel for schedule(static)
+    for (int j = 0; j < cols; ++j)
+        for (int i = 0; i < rows; ++i) r[(size_t)i + (size_t)j * rows] = orc_bf16_round(CM(A, ld, i, j));
+    return r;
+}
 static void gemm_cm(int tA, int tB, int M, int N, int K, const float *A, int lda, const float *B, int ldb,
                     float beta, float *C, int ldc) {
+    if (g_emu) { /* every contraction of the bf16 path takes bf16 operands (MFMA bf16 x bf16 -> f32): round both on load */
+        const int ra = tA ? K : M, ca = tA ? M : K, rbw = tB ? N : K, cbw = tB ? K : N;
+        float *Ar = rounded_copy(A, ra, ca, lda), *Br = rounded_copy(B, rbw, cbw, ldb);
+        gemm_cm_plain(tA, tB, M, N, K, Ar, ra, Br, rbw, beta, C, ldc);
+        free(Ar);
+        free(Br);
+        return;
+    }
+    gemm_cm_plain(tA, tB, M, N, K, A, lda, B, ldb, beta, C, ldc);
+}
+static void gemm_cm_plain(int tA, int tB, int M, int N, int K, const float *A, int lda, const float *B, int ldb,
+                          float beta, float *C, int ldc) {
 #ifdef ORC_FAST_GEMM
     /* Timed CPU-baseline build only: the two operand orders that the plain loops below walk with long strides or as
      * millions of 16-element dot products (the reverse pass of every timestep) are re-ordered so that the inner loop streams
@@ -282,14 +324,17 @@ static void lrcn_fwd(const orc_model *m, int B, const float *h1, const float *c1
                      const float *mask2, step_tape *t) {
     const int E = m->E, H1 = m->H1, H2 = m->H2, V = m->V, hh = (H2 + 1) / 2;
     /* x = dropout(x_lstm, pdrop)  :542  (Knet 0.8.x: x .* (rand .> p) ./ (1-p); the mask is supplied) */
-    for (size_t i = 0; i < (size_t)B * E; ++i) t->x1[i] = mask1 ? x_lstm[i] * mask1[i] : x_lstm[i];
+    /* [bf16] the gather writes bf16(embedding * multiplier) (embed_gather_kernel) */
+    for (size_t i = 0; i < (size_t)B * E; ++i) t->x1[i] = rb(mask1 ? x_lstm[i] * mask1[i] : x_lstm[i]);
     memcpy(t->c1p, c1, sizeof(float) * (size_t)B * H1);
     lstm_fwd(m->W1, m->b1, E, H1, B, t->x1, h1, c1, t->h1, t->c1, t->g1, t->xh1); /* :543 */
     /* x = s[1] * w[end-4]; x = hcat(x, x_cnn); x = dropout(x)  :544-547 */
     gemm_cm(0, 0, B, hh, H1, t->h1, B, m->Wproj, H1, 0.0f, t->x2, B);
     memcpy(t->x2 + (size_t)B * hh, x_cnn, sizeof(float) * (size_t)B * hh);
-    if (mask2)
-        for (size_t i = 0; i < (size_t)B * H2; ++i) t->x2[i] *= mask2[i];
+    /* [bf16] the projection GEMM stores bf16; concat_x2_kernel then writes bf16(value * multiplier) over all 2h columns, reading the
+     * left half back as bf16 and the right half (x_cnn) as f32 */
+    for (size_t i = 0; i < (size_t)B * hh; ++i) t->x2[i] = rb(t->x2[i]);
+    for (size_t i = 0; i < (size_t)B * H2; ++i) t->x2[i] = rb(mask2 ? t->x2[i] * mask2[i] : t->x2[i]);
     memcpy(t->c2p, c2, sizeof(float) * (size_t)B * H2);
     lstm_fwd(m->W2, m->b2, H2, H2, B, t->x2, h2, c2, t->h2, t->c2, t->g2, t->xh2); /* :548 */
     /* return x * w[end-1] .+ w[end]  :550 */
@@ -317,7 +362,7 @@ void orc_lrcn_step(const orc_model *m, int B, float *h1, float *c1, float *h2, f
 /* param[end-2][idx,:]  (lrcn.jl:556, 569): row gather of the V x E embedding. */
 static void embed_rows(const orc_model *m, const int32_t *idx, int B, float *out /* B x E */) {
     for (int e = 0; e < m->E; ++e)
-        for (int i = 0; i < B; ++i) CM(out, B, i, e) = CM(m->Wembed, m->V, idx[i], e);
+        for (int i = 0; i < B; ++i) CM(out, B, i, e) = rb(CM(m->Wembed, m->V, idx[i], e)); /* [bf16] gathered from the bf16 shadow */
 }
 
 /* logp(ypred,2) (lrcn.jl:562): row-wise log-softmax; returns sum_i logp(i, target[i]) in double (the host
@@ -335,7 +380,7 @@ static double logp_pick(const float *logits, int B, int V, const int32_t *target
         if (dlogits)
             for (int v = 0; v < V; ++v) {
                 const double p = exp((double)CM(logits, B, i, v) - lse);
-                CM(dlogits, B, i, v) = (float)((p - (v == target[i] ? 1.0 : 0.0)) * scale);
+                CM(dlogits, B, i, v) = rb((float)((p - (v == target[i] ? 1.0 : 0.0)) * scale)); /* [bf16] dlogits stored bf16 */
             }
     }
     return total;
@@ -345,19 +390,20 @@ static double logp_pick(const float *logits, int B, int V, const int32_t *target
  * dc_prev; accumulates dW, db. */
 static void lstm_bwd(const float *W, int X, int H, int B, const float *xh, const float *gates, const float *c_prev,
                      const float *c_new, const float *dh, const float *dc_in, float *dxh, float *dc_prev,
-                     float *dW, float *db, float *dz /* B x 4H scratch */) {
+                     float *dW, float *db, float *dz /* B x 4H scratch */, int dx_bf16 /* [bf16] the dX GEMM stores bf16 */) {
     for (int j = 0; j < H; ++j)
         for (int i = 0; i < B; ++i) {
-            const float f = CM(gates, B, i, j), in = CM(gates, B, i, H + j), o = CM(gates, B, i, 2 * H + j),
-                        g = CM(gates, B, i, 3 * H + j);
+            /* [bf16] the forward cell kernel keeps the activated gates in bf16 for this pass (cell state stays f32) */
+            const float f = rb(CM(gates, B, i, j)), in = rb(CM(gates, B, i, H + j)), o = rb(CM(gates, B, i, 2 * H + j)),
+                        g = rb(CM(gates, B, i, 3 * H + j));
             const float tc = tanhf(CM(c_new, B, i, j));
             const float dhv = CM(dh, B, i, j);
             const float dov = dhv * tc;
             const float dcv = CM(dc_in, B, i, j) + dhv * o * (1.0f - tc * tc);
-            CM(dz, B, i, j) = dcv * CM(c_prev, B, i, j) * f * (1.0f - f);
-            CM(dz, B, i, H + j) = dcv * g * in * (1.0f - in);
-            CM(dz, B, i, 2 * H + j) = dov * o * (1.0f - o);
-            CM(dz, B, i, 3 * H + j) = dcv * in * (1.0f - g * g);
+            CM(dz, B, i, j) = rb(dcv * CM(c_prev, B, i, j) * f * (1.0f - f)); /* [bf16] dz stored bf16 */
+            CM(dz, B, i, H + j) = rb(dcv * g * in * (1.0f - in));
+            CM(dz, B, i, 2 * H + j) = rb(dov * o * (1.0f - o));
+            CM(dz, B, i, 3 * H + j) = rb(dcv * in * (1.0f - g * g));
             CM(dc_prev, B, i, j) = dcv * f;
         }
     /* dW += [x h]' * dz ; db += colsum(dz) ; [dx dh_prev] = dz * W' */
@@ -368,6 +414,8 @@ static void lstm_bwd(const float *W, int X, int H, int B, const float *xh, const
         db[n] += (float)s;
     }
     gemm_cm(0, 1, B, X + H, 4 * H, dz, B, W, X + H, 0.0f, dxh, B);
+    if (dx_bf16)
+        for (size_t i = 0; i < (size_t)B * X; ++i) dxh[i] = rb(dxh[i]);
 }
 
 static void zero_model(orc_model *g) {
@@ -431,7 +479,7 @@ static double loss_impl(const orc_model *m, const float *feats, const int32_t *t
                 G->bout[v] += (float)a;
             }
             gemm_cm(0, 1, B, H2, V, dlog, B, m->Wout, H2, 1.0f, dh2, B); /* dh2 += dlog*Wout' (dh2 holds recurrent part) */
-            lstm_bwd(m->W2, H2, H2, B, t->xh2, t->g2, t->c2p, t->c2, dh2, dc2, dxh2, dc2p, G->W2, G->b2, dz2);
+            lstm_bwd(m->W2, H2, H2, B, t->xh2, t->g2, t->c2p, t->c2, dh2, dc2, dxh2, dc2p, G->W2, G->b2, dz2, 1);
             /* dxh2 = [d x2 (H2 cols) | d h2_prev (H2 cols)] */
             memcpy(dh2, dxh2 + (size_t)B * H2, sizeof(float) * (size_t)B * H2);
             memcpy(dc2, dc2p, sizeof(float) * (size_t)B * H2);
@@ -439,13 +487,14 @@ static double loss_impl(const orc_model *m, const float *feats, const int32_t *t
                 const float *mk = mask2 + (size_t)s * B * H2;
                 for (size_t i = 0; i < (size_t)B * H2; ++i) dxh2[i] *= mk[i];
             }
-            /* left hh columns -> projection; right hh columns -> x_cnn (summed over steps) */
-            memcpy(dp, dxh2, sizeof(float) * (size_t)B * hh);
+            /* left hh columns -> projection; right hh columns -> x_cnn (summed over steps).
+             * [bf16] dx2_mask_reduce_kernel sums the f32 products into d x_cnn and writes the masked values back as bf16 */
+            for (size_t i = 0; i < (size_t)B * hh; ++i) dp[i] = rb(dxh2[i]);
             for (size_t i = 0; i < (size_t)B * hh; ++i) dxcnn[i] += dxh2[(size_t)B * hh + i];
             gemm_cm(1, 0, H1, hh, B, t->h1, B, dp, B, 1.0f, G->Wproj, H1);
             gemm_cm(0, 1, B, H1, hh, dp, B, m->Wproj, H1, 0.0f, dh1p, B);
             for (size_t i = 0; i < (size_t)B * H1; ++i) dh1[i] += dh1p[i];
-            lstm_bwd(m->W1, E, H1, B, t->xh1, t->g1, t->c1p, t->c1, dh1, dc1, dxh1, dc1p, G->W1, G->b1, dz1);
+            lstm_bwd(m->W1, E, H1, B, t->xh1, t->g1, t->c1p, t->c1, dh1, dc1, dxh1, dc1p, G->W1, G->b1, dz1, 0);
             memcpy(dh1, dxh1 + (size_t)B * E, sizeof(float) * (size_t)B * H1);
             memcpy(dc1, dc1p, sizeof(float) * (size_t)B * H1);
             if (mask1) {
@@ -540,8 +589,8 @@ static void lrcn1_fwd(const orc_model *m, int B, const float *h, const float *c,
     const int E = m->E, H = m->H1, V = m->V, hh = (H + 1) / 2, X = E + hh;
     memcpy(t->x, x_lstm, sizeof(float) * (size_t)B * E);                  /* hcat(x_lstm, x_cnn) */
     memcpy(t->x + (size_t)B * E, x_cnn, sizeof(float) * (size_t)B * hh);
-    if (mask)
-        for (size_t i = 0; i < (size_t)B * X; ++i) t->x[i] *= mask[i];    /* dropout */
+    /* dropout.  [bf16] the embedding half was gathered as bf16, x_cnn is f32; concat_x2_kernel writes bf16(value * multiplier) */
+    for (size_t i = 0; i < (size_t)B * X; ++i) t->x[i] = rb(mask ? t->x[i] * mask[i] : t->x[i]);
     memcpy(t->cp, c, sizeof(float) * (size_t)B * H);
     lstm_fwd(m->W1, m->b1, X, H, B, t->x, h, c, t->h, t->c, t->g, t->xh);
     gemm_cm(0, 0, B, V, H, t->h, B, m->Wout, H, 0.0f, t->logits, B);     /* x * w[end-1] .+ w[end]  :550 */
@@ -610,7 +659,7 @@ static double loss1_impl(const orc_model *m, const float *feats, const int32_t *
                 G->bout[v] += (float)a;
             }
             gemm_cm(0, 1, B, H, V, dlog, B, m->Wout, H, 1.0f, dh, B); /* dh holds the recurrent part */
-            lstm_bwd(m->W1, X, H, B, t->xh, t->g, t->cp, t->c, dh, dc, dxh, dcp, G->W1, G->b1, dz);
+            lstm_bwd(m->W1, X, H, B, t->xh, t->g, t->cp, t->c, dh, dc, dxh, dcp, G->W1, G->b1, dz, 0);
             memcpy(dh, dxh + (size_t)B * X, sizeof(float) * (size_t)B * H);
             memcpy(dc, dcp, sizeof(float) * (size_t)B * H);
             if (mask) {
@@ -846,6 +895,13 @@ void orc_conv3x3(const float *x, int W, int H, int Cin, int N, const float *w, c
     return;
 #endif
     const size_t plane = (size_t)W * H;
+    float *xr_ = NULL, *wr_ = NULL;
+    if (g_emu) { /* [bf16] NHWC bf16 activations and bf16 filters into the MFMA, f32 bias as the accumulator's start, bf16 result */
+        xr_ = rounded_copy(x, (int)plane, Cin * N, (int)plane);
+        wr_ = rounded_copy(w, 9, Cin * Cout, 9);
+        x = xr_;
+        w = wr_;
+    }
 #pragma omp parallel
     {
         acc_t *acc = (acc_t *)xmalloc(plane * sizeof(acc_t));
@@ -871,11 +927,13 @@ void orc_conv3x3(const float *x, int W, int H, int Cin, int N, const float *w, c
                 float *yp = y + ((size_t)n * Cout + co) * plane;
                 for (size_t p = 0; p < plane; ++p) {
                     const float v = (float)acc[p];
-                    yp[p] = (relu && v < 0.0f) ? 0.0f : v; /* relux  :725 */
+                    yp[p] = rb((relu && v < 0.0f) ? 0.0f : v); /* relux  :725 */
                 }
             }
         free(acc);
     }
+    free(xr_);
+    free(wr_);
 }
 
 void orc_pool2(const float *x, int W, int H, int C, int N, float *y) { /* poolx :726, Knet pool default 2x2/2 max */
@@ -926,6 +984,7 @@ void orc_vgg_forward(const orc_vgg *v, const float *x, int S, int N, float *feat
     const int K6 = W * H * C;
     float *f6 = (float *)xmalloc(sizeof(float) * (size_t)4096 * N);
     orc_fc(v->fc6_w, v->fc6_b, 4096, K6, N, cur, 1, f6);
+    for (size_t i = 0; i < (size_t)4096 * N; ++i) f6[i] = rb(f6[i]); /* [bf16] relu6's output is stored bf16; fc7's stays f32 */
     float *f7 = (float *)xmalloc(sizeof(float) * (size_t)4096 * N);
     orc_fc(v->fc7_w, v->fc7_b, 4096, 4096, N, f6, 0, f7);
     /* return transpose(xs)  :746  -> N x 4096 col-major */

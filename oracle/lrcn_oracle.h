@@ -135,6 +135,28 @@ void orc_vgg_forward(const orc_vgg *v, const float *x, int S, int N, float *feat
  * out: (224,224,3,N) col-major with the H<->W swap of :771, out(i,j,c,n) = img(y=j? ...) see .c */
 void orc_preprocess_u8(const uint8_t *img, int S, int N, const float mean[3], float *out);
 
+/* ---- ORC_EMULATE_BF16: the same restatement with bfloat16 rounding where the HIP library's bf16 arithmetic has it ----
+ * orc_set_emulate_bf16(1) makes every function above round (to nearest even, orc_bf16_round) exactly where liblrcn_hip.so's
+ * LRCN_BF16 LSTM path / bf16 VGG path stores or feeds a bf16 value; everything else (ORC_ACC accumulation, f32 cell state, f32 logits,
+ * double softmax / loss, f32 gradients) is untouched.  Off (default) the oracle is bit-for-bit the one tests/golden pins.
+ * Rounding points (kernel that has them in brackets; DESIGN.md section 2 repeats the list):
+ *   every contraction     both operands bf16: shadow weights = bf16(f32 master), feats, h(t-1), x, dlogits, dz ... [gemm*.hip, lstm_fused.hip]
+ *   embedding gather      bf16(bf16(Wembed[tok,:]) * multiplier)                                  [embed_gather_kernel]
+ *   LSTM-2 input          bf16(bf16(h1*Wproj) * multiplier) | bf16(x_cnn * multiplier); x_cnn itself is f32   [concat_x2_kernel]
+ *   LRCN-1f input         bf16(bf16(Wembed[tok,:]) * multiplier) | bf16(x_cnn * multiplier)                   [concat_x2_kernel]
+ *   cell forward          gates accumulate in f32, c stays f32; the activated gates kept for the reverse pass and h are bf16  [lstm_fwd_kernel]
+ *   loss head             logits f32, log-softmax f32/double, dlogits = bf16((p - onehot) * scale)            [softmax_xent*_kernel]
+ *   cell backward         dz = bf16(.), dc f32, dh f32                                                        [lstm_bwd_kernel]
+ *   dX of LSTM-2          bf16(dz2 * W2x'), then bf16(that * multiplier); d x_cnn sums the f32 products        [dx2_mask_reduce_kernel]
+ *   dX of LSTM-1          f32 (not rounded); embedding scatter in f32
+ *   image-embedding grad  bf16(d x_cnn), bf16(feats) into the contraction
+ *   convx / poolx         bf16 inputs and filters, f32 accumulation starting from the f32 bias, bf16(relu(.)); max of bf16 values
+ *   fcx                   bf16 operands; relu6's output bf16, fc7's output f32
+ * Not emulated (functions keep their f32 meaning): Adam (f32 master weights), beam search, preprocessing. */
+void orc_set_emulate_bf16(int on);
+int orc_get_emulate_bf16(void);
+float orc_bf16_round(float x);
+
 /* Number of OpenMP threads the library will use / set it (e.g. to the container's CPU share). */
 int orc_num_threads(void);
 void orc_set_num_threads(int n);

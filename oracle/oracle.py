@@ -100,11 +100,44 @@ def lib(fast=False):
         L.orc_vgg_forward.argtypes = [C.POINTER(_Vgg), _fp, C.c_int, C.c_int, _fp]
         L.orc_preprocess_u8.restype = None
         L.orc_preprocess_u8.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.c_int, _fp, _fp]
+        L.orc_set_emulate_bf16.restype = None
+        L.orc_set_emulate_bf16.argtypes = [C.c_int]
+        L.orc_get_emulate_bf16.restype = C.c_int
+        L.orc_bf16_round.restype = C.c_float
+        L.orc_bf16_round.argtypes = [C.c_float]
         L.orc_num_threads.restype = C.c_int
         L.orc_set_num_threads.restype = None
         L.orc_set_num_threads.argtypes = [C.c_int]
         _LIBS[key] = L
     return _LIBS[key]
+
+
+class emulate_bf16:
+    """`with orc.emulate_bf16():` -- the checker rounds to bfloat16 wherever the HIP library's bf16 arithmetic does
+    (ORC_EMULATE_BF16, lrcn_oracle.h).  Outside the block the oracle is the plain fp32-storage restatement again."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.prev = lib().orc_get_emulate_bf16()
+        lib().orc_set_emulate_bf16(int(self.on))
+        return self
+
+    def __exit__(self, *exc):
+        lib().orc_set_emulate_bf16(self.prev)
+        return False
+
+
+def bf16_round(a):
+    """Round a float32 array to bfloat16 (nearest even), returned as float32 -- numpy twin of orc_bf16_round."""
+    a = np.ascontiguousarray(np.asarray(a, np.float32))
+    u = a.view(np.uint32).astype(np.uint64)
+    nan = (u & 0x7FFFFFFF) > 0x7F800000
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)
+    out = r.view(np.float32).reshape(a.shape).copy()
+    out[nan.reshape(a.shape)] = a[nan.reshape(a.shape)]
+    return out
 
 
 def _f(a):

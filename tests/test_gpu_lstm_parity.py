@@ -1,6 +1,7 @@
 """GPU: the HIP LSTM/loss/gradient/Adam/beam path (through the C ABI) against the golden vectors and the CPU oracle.
 fp32 tolerances: loss |d|/loss <= 1e-5; gradients max-abs <= 1e-5 + 1e-3*|g|.
-bf16: loss <= 2e-2 relative."""
+bf16: loss <= 2e-2 relative to the f32 oracle (north_star's stated tolerance) AND -- every kernel route -- loss 1e-6 / all nine
+gradients elementwise (rtol 5e-3) against the bf16-EMULATING oracle (tests/parity_util.py)."""
 import os
 
 import numpy as np
@@ -10,6 +11,7 @@ import torch
 import lrcn_amd
 from lrcn_amd import lrcn as L
 from oracle import oracle as orc
+from parity_util import assert_bf16_matches_emulation, emulated_reference
 
 pytestmark = pytest.mark.gpu
 
@@ -158,12 +160,10 @@ def test_config1_shape_vs_oracle_fp32_and_bf16():
     ctx.close()
     ctx16 = L.Context(E, H1, H2, V, max_B=B, max_T=T, lstm_dtype=lrcn_amd.LRCN_BF16)
     grads16, val16 = L.lossgradient(ctx16, param, L.to_jl(feats), tokens)
-    assert abs(val16 - ref_loss) <= 2e-2 * abs(ref_loss)
-    # bf16 gradients: direction agrees (cosine) -- the tolerance north_star states is on the loss
-    for n, g in zip(orc.PARAM_NAMES, grads16):
-        a, b = L.from_jl(g).ravel().astype(np.float64), ref_g.p[n].ravel().astype(np.float64)
-        cos = a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30)
-        assert cos > 0.99, (n, cos)
+    assert abs(val16 - ref_loss) <= 2e-2 * abs(ref_loss)  # the tolerance north_star states (on the loss, against fp32)
+    emu_loss, emu_g = emulated_reference(m, feats, tokens)
+    assert_bf16_matches_emulation(val16, grads16, emu_loss, emu_g, "config-1 shape")
+    ctx16.close()
 
 
 @pytest.mark.parametrize("B,T,E,H,V", [(5, 0, 24, 40, 31), (3, 1, 52, 36, 97), (37, 6, 100, 72, 1003), (9, 27, 64, 64, 130)])
@@ -196,7 +196,8 @@ def test_bf16_recurrent_gemms_on_skinny_kernel(B, T, monkeypatch):
     m = orc.init_weights(E, H1, H2, V, seed=3)
     feats = (rng.standard_normal((B, 4096)) * 0.01).astype(np.float32)
     tokens = rng.integers(3, V, size=(T, B)).astype(np.int32)
-    ref_loss, ref_g = orc.loss(m, feats, tokens, want_grad=True)
+    ref_loss = orc.loss(m, feats, tokens)
+    emu_loss, emu_g = emulated_reference(m, feats, tokens)
     param = L.model_from_arrays(m.p)
     res = {}
     for knob in ("1", "0"):
@@ -207,9 +208,7 @@ def test_bf16_recurrent_gemms_on_skinny_kernel(B, T, monkeypatch):
         res[knob] = (val, [L.from_jl(g).astype(np.float64) for g in grads])
         ctx.close()
         assert abs(val - ref_loss) <= 2e-2 * abs(ref_loss)
-        for n, g in zip(orc.PARAM_NAMES, res[knob][1]):
-            a, b = g.ravel(), ref_g.p[n].ravel().astype(np.float64)
-            assert a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30) > 0.99, n
+        assert_bf16_matches_emulation(val, res[knob][1], emu_loss, emu_g, "skinny/fused=%s B=%d" % (knob, B))
     assert abs(res["1"][0] - res["0"][0]) <= 2e-3 * abs(ref_loss)
     for a, b in zip(res["1"][1], res["0"][1]):
         assert np.linalg.norm(a - b) <= 3e-2 * np.linalg.norm(b) + 1e-12
@@ -225,7 +224,8 @@ def test_bf16_time_batched_gemms_on_phase_interleaved_kernel(monkeypatch):
     m = orc.init_weights(E, H1, H2, V, seed=9)
     feats = (rng.standard_normal((B, 4096)) * 0.01).astype(np.float32)
     tokens = rng.integers(3, V, size=(T, B)).astype(np.int32)
-    ref_loss, ref_g = orc.loss(m, feats, tokens, want_grad=True)
+    ref_loss = orc.loss(m, feats, tokens)
+    emu_loss, emu_g = emulated_reference(m, feats, tokens)
     param = L.model_from_arrays(m.p)
     res = {}
     for knob in ("force", "0"):
@@ -235,9 +235,7 @@ def test_bf16_time_batched_gemms_on_phase_interleaved_kernel(monkeypatch):
         res[knob] = (val, [L.from_jl(g).astype(np.float64) for g in grads])
         ctx.close()
         assert abs(val - ref_loss) <= 2e-2 * abs(ref_loss)
-        for n, g in zip(orc.PARAM_NAMES, res[knob][1]):
-            a, b = g.ravel(), ref_g.p[n].ravel().astype(np.float64)
-            assert a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30) > 0.99, n
+        assert_bf16_matches_emulation(val, res[knob][1], emu_loss, emu_g, "LRCN_8P=%s" % knob)
     assert abs(res["force"][0] - res["0"][0]) <= 2e-3 * abs(ref_loss)
     for a, b in zip(res["force"][1], res["0"][1]):
         assert np.linalg.norm(a - b) <= 3e-2 * np.linalg.norm(b) + 1e-12
@@ -335,7 +333,8 @@ def test_recurrence_kernel_routes_by_batch_size_vs_oracle_bf16(B):
     tokens = rng.integers(0, V, size=(T, B)).astype(np.int32)
     mask1 = ((rng.random((T + 1, B, E)) > 0.3) / 0.7).astype(np.float32)
     mask2 = ((rng.random((T + 1, B, H)) > 0.3) / 0.7).astype(np.float32)
-    ref_loss, ref_g = orc.loss(m, feats, tokens, mask1=mask1, mask2=mask2, want_grad=True)
+    ref_loss = orc.loss(m, feats, tokens, mask1=mask1, mask2=mask2)
+    emu_loss, emu_g = emulated_reference(m, feats, tokens, mask1=mask1, mask2=mask2)
     ctx = L.Context(E, H, H, V, max_B=B, max_T=T, lstm_dtype=lrcn_amd.LRCN_BF16, vgg_dtype=lrcn_amd.LRCN_BF16, max_images=1 if beside else 0)
     if beside:
         L.vgg_load(ctx, *L.synthetic_vgg_weights(seed=1))
@@ -348,16 +347,9 @@ def test_recurrence_kernel_routes_by_batch_size_vs_oracle_bf16(B):
             grads, val = L.lossgradient(ctx, L.model_from_arrays(m.p), L.to_jl(feats), tokens, mask1=mask1, mask2=mask2)
         finally:
             del os.environ["LRCN_LSTM_EPI"]
-        assert abs(val - val0) <= 2e-3 * abs(val0)
-        for n, g, g0 in zip(orc.PARAM_NAMES, grads, grads0):
-            a, b = L.from_jl(g).ravel().astype(np.float64), L.from_jl(g0).ravel().astype(np.float64)
-            assert np.linalg.norm(a - b) <= 2e-2 * np.linalg.norm(b) + 1e-12, n
+        assert_bf16_matches_emulation(val0, grads0, emu_loss, emu_g, "beside the convolutions, B=%d" % B)
     assert abs(val - ref_loss) <= 2e-2 * abs(ref_loss), (B, val, ref_loss)
-    for n, g in zip(orc.PARAM_NAMES, grads):
-        a, b = L.from_jl(g).ravel().astype(np.float64), ref_g.p[n].ravel().astype(np.float64)
-        cos = a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30)
-        rel = np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30)
-        assert cos > 0.995 and rel < 0.1, (B, n, cos, rel)
+    assert_bf16_matches_emulation(val, grads, emu_loss, emu_g, "B=%d%s" % (B, " (cell-epilogue route)" if beside else ""))
     ctx.close()
 
 
@@ -375,7 +367,8 @@ def test_fused_recurrence_small_batch_forms_equal_ring_forms(B, H, monkeypatch):
     m = orc.init_weights(E, H, H, V, seed=5)
     feats = (rng.standard_normal((B, 4096)) * 0.05).astype(np.float32)
     tokens = rng.integers(0, V, size=(T, B)).astype(np.int32)
-    ref_loss, ref_g = orc.loss(m, feats, tokens, want_grad=True)
+    ref_loss = orc.loss(m, feats, tokens)
+    emu_loss, emu_g = emulated_reference(m, feats, tokens)
     res = {}
     for knob in ("128", "0"):
         monkeypatch.setenv("LRCN_LSTM_REC2", knob)
@@ -384,9 +377,44 @@ def test_fused_recurrence_small_batch_forms_equal_ring_forms(B, H, monkeypatch):
         res[knob] = (val, [L.from_jl(g).astype(np.float64) for g in grads])
         ctx.close()
         assert abs(val - ref_loss) <= 2e-2 * abs(ref_loss)
-        for n, g in zip(orc.PARAM_NAMES, res[knob][1]):
-            a, b = g.ravel(), ref_g.p[n].ravel().astype(np.float64)
-            assert a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30) > 0.99, (knob, n)
+        assert_bf16_matches_emulation(val, res[knob][1], emu_loss, emu_g, "LRCN_LSTM_REC2=%s B=%d H=%d" % (knob, B, H))
     assert abs(res["128"][0] - res["0"][0]) <= 1e-4 * abs(ref_loss)
     for n, a, b in zip(orc.PARAM_NAMES, res["128"][1], res["0"][1]):
         assert np.linalg.norm(a - b) <= 1e-2 * np.linalg.norm(b) + 1e-12, n
+
+
+def test_bf16_full_c4_dimensions_vs_emulating_oracle():
+    # BASELINE configs[3] dimensions (E = H = 1000, V = 10640: K = 1000 padded to 1024, 4H = 4000 -> 4032, V -> 10688) on a row subset the
+    # oracle finishes in seconds (32 rows = one rank of 8, T = 3), device-independent dropout masks: loss and all nine gradients
+    # elementwise against the bf16-emulating oracle.  (tests/test_gpu_fullsize.py covers B = 256, T = 11 through size-independent
+    # properties; this is the oracle comparison at the benchmark's own dimensions.)
+    rng = np.random.default_rng(32)
+    E = H = 1000
+    V, B, T = 10640, 32, 3
+    m = orc.init_weights(E, H, H, V, seed=42)
+    feats = (rng.standard_normal((B, 4096)) * 0.05).astype(np.float32)
+    tokens = rng.integers(0, V, size=(T, B)).astype(np.int32)
+    mask1 = ((rng.random((T + 1, B, E)) > 0.4) / 0.6).astype(np.float32)
+    mask2 = ((rng.random((T + 1, B, H)) > 0.4) / 0.6).astype(np.float32)
+    emu_loss, emu_g = emulated_reference(m, feats, tokens, norm_B=256, mask1=mask1, mask2=mask2)
+    ctx = L.Context(E, H, H, V, max_B=B, max_T=T, lstm_dtype=lrcn_amd.LRCN_BF16)
+    grads, val = L.lossgradient(ctx, L.model_from_arrays(m.p), L.to_jl(feats), tokens, norm_B=256, mask1=mask1, mask2=mask2)
+    assert_bf16_matches_emulation(val, grads, emu_loss, emu_g, "C4 dimensions, 32 of 256 rows")
+    ctx.close()
+
+
+def test_emulation_is_needed_for_the_tight_bound():
+    # the same bf16 result does NOT meet the elementwise bound against the plain f32 oracle (the bound is about rounding points, not
+    # loose enough to pass by accident): guards the tolerance itself
+    rng = np.random.default_rng(3)
+    E = H = 256
+    V, B, T = 1000, 24, 5
+    m = orc.init_weights(E, H, H, V, seed=7)
+    feats = (rng.standard_normal((B, 4096)) * 0.05).astype(np.float32)
+    tokens = rng.integers(0, V, size=(T, B)).astype(np.int32)
+    f32_loss, f32_g = orc.loss(m, feats, tokens, want_grad=True)
+    ctx = L.Context(E, H, H, V, max_B=B, max_T=T, lstm_dtype=lrcn_amd.LRCN_BF16)
+    grads, val = L.lossgradient(ctx, L.model_from_arrays(m.p), L.to_jl(feats), tokens)
+    with pytest.raises(AssertionError):
+        assert_bf16_matches_emulation(val, grads, f32_loss, f32_g, "against the un-emulated oracle")
+    ctx.close()

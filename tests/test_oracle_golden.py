@@ -4,6 +4,7 @@ import os
 
 import numpy as np
 import pytest
+import torch
 
 from oracle import oracle as orc
 
@@ -207,3 +208,120 @@ def test_fast_baseline_build_matches_the_checker_build():
     assert abs(l1 - l0) <= 1e-6 * abs(l0)
     for n in orc.PARAM_NAMES:
         np.testing.assert_allclose(g1.p[n], g0.p[n], rtol=1e-3, atol=1e-6, err_msg=n)
+
+
+# ---- ORC_EMULATE_BF16 (oracle/lrcn_oracle.h): the rounding points of the HIP library's bf16 arithmetic, restated ----
+def test_bf16_round_is_round_to_nearest_even():
+    cases = np.array([1.0, 1.00390625, 1.005859375, 1.001953125, 1.998046875, -3.1415927, 1e-40, 65504.0, 3.3895314e38, 0.0, -0.0], np.float32)
+    got = orc.bf16_round(cases)
+    want = torch.as_tensor(cases).to(torch.bfloat16).to(torch.float32).numpy()
+    np.testing.assert_array_equal(got.view(np.uint32), want.view(np.uint32))
+    rng = np.random.default_rng(0)
+    x = (rng.standard_normal(200000) * np.exp(rng.uniform(-30, 30, 200000))).astype(np.float32)
+    np.testing.assert_array_equal(orc.bf16_round(x), torch.as_tensor(x).to(torch.bfloat16).to(torch.float32).numpy())
+    for v in (1.0, 1.005859375, -2.71828, 1e-3):
+        assert orc.lib().orc_bf16_round(v) == orc.bf16_round(np.float32(v))
+    assert np.isnan(orc.bf16_round(np.array([np.nan], np.float32)))[0]
+
+
+def _np_forward_emulated(m, feats, tokens, mask1, mask2):
+    """Forward pass of loss() with the bf16 rounding points, written independently of the C code (numpy, float64 contractions):
+    per-step logits (T+1, B, V).  Statement of WHERE the HIP library rounds (lrcn_oracle.h lists the same points)."""
+    rb = orc.bf16_round
+    f64 = np.float64
+    E, H1, H2, V = m.E, m.H1, m.H2, m.V
+    hh = H2 // 2
+    W = {n: rb(m.p[n]).astype(f64) for n in ("W1", "W2", "Wproj", "Wcnn", "Wembed", "Wout")}
+    T, B = tokens.shape
+    sig = lambda z: (np.float32(1) / (np.float32(1) + np.exp(-z, dtype=np.float32))).astype(np.float32)
+    xcnn = (rb(feats).astype(f64) @ W["Wcnn"]).astype(np.float32)                     # f32, not rounded
+    h1 = np.zeros((B, H1), np.float32); c1 = np.zeros((B, H1), np.float32)
+    h2 = np.zeros((B, H2), np.float32); c2 = np.zeros((B, H2), np.float32)
+    out = []
+    for s in range(T + 1):
+        inp = np.full(B, orc.BOS) if s == 0 else tokens[s - 1]
+        x1 = rb(W["Wembed"][inp].astype(np.float32) * (mask1[s] if mask1 is not None else np.float32(1)))
+        g = (np.hstack([x1, rb(h1)]).astype(f64) @ W["W1"]).astype(np.float32) + m.p["b1"]
+        f, i, o, ch = sig(g[:, :H1]), sig(g[:, H1:2 * H1]), sig(g[:, 2 * H1:3 * H1]), np.tanh(g[:, 3 * H1:])
+        c1 = c1 * f + i * ch
+        h1 = o * np.tanh(c1)
+        left = rb((rb(h1).astype(f64) @ W["Wproj"]).astype(np.float32))
+        x2 = np.hstack([left, xcnn])
+        x2 = rb(x2 * (mask2[s] if mask2 is not None else np.float32(1)))
+        g = (np.hstack([x2, rb(h2)]).astype(f64) @ W["W2"]).astype(np.float32) + m.p["b2"]
+        f, i, o, ch = sig(g[:, :H2]), sig(g[:, H2:2 * H2]), sig(g[:, 2 * H2:3 * H2]), np.tanh(g[:, 3 * H2:])
+        c2 = c2 * f + i * ch
+        h2 = o * np.tanh(c2)
+        out.append((rb(h2).astype(f64) @ W["Wout"]).astype(np.float32) + m.p["bout"])
+    return np.stack(out)
+
+
+def test_emulated_forward_equals_independent_numpy_statement_and_off_is_untouched():
+    rng = np.random.default_rng(4)
+    E, H1, H2, V, B, T = 40, 48, 32, 97, 6, 4
+    m = orc.init_weights(E, H1, H2, V, seed=3)
+    for n in ("W1", "W2", "Wout"):
+        m.p[n] *= 3.0
+    feats = (rng.standard_normal((B, 4096)) * 0.05).astype(np.float32)
+    tokens = rng.integers(0, V, size=(T, B)).astype(np.int32)
+    plain = orc.forward_logits(m, feats, tokens)
+    l_plain, g_plain = orc.loss(m, feats, tokens, want_grad=True)
+    with orc.emulate_bf16():
+        emu = orc.forward_logits(m, feats, tokens)
+        l_emu, g_emu = orc.loss(m, feats, tokens, want_grad=True)
+        assert orc.lib().orc_get_emulate_bf16() == 1
+    assert orc.lib().orc_get_emulate_bf16() == 0
+    np.testing.assert_array_equal(plain, orc.forward_logits(m, feats, tokens))          # the switch leaves no trace
+    l_again, g_again = orc.loss(m, feats, tokens, want_grad=True)
+    assert l_again == l_plain and all(np.array_equal(g_again.p[n], g_plain.p[n]) for n in orc.PARAM_NAMES)
+    want = _np_forward_emulated(m, feats, tokens, None, None)
+    np.testing.assert_allclose(emu, want, rtol=2e-6, atol=2e-6)
+    d = np.abs(emu - plain).max() / np.abs(plain).max()
+    assert 1e-4 < d < 3e-2, d                                                           # bf16 is visible, and small
+    assert abs(l_emu - l_plain) <= 2e-2 * abs(l_plain) and l_emu != l_plain
+    for n in orc.PARAM_NAMES:                                                           # gradients: same direction, not the same numbers
+        a, b = g_emu.p[n].ravel().astype(np.float64), g_plain.p[n].ravel().astype(np.float64)
+        assert a @ b / (np.linalg.norm(a) * np.linalg.norm(b)) > 0.999, n
+        assert not np.array_equal(g_emu.p[n], g_plain.p[n]), n
+
+
+def test_emulated_forward_with_dropout_masks_and_gradient_by_finite_differences_of_the_bias():
+    # masks: the double rounding bf16(bf16(.) * multiplier) of both halves of LSTM-2's input; d loss / d bout is exact under emulation
+    # (bout enters after the last rounding), so finite differences of the EMULATED loss must reproduce the emulated gradient
+    rng = np.random.default_rng(9)
+    E, H1, H2, V, B, T = 24, 32, 32, 53, 5, 3
+    m = orc.init_weights(E, H1, H2, V, seed=8)
+    feats = (rng.standard_normal((B, 4096)) * 0.05).astype(np.float32)
+    tokens = rng.integers(0, V, size=(T, B)).astype(np.int32)
+    mask1 = ((rng.random((T + 1, B, E)) > 0.4) / 0.6).astype(np.float32)
+    mask2 = ((rng.random((T + 1, B, H2)) > 0.4) / 0.6).astype(np.float32)
+    with orc.emulate_bf16():
+        l0, g = orc.loss(m, feats, tokens, mask1=mask1, mask2=mask2, want_grad=True)
+        want_logits = _np_forward_emulated(m, feats, tokens, mask1, mask2)
+        # loss from the independent logits
+        tg = np.vstack([tokens, np.zeros((1, B), np.int32)])
+        z = want_logits.astype(np.float64)
+        lse = np.log(np.exp(z - z.max(-1, keepdims=True)).sum(-1)) + z.max(-1)
+        l_np = -(np.take_along_axis(z, tg[..., None], -1)[..., 0] - lse).sum() / (B * (T + 1))
+        assert abs(l0 - l_np) <= 2e-6 * abs(l_np)
+        eps = 1e-2
+        for j in (0, 7, 31):
+            m.p["bout"][0, j] += eps
+            lp = orc.loss(m, feats, tokens, mask1=mask1, mask2=mask2)
+            m.p["bout"][0, j] -= 2 * eps
+            lm = orc.loss(m, feats, tokens, mask1=mask1, mask2=mask2)
+            m.p["bout"][0, j] += eps
+            # dlogits is stored as bf16 (3 significant digits) before its column sum: the gradient agrees to that
+            assert abs((lp - lm) / (2 * eps) - g.p["bout"][0, j]) <= 6e-3 * abs(g.p["bout"][0, j]) + 1e-5
+
+
+def test_emulated_conv_layer_rounds_operands_and_result():
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((6, 6, 5, 2)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 5, 4)) * 0.3).astype(np.float32)
+    b = rng.standard_normal(4).astype(np.float32)
+    plain = orc.conv3x3(orc.bf16_round(x), orc.bf16_round(w), b, relu=True)   # bf16 operands, exact accumulation, f32 result
+    with orc.emulate_bf16():
+        emu = orc.conv3x3(x, w, b, relu=True)
+    np.testing.assert_array_equal(emu, orc.bf16_round(plain))
+    assert not np.array_equal(emu, orc.conv3x3(x, w, b, relu=True))
