@@ -8,7 +8,9 @@
 Workload = BASELINE.json configs[3] / SURVEY.md 8(d) "C4": MS-COCO-shaped synthetic data, VGG-16 bf16 + LSTM
 E=H1=H2=1000 bf16 (fp32 accumulate / master weights / Adam), V=10640, T=11, GLOBAL batch 256 split by rows over the
 N ranks ("strong" scaling), dropout 0.4, one RCCL all-reduce(SUM) of the 39.8 M fp32 gradients per step.
-A step = [VGG fwd on B/N images] + lossgradient + all-reduce + update!; inputs (uint8 crops, tokens) resident in HBM.
+A step = [VGG fwd on B/N images] + lossgradient + all-reduce + update!.  Crops: pinned HOST memory, uploaded per step on a copy stream
+a step ahead of the forward that reads them (--inputs host, the default: BASELINE.md section 3 / lrcn.jl:369-376) or resident in HBM
+(--inputs hbm); tokens resident.
 The VGG forward of step k+1 runs on a side HIP stream beside the LSTM work of step k (dp.py).  The timed region is the pipeline
 in steady state: each of its K steps issues one VGG forward (of the next batch) and one LSTM step, K of each in total.
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
@@ -105,12 +107,14 @@ def cpu_baseline(vgg_w, E, H, V, T, rng, n_layers=2):
                   "ref_grads": g}
 
 
-def parity_spot_check(ctx, L, sample, batch_imgs):
+def parity_spot_check(ctx, L, sample, batch_imgs, dtype="bf16"):
     """The cpu_baseline sample through the HIP path of THIS context: the 4 crops replace the first rows of one of the
     benchmark's own image batches, so the VGG forward runs at the benchmark's batch size with the benchmark's kernels and
-    routes (reported); loss + gradients of the 16 captions against the oracle's.  Not timed."""
+    routes (reported); loss + gradients of the 16 captions against the oracle's.  bf16: additionally against the bf16-EMULATING
+    oracle (oracle/lrcn_oracle.h ORC_EMULATE_BF16, the checker build), elementwise -- the bound of tests/parity_util.py.  Not timed."""
     import numpy as np
     import torch
+    from oracle import oracle as orc
     imgs = batch_imgs.clone()
     n = min(sample["img"].shape[0], imgs.shape[0])
     imgs[:n] = torch.as_tensor(sample["img"][:n]).cuda()
@@ -125,9 +129,23 @@ def parity_spot_check(ctx, L, sample, batch_imgs):
             continue
         a, b = L.from_jl(g).ravel().astype(np.float64), sample["ref_grads"].p[n].ravel().astype(np.float64)
         cos.append(float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-300)))
-    return {"vgg_rel_max_err": vgg_err, "n_images": int(ref.shape[0]), "vgg_routes": L.debug_route(ctx, 1),
-            "loss_rel_err": float(abs(val - sample["ref_loss"]) / abs(sample["ref_loss"])), "n_captions": int(sample["tokens"].shape[1]),
-            "grad_cos_min": min(cos), "checker": "oracle (liblrcn_cpu_f32.so) on the cpu_baseline sample"}
+    out = {"vgg_rel_max_err": vgg_err, "n_images": int(ref.shape[0]), "vgg_routes": L.debug_route(ctx, 1),
+           "loss_rel_err": float(abs(val - sample["ref_loss"]) / abs(sample["ref_loss"])), "n_captions": int(sample["tokens"].shape[1]),
+           "grad_cos_min": min(cos), "checker": "oracle (liblrcn_cpu_f32.so) on the cpu_baseline sample"}
+    if dtype == "bf16":
+        with orc.emulate_bf16():
+            e_loss, e_g = orc.loss(m, sample["feats"], sample["tokens"], want_grad=True)
+        worst, norm = 0.0, 0.0
+        for n, g in zip(L.PARAM_NAMES, grads):
+            if g.numel() == 0:
+                continue
+            a, b = L.from_jl(g).astype(np.float64), e_g.p[n].astype(np.float64)
+            worst = max(worst, float((np.abs(a - b) / (5e-3 * np.abs(b) + 2.5e-3 * np.abs(b).max())).max()))
+            norm = max(norm, float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-300)))
+        out["bf16_emulation"] = {"loss_rel_err": float(abs(val - e_loss) / abs(e_loss)), "grad_worst_over_tol": worst, "grad_rel_norm_max": norm,
+                                 "tol": "per element |d| <= 5e-3 |ref| + 2.5e-3 max|ref| (worst_over_tol <= 1), per tensor ||d|| <= 3e-3 ||ref||",
+                                 "checker": "bf16-emulating oracle (liblrcn_oracle.so, orc_set_emulate_bf16) on the same 16 captions"}
+    return out
 
 
 PRESETS = {  # BASELINE.json configs[k] -> flags (SURVEY.md 8d "Config -> shapes"); c4 is the headline and the default
@@ -153,6 +171,9 @@ def parse_args(argv=None):
     ap.add_argument("--pdrop", type=float, default=0.4)
     ap.add_argument("--layers", type=int, default=None, choices=[1, 2])  # 1 = LRCN-1f (this repo's definition of configs[1]'s "1-layer LSTM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inputs", default="host", choices=["host", "hbm"],
+                    help="where a step finds its crops: 'host' (default; BASELINE.md section 3) = pinned host memory, uploaded per step on the library's "
+                         "copy stream one step ahead of the VGG forward that reads them (lrcn_upload_crops); 'hbm' = already resident in device memory")
     ap.add_argument("--emulate-world", type=int, default=1,
                     help="ONE process runs rank 0's shard of an N-rank job (global batch / N rows, the GLOBAL normaliser, no collective): the "
                          "per-rank step that bounds the N-GPU number, measurable on one GPU.  Labelled; NOT the headline metric.")
@@ -194,8 +215,10 @@ def workload_name(a):
 HEADLINE_METRIC = "training images/sec (VGG16+LSTM, COCO, batch 256) at 1/2/4/8 MI355X"
 
 
-def metric_name(a):
+def metric_name(a, fake_multi=False):
     w = workload_name(a)
+    if fake_multi:
+        return "VALIDATION (%d ranks sharing ONE GPU over gloo) -- not a measurement; would be: %s" % (a.gpus, metric_name(a))
     if a.emulate_world > 1:
         return "EMULATED rank-0 step of a %d-rank job (%d of %d rows, global normaliser, no collective) -- not the headline" % (
             a.emulate_world, a.global_batch // a.emulate_world, a.global_batch)
@@ -230,21 +253,41 @@ def launch(a, argv):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
                "--master-port", str(find_free_port()), os.path.abspath(__file__)] + child_argv
         proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True, start_new_session=True)
-        try:
-            out, _ = proc.communicate(timeout=a.watchdog_s)
-            rc = proc.returncode
-        except subprocess.TimeoutExpired:
-            # the exact process group started above, nothing else
+
+        def stop_job():
+            """End the ranks: the exact process group started above (its own session), nothing else.  Runs on EVERY way out of the wait
+            below -- watchdog, SIGTERM / SIGINT to this parent, any exception -- so that no rank is left holding a GPU."""
+            if proc.poll() is not None:
+                return
             try:
                 os.killpg(proc.pid, signal.SIGTERM)
-                time.sleep(3)
+                for _ in range(30):
+                    if proc.poll() is not None:
+                        break
+                    time.sleep(0.1)
                 os.killpg(proc.pid, signal.SIGKILL)
-            except ProcessLookupError:
+            except (ProcessLookupError, PermissionError):
                 pass
-            out, _ = proc.communicate()
-            rc = 124
-            print("bench.py: the %d-rank job (dp backend %s) did not finish within %.0f s and was stopped" % (a.gpus, backend, a.watchdog_s),
-                  file=sys.stderr)
+
+        def on_signal(signum, _frame):
+            stop_job()
+            raise SystemExit(128 + signum)
+
+        old = {sg: signal.signal(sg, on_signal) for sg in (signal.SIGTERM, signal.SIGINT)}
+        try:
+            try:
+                out, _ = proc.communicate(timeout=a.watchdog_s)
+                rc = proc.returncode
+            except subprocess.TimeoutExpired:
+                stop_job()
+                out, _ = proc.communicate()
+                rc = 124
+                print("bench.py: the %d-rank job (dp backend %s) did not finish within %.0f s and was stopped" % (a.gpus, backend, a.watchdog_s),
+                      file=sys.stderr)
+        finally:
+            stop_job()   # no-op when the job has ended
+            for sg, h in old.items():
+                signal.signal(sg, h)
         lines = [ln for ln in (out or "").splitlines() if ln.startswith("{") and '"metric"' in ln]
         if rc == 0 and lines:
             line = json.loads(lines[-1])
@@ -269,6 +312,10 @@ def dryrun_main(a, world, rank):
     import dp_oracle_ops as doo
     if os.environ.get("LRCN_BENCH_DRYRUN_FAIL_ABI") and os.environ.get("LRCN_DP_BACKEND") == "abi":
         raise SystemExit("dry run: simulated failure of the C-ABI communicator")
+    if os.environ.get("LRCN_BENCH_DRYRUN_HANG"):   # a rank stuck in a collective: the file named here receives its pid, then it sleeps
+        with open(os.environ["LRCN_BENCH_DRYRUN_HANG"] + ".%d" % rank, "w") as f:
+            f.write(str(os.getpid()))
+        time.sleep(3600)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -383,8 +430,10 @@ def main(argv=None):
     g = torch.Generator(device="cuda")
     g.manual_seed(1234)
     n_sets = 2
-    imgs_all = [torch.randint(0, 256, (Bg, 224, 224, 3), generator=g, device="cuda", dtype=torch.uint8)[rows].contiguous()
+    imgs_dev = [torch.randint(0, 256, (Bg, 224, 224, 3), generator=g, device="cuda", dtype=torch.uint8)[rows].contiguous()
                 for _ in range(n_sets)]
+    # --inputs host: the same crops in page-locked host memory; every step uploads the batch AFTER next on the copy stream
+    imgs_all = [t.cpu().pin_memory() for t in imgs_dev] if a.inputs == "host" else imgs_dev
     rng = np.random.default_rng(7)
     pz = 1.0 / np.arange(1, V - 3 + 1)
     pz /= pz.sum()
@@ -392,6 +441,7 @@ def main(argv=None):
                                 .copy()).cuda() for _ in range(n_sets)]
 
     step_ev = []
+    host_t = [] if os.environ.get("LRCN_BENCH_HOST_TIMES") else None   # development: when the host ENTERED each step (issue-side timeline)
 
     def run(nsteps, events=False):
         # steady-state pipeline: EVERY step (the last one too) issues the VGG forward of the batch after it, so a run of K steps
@@ -399,7 +449,10 @@ def main(argv=None):
         # run's last step (the warm-up's, for the timed region), or in order if there is none.
         for _ in range(nsteps):
             k = trainer.step_no  # global step index: batch k uses image/token set k mod n_sets, also across warm-up -> timed region
-            trainer.step(imgs_all[k % n_sets], toks_all[k % n_sets], next_img_u8=imgs_all[(k + 1) % n_sets])
+            if host_t is not None:
+                host_t.append(time.perf_counter())
+            trainer.step(imgs_all[k % n_sets], toks_all[k % n_sets], next_img_u8=imgs_all[(k + 1) % n_sets],
+                         prefetch_img_u8=imgs_all[(k + 2) % n_sets] if a.inputs == "host" else None)
             if events:  # one event per step on the main stream (no host sync): per-step intervals -> the median SURVEY 8(d) asks for
                 e = torch.cuda.Event(enable_timing=True)
                 e.record()
@@ -419,7 +472,7 @@ def main(argv=None):
     if a.spinup_ms > 0:
         t_spin = time.perf_counter()
         while (time.perf_counter() - t_spin) * 1e3 < a.spinup_ms:
-            L.convnet_u8(ctx, imgs_all[0])
+            L.convnet_u8(ctx, imgs_dev[0])
             torch.cuda.synchronize()
             spun += 1
     run(a.warmup)
@@ -458,11 +511,12 @@ def main(argv=None):
         peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
         traffic, traffic_note = pmc_traffic(a.dtype, B)
         out = {
-            "metric": metric_name(a),
+            "metric": metric_name(a, fake_multi),
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_step, "ms_per_step_median": median_ms,
             "ms_per_step_first8": [round(x, 3) for x in step_ms_seq[:8]], "ms_per_step_last": round(step_ms_seq[-1], 3),
             **({"ms_per_step_all": [round(x, 3) for x in step_ms_seq]} if os.environ.get("LRCN_BENCH_ALL_STEPS") else {}),
+            **({"host_issue_ms_all": [round(1e3 * (host_t[i + 1] - host_t[i]), 3) for i in range(len(host_t) - 1)]} if host_t else {}),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": "%s: VGG-16 -> fc7 fwd + %s LSTM "
@@ -472,6 +526,8 @@ def main(argv=None):
                                       world, a.pdrop),
                        "global_batch": Bg, "per_gpu_batch": B, "seq_len": T + 1, "parallelism": "dp%d" % world,
                        "last_loss": loss,
+                       "inputs": ("pinned host, H2D per step on a copy stream (%.1f MB per step, uploaded one step ahead of the forward that reads it)"
+                                  % (B * 224 * 224 * 3 / 1e6)) if a.inputs == "host" else "resident in HBM",
                        "setup_spinup": "%d untimed VGG forwards (%.0f ms) before the warm-up steps; not training steps" % (spun, a.spinup_ms)},
             "rccl": {"world": world, "backend": ("none (one rank: no collective)" if world == 1 else
                                                  ("gloo on ONE shared GPU (LRCN_BENCH_FAKE_MULTI: validation, not a measurement)" if fake_multi else trainer.backend)),
@@ -491,7 +547,7 @@ def main(argv=None):
             host_w = ([L.from_jl(w) for w in vgg_w[0]], [b.cpu().numpy() for b in vgg_w[1]],
                       (L.from_jl(vgg_w[2][0]), vgg_w[2][1].cpu().numpy()), (L.from_jl(vgg_w[3][0]), vgg_w[3][1].cpu().numpy()))
             out["cpu_baseline"], sample = cpu_baseline(host_w, E, H, V, T, np.random.default_rng(3), a.layers)
-            out["parity"] = parity_spot_check(ctx, L, sample, imgs_all[0])
+            out["parity"] = parity_spot_check(ctx, L, sample, imgs_dev[0], a.dtype)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

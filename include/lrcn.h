@@ -79,9 +79,9 @@ int lrcn_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
 int lrcn_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
 const char *lrcn_version(void);
 /* ABI revision of this header.  It changes whenever a struct layout or an existing signature changes (lrcn_config gained its trailing
- * n_layers field at revision 2; revision 3 added the entry points marked "rev 3").  A binding compiled against another revision must
- * refuse to run: lrcn_create reads sizeof(lrcn_config) bytes of the caller's struct. */
-#define LRCN_ABI_VERSION 3
+ * n_layers field at revision 2; revision 3 added the entry points marked "rev 3", revision 4 those marked "rev 4").  A binding compiled
+ * against another revision must refuse to run: lrcn_create reads sizeof(lrcn_config) bytes of the caller's struct. */
+#define LRCN_ABI_VERSION 4
 int lrcn_abi_version(void);
 /* Options (rev 3).  Returns LRCN_EINVAL for an unknown option or a value outside its range.
  *   LRCN_OPT_FUSED_UPDATE (0 | 1, default 0): lrcn_train_step / lrcn_train_step_dp write the NEXT step's K-contiguous shadow weights
@@ -243,6 +243,20 @@ int lrcn_set_average_image(lrcn_ctx *ctx, const float *average_image);
  * (round half up); Images.imresize's own kernel is not pinned by the reference. */
 int lrcn_resize_crop_u8(lrcn_ctx *ctx, const uint8_t *src, const int64_t *offsets, const int *heights, const int *widths,
                         const int *channels, int N, uint8_t *out);
+/* ---- input feed (rev 4): the per-batch host -> device copy of the reference's training loop (lrcn.jl:369-376 uploads every batch's
+ * inputs), moved off the critical path.  lrcn_upload_crops copies N decoded crops (uint8 [N][224][224][3], HOST memory; page-locked memory
+ * -- lrcn_host_alloc -- makes the copy a true asynchronous DMA) on the context's own copy stream into one of THREE device staging buffers and
+ * returns that buffer in *dev_out.  The pointer is accepted wherever device crops are (lrcn_vgg_forward_u8, lrcn_train_step_dp,
+ * lrcn_vgg_calibrate): such a forward waits ON THE DEVICE for the upload, and a later upload into the same staging buffer waits for the
+ * forward's first kernel (the only one that reads the crops).  Uploads may run at most three batches ahead of the forwards that consume them
+ * (LRCN_ESTATE otherwise); the call returns at once unless the host is more than two batches ahead of the DEVICE: it then waits, on the
+ * calling thread, until the forward that last read the staging buffer has started (a bound on the run-ahead, not a cost; the copy stream
+ * never carries a device-side wait for a future event, which would stall compute streams sharing its hardware queue).  The host buffer must stay valid and unchanged until the copy has run:
+ * lrcn_upload_wait blocks until every upload issued so far has finished (what a loader thread calls before refilling its buffer). */
+int lrcn_host_alloc(void **host_ptr, size_t bytes);
+int lrcn_host_free(void *host_ptr);
+int lrcn_upload_crops(lrcn_ctx *ctx, const uint8_t *host_u8, int N, const uint8_t **dev_out);
+int lrcn_upload_wait(lrcn_ctx *ctx);
 /* feats (N x 4096 column-major, device) <- every row divided by its sum: generate's `input/sum(input)` (lrcn.jl:595-597) and
  * what the reference's training features (`featsn`, lrcn.jl:121-123) hold. */
 int lrcn_normalize_features(lrcn_ctx *ctx, float *feats, int N);

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("LRCN_HIP_LIB") or os.path.join(CSRC, "liblrcn_hip.so"
 HEADER = os.path.normpath(os.path.join(HERE, "..", "include", "lrcn.h"))
 
 LRCN_F32, LRCN_BF16, LRCN_FP8 = 0, 1, 2
-LRCN_ABI_VERSION = 3   # include/lrcn.h: the revision this binding's struct layouts and signatures were written against
+LRCN_ABI_VERSION = 4   # include/lrcn.h: the revision this binding's struct layouts and signatures were written against
 LRCN_OPT_FUSED_UPDATE, LRCN_OPT_DETERMINISTIC, LRCN_OPT_CONV_CHUNK_BYTES = 1, 2, 3
 EOS, BOS, UNK = 0, 1, 2
 CNNOUT = 4096
@@ -95,6 +95,10 @@ SIGNATURES = {
     "lrcn_resize_crop_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                       C.c_int, C.c_void_p]),
     "lrcn_normalize_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "lrcn_host_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "lrcn_host_free": (C.c_int, [C.c_void_p]),
+    "lrcn_upload_crops": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "lrcn_upload_wait": (C.c_int, [C.c_void_p]),
     "lrcn_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "lrcn_profile_get": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "lrcn_debug_stamps": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int64]),

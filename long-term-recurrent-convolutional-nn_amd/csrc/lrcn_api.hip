@@ -66,6 +66,7 @@ struct lrcn_ctx {
     bool opt_fused = false, opt_det = false;
     int64_t conv_chunk_bytes = 0;           // LRCN_OPT_CONV_CHUNK_BYTES (0 = default)
     unsigned fused_groups = 0;              // gradient groups whose fused Adam has been issued in the current step (bit per group)
+    int fused_step = 0;                     // the `step` those bits belong to: a call with another step starts a new mask
     bool shadow_valid = false;              // the current set holds the shadows (direct AND transposed) of the parameters at shadow_p
     const float *shadow_p[9] = {};
     float *dWe_rm = nullptr;                // [V][ldE] f32, all zero between calls: row-major staging of the embedding gradient
@@ -134,6 +135,22 @@ struct lrcn_ctx {
     unsigned long long *stamps = nullptr;  // kernel-development: per-tile segment stamps (LRCN_STAMPS=1, lrcn_debug_stamps)
     int64_t stamps_n = 0;
     int *tile_ctr = nullptr;  // per-layer work queues of the capped persistent convolution grids (GemmArgs::tile_ctr)
+    // input feed (lrcn_upload_crops): uint8 crops travel host -> HBM on the context's own copy stream into one of kStage staging buffers,
+    // beside the running step; a VGG forward that is handed a staging buffer waits (on the device) for its upload, and the upload into a
+    // staging buffer waits for the one kernel of the forward that last read it (the crops are consumed by the forward's FIRST kernel).
+    // The copy stream never carries a device-side wait for a read that has not happened yet.  Measured (bench.py, host 4 steps ahead of the
+    // device, which is where it runs when nothing holds it back): a hipStreamWaitEvent on an event one or two steps in the device's future
+    // is a barrier packet at the head of a HARDWARE queue that the copy stream shares with compute streams (HIP maps its streams onto a few
+    // hardware queues) -- kernels queued behind it stall, and the step ran 8.5 instead of 7.0 ms until the host happened to fall back.  So an
+    // upload whose staging buffer is still unread BLOCKS THE CALLING THREAD (hipEventSynchronize) and then queues a copy with no dependency.
+    // With kStage buffers that happens only when the host is more than kStage - 1 steps ahead of the device: a bound on the run-ahead.
+    static constexpr int kStage = 3;
+    hipStream_t copy_stream = nullptr;
+    uint8_t *stage[kStage] = {};
+    hipEvent_t up_done[kStage] = {}, rd_done[kStage] = {};
+    bool stage_full[kStage] = {};   // holds crops that no forward has been issued on yet
+    bool stage_read[kStage] = {};   // rd_done[j] has been recorded at least once
+    int stage_next = 0;
     LrcnComm *comm = nullptr;
     hipStream_t comm_stream = nullptr;  // every collective of the communicator is issued on this ONE stream, in group order
     hipStream_t bucket[LRCN_GRAD_GROUPS] = {};
@@ -815,7 +832,7 @@ void ctx_sizes(const lrcn_ctx *c, int64_t sz[9]) { lrcn_param_sizes_n(c->nl, c->
 // =====================================================================================================
 extern "C" {
 
-const char *lrcn_version(void) { return "lrcn-hip 0.3 (gfx950)"; }
+const char *lrcn_version(void) { return "lrcn-hip 0.4 (gfx950)"; }
 int lrcn_abi_version(void) { return LRCN_ABI_VERSION; }
 
 int lrcn_set_option(lrcn_ctx *c, int option, int64_t value) {
@@ -847,6 +864,7 @@ int lrcn_set_option(lrcn_ctx *c, int option, int64_t value) {
 int lrcn_params_touched(lrcn_ctx *c) {
     if (!c) return LRCN_EINVAL;
     c->shadow_valid = false;
+    c->fused_groups = 0;  // a per-group update that stopped partway must not complete a later step's mask
     return LRCN_OK;
 }
 
@@ -892,6 +910,11 @@ void lrcn_destroy(lrcn_ctx *c) {
     if (c->wg_done) (void)hipEventDestroy(c->wg_done);
     if (c->pin) (void)hipHostFree(c->pin);
     if (c->wg_stream) (void)hipStreamDestroy(c->wg_stream);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    for (int j = 0; j < lrcn_ctx::kStage; ++j) {
+        if (c->up_done[j]) (void)hipEventDestroy(c->up_done[j]);
+        if (c->rd_done[j]) (void)hipEventDestroy(c->rd_done[j]);
+    }
     comm_destroy(c->comm);
     for (auto &e : c->bucket_done)
         if (e) (void)hipEventDestroy(e);
@@ -1082,6 +1105,7 @@ int lrcn_init_weights(lrcn_ctx *c, float *const p[9], uint64_t seed) {
     }
     KCHK(c, "init_weights");
     c->shadow_valid = false;
+    c->fused_groups = 0;
     return LRCN_OK;
 }
 
@@ -1127,7 +1151,9 @@ int lrcn_adam_update(lrcn_ctx *c, float *const p[9], const float *const g[9], fl
                      float lr, float b1, float b2, float eps) {
     DeviceGuard dg(c);
     if (!c || !p || !g || !m || !v || step < 1) return LRCN_EINVAL;
+    c->fused_groups = 0;  // the whole-model update supersedes any per-group sequence left unfinished (an error between two groups)
     if (c->opt_fused) {  // LRCN_OPT_FUSED_UPDATE: the same update, and the next step's shadow weights in the same pass
+        c->shadow_valid = false;
         int r = adam_fused(c, p, g, m, v, -1, step, lr, b1, b2, eps, c->stream);
         if (r) return r;
         fused_update_done(c, p);
@@ -1158,10 +1184,17 @@ int lrcn_adam_update_group(lrcn_ctx *c, float *const p[9], const float *const g[
     if (c->opt_fused) {
         // fused with the shadow pass; the written set becomes current once all five groups of this step have been issued (they are
         // issued in any order, each exactly once per step, with the same `step`)
-        int r = adam_fused(c, p, g, m, v, group, step, lr, b1, b2, eps, stream ? reinterpret_cast<hipStream_t>(stream) : c->stream);
-        if (r) return r;
-        c->fused_groups |= 1u << group;
+        if (step != c->fused_step) {  // first group of a new step: bits left by a step that never completed do not count
+            c->fused_groups = 0;
+            c->fused_step = step;
+        }
         c->shadow_valid = false;
+        int r = adam_fused(c, p, g, m, v, group, step, lr, b1, b2, eps, stream ? reinterpret_cast<hipStream_t>(stream) : c->stream);
+        if (r) {
+            c->fused_groups = 0;
+            return r;
+        }
+        c->fused_groups |= 1u << group;
         if (c->fused_groups == (1u << LRCN_GRAD_GROUPS) - 1) {
             c->fused_groups = 0;
             fused_update_done(c, p);
@@ -1746,11 +1779,27 @@ int vgg_body(lrcn_ctx *c, int N, const void *src, bool src_u8, const float *mean
     const char *kf = getenv("LRCN_FUSE11");  // LRCN_FUSE11=0: conv1_1 and conv1_2 as two launches
     const bool fuse11 = vdt == GEMM_T_BF16 && src_u8 && c->conv[0].w_fused && conv64_enabled() && !(kf && kf[0] == '0');
     const float *avg = (src_u8 && c->avg_on) ? c->avg_img : nullptr;
+    // crops that arrived through lrcn_upload_crops: the forward's stream waits for the upload; the staging buffer is free again as soon as the
+    // ONE kernel below that reads the uint8 source has run (recorded right after it)
+    int staged = -1;
+    if (src_u8)
+        for (int j = 0; j < lrcn_ctx::kStage; ++j)
+            if (c->stage[j] && src == c->stage[j]) staged = j;
+    if (staged >= 0) HIPCHK(c, hipStreamWaitEvent(c->stream, c->up_done[staged], 0));
+    auto crops_consumed = [&]() -> int {
+        if (staged < 0) return LRCN_OK;
+        HIPCHK(c, hipEventRecord(c->rd_done[staged], c->stream));
+        c->stage_read[staged] = true;
+        c->stage_full[staged] = false;
+        staged = -1;
+        return LRCN_OK;
+    };
     if (avg && !fuse11) {
         // full averageImage outside the fused path: read_image_data's arithmetic as its own pass into a float tensor (lrcn.jl:770-771),
         // then the float-input route
         if (!c->pre_f32) DALLOC(c, c->pre_f32, sizeof(float) * (size_t)c->cfg.max_images * 224 * 224 * 3);
         k_preprocess_u8(c->stream, reinterpret_cast<const uint8_t *>(src), N, 224, 0.f, 0.f, 0.f, avg, c->pre_f32);
+        if (int r = crops_consumed()) return r;
         src = c->pre_f32;
         src_u8 = false;
     }
@@ -1791,6 +1840,8 @@ int vgg_body(lrcn_ctx *c, int N, const void *src, bool src_u8, const float *mean
         hipError_t e = launch_gemm(c->stream, g);
         if (e != hipSuccess) FAIL(c, LRCN_EHIP, "conv1_1: %s", hipGetErrorString(e));
     }
+    // (f32: the im2col pass above was the reader and the GEMM after it does not touch the crops -- recording behind it only delays the release)
+    if (int r = crops_consumed()) return r;
     if (!fuse11) note(vdt == GEMM_T_BF16 ? "conv11" : gemm_debug_last_route());
     void *cur = c->actA, *nxt = c->actB;
     // capped persistent grids (the two-stream training step): LRCN_DYN_TILES=1 makes the workgroups of a layer PULL their tiles
@@ -2064,6 +2115,50 @@ int lrcn_bench_gemm(lrcn_ctx *c, int M, int N, int K, int iters, double *ms_out)
     cleanup();
     if (r) return r;
     *ms_out = ms / iters;
+    return LRCN_OK;
+}
+
+// ---- input feed (rev 4) ----
+int lrcn_host_alloc(void **host_ptr, size_t bytes) {
+    if (!host_ptr) return LRCN_EINVAL;
+    *host_ptr = nullptr;
+    return hipHostMalloc(host_ptr, bytes ? bytes : 16, hipHostMallocDefault) == hipSuccess ? LRCN_OK : LRCN_ENOMEM;
+}
+int lrcn_host_free(void *host_ptr) { return hipHostFree(host_ptr) == hipSuccess ? LRCN_OK : LRCN_EHIP; }
+
+int lrcn_upload_crops(lrcn_ctx *c, const uint8_t *host_u8, int N, const uint8_t **dev_out) {
+    DeviceGuard dg(c);
+    if (!c || !host_u8 || !dev_out) return LRCN_EINVAL;
+    *dev_out = nullptr;
+    if (c->cfg.max_images < 1) FAIL(c, LRCN_ESTATE, "context was created with max_images = 0");
+    if (N < 1 || N > c->cfg.max_images) FAIL(c, LRCN_EINVAL, "N=%d outside [1,%d]", N, c->cfg.max_images);
+    const size_t per = (size_t)224 * 224 * 3;
+    if (!c->copy_stream) {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        for (int j = 0; j < lrcn_ctx::kStage; ++j) {
+            HIPCHK(c, hipEventCreateWithFlags(&c->up_done[j], hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&c->rd_done[j], hipEventDisableTiming));
+            DALLOC(c, c->stage[j], per * (size_t)c->cfg.max_images);
+        }
+    }
+    const int j = c->stage_next;
+    if (c->stage_full[j])
+        FAIL(c, LRCN_ESTATE, "all %d staging buffers hold crops that no VGG forward has been issued on yet (upload at most %d batches ahead)",
+             lrcn_ctx::kStage, lrcn_ctx::kStage);
+    // the forward that last read this buffer: normally long finished; otherwise wait for it HERE, on the host (see lrcn_ctx::kStage)
+    if (c->stage_read[j] && hipEventQuery(c->rd_done[j]) != hipSuccess) HIPCHK(c, hipEventSynchronize(c->rd_done[j]));
+    HIPCHK(c, hipMemcpyAsync(c->stage[j], host_u8, per * (size_t)N, hipMemcpyHostToDevice, c->copy_stream));
+    HIPCHK(c, hipEventRecord(c->up_done[j], c->copy_stream));
+    c->stage_full[j] = true;
+    c->stage_next = (j + 1) % lrcn_ctx::kStage;
+    *dev_out = c->stage[j];
+    return LRCN_OK;
+}
+
+int lrcn_upload_wait(lrcn_ctx *c) {
+    DeviceGuard dg(c);
+    if (!c) return LRCN_EINVAL;
+    if (c->copy_stream) HIPCHK(c, hipStreamSynchronize(c->copy_stream));
     return LRCN_OK;
 }
 

@@ -73,7 +73,14 @@ class HipOps:
         self.ctx = ctx
 
     def vgg(self, img_u8, feats=None):
-        return L.convnet_u8(self.ctx, img_u8, feats=feats)
+        return L.convnet_u8(self.ctx, img_u8, feats=feats)   # host crops are uploaded through the staging buffers first
+
+    def upload(self, host_u8):
+        """Start the host -> device copy of a batch of crops on the library's copy stream (returns at once)."""
+        return L.upload_crops(self.ctx, host_u8)
+
+    def params_touched(self):
+        self.ctx.params_touched()
 
     def side_stream(self):
         """A second HIP stream for the VGG forward (None = run everything in order on the caller's stream)."""
@@ -140,7 +147,13 @@ class HipOps:
 
 class DataParallelTrainer:
     """train1's batch loop body (lrcn.jl:369-394) sharded over ranks. world_size 1 = no collective.
-    `ops` defaults to the HIP operations; tests of the collective logic on CPU (gloo) inject their own."""
+    `ops` defaults to the HIP operations; tests of the collective logic on CPU (gloo) inject their own.
+
+    The trainer OWNS the parameters between steps: it turns LRCN_OPT_FUSED_UPDATE on (unless LRCN_FUSED_UPDATE=0 or the sharded update
+    is selected), under which every update! also writes the NEXT step's shadow weights and the next step skips its shadow pass.  Code that
+    writes the parameter tensors itself between two steps -- a checkpoint restored into the same tensors, weight clipping,
+    re-initialisation -- must say so with trainer.params_touched() (restore() does it), or the next step trains on stale shadows.
+    close() turns the option off again: it belongs to the context and would otherwise outlive the trainer."""
 
     def __init__(self, ctx, param, optim, B_global, world=1, rank=0, pdrop=0.4, seed=0, group=None, ops=None, backend=None, shard_adam=None):
         """backend (world > 1): "torch" (default) = the per-group all-reduces are issued from here through torch.distributed's RCCL
@@ -178,7 +191,8 @@ class DataParallelTrainer:
         self.shard = bool(shard_adam) and self.backend == "torch" and hasattr(self.ops, "update_flat") and hasattr(self.ops, "grad_group_wait")
         env = os.environ.get("LRCN_FUSED_UPDATE")
         fused = (env[:1] != "0") if env else True
-        if fused and not self.shard and hasattr(self.ops, "set_fused_update"):
+        self._fused = bool(fused and not self.shard and hasattr(self.ops, "set_fused_update"))
+        if self._fused:
             self.ops.set_fused_update(True)
         shapes = [tuple(t.shape) for t in param]
         if self.shard:
@@ -190,9 +204,11 @@ class DataParallelTrainer:
                 param[k] = v           # the caller's list now refers to the flat buffer
             self.flat_grads, self.grads, _ = flat_model_like(shapes, device=dev, group_align=align)
             n_of = [(b - a) // max(world, 1) for a, b in self._ranges]
+            self._shapes, self._align = shapes, align
             self._m = [torch.zeros(n, device=dev, dtype=torch.float32) for n in n_of]
             self._v = [torch.zeros(n, device=dev, dtype=torch.float32) for n in n_of]
             self._gshard = [torch.zeros(n, device=dev, dtype=torch.float32) for n in n_of]
+            self._scatter_optim_state()   # a resumed optimizer (optim.t > 0) keeps its moments: this rank's slices of optim.m / optim.v
         else:
             self.flat_grads, self.grads = flat_model_like(shapes, device=param[0].device)
         self.step_no = 0
@@ -205,6 +221,76 @@ class DataParallelTrainer:
         self._vgg_done = None    # event: the side stream finished the VGG forward whose output is _feats_next
         self._feats_buf = [None, None]  # ping-pong outputs of the side-stream VGG
         self._bucket_streams = None
+        self._prefetched = None  # (host tensor, staged device crops): the upload started by the previous step's prefetch_img_u8
+
+    # ---- parameter / optimizer state hand-over (checkpoints) ----
+    def params_touched(self):
+        """The caller wrote the parameter tensors itself since the last step (see the class docstring)."""
+        if hasattr(self.ops, "params_touched"):
+            self.ops.params_touched()
+
+    def restore(self, arrays=None, adam=None):
+        """Load a checkpoint into the trainer's tensors: arrays = the nine parameter arrays (logical reference shapes; None = keep),
+        adam = (m arrays, v arrays, t) or None.  Declares the write (params_touched) and re-slices the moments of a sharded update."""
+        if arrays is not None:
+            for t, a in zip(self.param, arrays):
+                if t.numel():
+                    t.copy_(L.to_jl(np.asarray(a, np.float32), device=t.device))
+            self.params_touched()
+        if adam is not None:
+            m, v, step = adam
+            for k in range(len(self.param)):
+                if self.optim.m[k].numel():
+                    self.optim.m[k].copy_(L.to_jl(np.asarray(m[k], np.float32), device=self.optim.m[k].device))
+                    self.optim.v[k].copy_(L.to_jl(np.asarray(v[k], np.float32), device=self.optim.v[k].device))
+            self.optim.t = int(step)
+            if self.shard:
+                self._scatter_optim_state()
+
+    def _scatter_optim_state(self):
+        """Sharded update: this rank's 1/N slices of the optimizer's moments (group-padded flat layout, as the parameters)."""
+        W, r = max(self.world, 1), self.rank
+        for src, dst in ((self.optim.m, self._m), (self.optim.v, self._v)):
+            flat, views, _ = flat_model_like(self._shapes, device=self.flat_param.device, group_align=self._align)
+            for vw, t in zip(views, src):
+                if t.numel():
+                    vw.copy_(t)
+            for k, (a, b) in enumerate(self._ranges):
+                n = (b - a) // W
+                dst[k].copy_(flat[a + r * n:a + (r + 1) * n])
+
+    def gather_optim_state(self):
+        """Sharded update: all-gather the rank-sharded moments back into optim.m / optim.v (every rank), so that a checkpoint written
+        from `optim` holds the real state.  A no-op for the replicated update, whose optim.m / optim.v are the state."""
+        if not self.shard:
+            return
+        W = max(self.world, 1)
+        coll = self.world > 1
+        for shards, dst in ((self._m, self.optim.m), (self._v, self.optim.v)):
+            flat, views, _ = flat_model_like(self._shapes, device=self.flat_param.device, group_align=self._align)
+            for k, (a, b) in enumerate(self._ranges):
+                if b == a:
+                    continue
+                n = (b - a) // W
+                if coll:
+                    parts = [torch.empty_like(shards[k]) for _ in range(W)]
+                    dist.all_gather(parts, shards[k].clone(), group=self.group)
+                else:
+                    parts = [shards[k]]
+                for i, t in enumerate(parts):
+                    flat[a + i * n:a + (i + 1) * n].copy_(t)
+            for vw, t in zip(views, dst):
+                if t.numel():
+                    t.copy_(vw)
+
+    def close(self):
+        """Give the context back as it was: the fused-update option belongs to the context and would outlive the trainer."""
+        if getattr(self, "_fused", False) and hasattr(self.ops, "set_fused_update"):
+            try:
+                self.ops.set_fused_update(False)
+            except Exception:
+                pass
+            self._fused = False
 
     def _init_abi_comm(self, world, rank, group, device):
         """Two phases, so that no rank can be left alone inside the collective lrcn_comm_init (= ncclCommInitRank):
@@ -294,15 +380,31 @@ class DataParallelTrainer:
         if torch.is_tensor(img_u8) and img_u8.is_cuda:
             # the crops were allocated on the main stream but are read by the side stream: tell the caching allocator, so a
             # caller that drops them right after step() cannot have the block recycled under the running convolution
-            img_u8.record_stream(self._side)
+            img_u8.record_stream(self._side)   # (staged crops live in the library's own buffers: nothing to record)
         self._vgg_done = torch.cuda.Event()
         self._vgg_done.record(self._side)
         return feats
 
-    def step(self, img_u8, tokens, next_img_u8=None, feats=None):
+    def _device_crops(self, img):
+        """Device crops for a batch that may still be in (pinned) host memory: the staged copy that the previous step's prefetch_img_u8
+        started, if `img` is that very tensor; otherwise the upload starts now (correct, but on the critical path of this batch)."""
+        if not (torch.is_tensor(img) and not img.is_cuda) or not hasattr(self.ops, "upload"):
+            return img
+        if self._prefetched is not None and self._prefetched[0] is img:
+            staged = self._prefetched[1]
+            self._prefetched = None
+            return staged
+        return self.ops.upload(img)
+
+    def step(self, img_u8, tokens, next_img_u8=None, feats=None, prefetch_img_u8=None):
         """One synchronous-SGD step on this rank's shard.  img_u8: this rank's uint8 crops (or feats given);
         next_img_u8: the NEXT step's crops, whose VGG forward runs beside this step's LSTM work and all-reduce.
-        img_u8 is IGNORED when the previous step() prefetched this batch's features through its next_img_u8."""
+        img_u8 is IGNORED when the previous step() prefetched this batch's features through its next_img_u8.
+        Crops may be CPU tensors (pinned for a true asynchronous copy): the reference uploads every batch's inputs inside its loop
+        (lrcn.jl:369-376); here the copy runs on the library's copy stream.  prefetch_img_u8: the crops of the step AFTER next (the
+        tensor that will be passed as next_img_u8 to the next call): their upload starts now, a whole step before the VGG forward that
+        reads them, so the forward never waits for PCIe.  A host buffer handed over must stay unchanged until its forward has been
+        queued AND the copy has run (HipOps.ctx: lrcn.upload_wait) -- a loader rotates at least three pinned buffers."""
         if feats is None:
             if self._feats_next is not None:
                 feats = self._feats_next
@@ -310,11 +412,16 @@ class DataParallelTrainer:
                     torch.cuda.current_stream(self.ctx.device).wait_event(self._vgg_done)
                     self._vgg_done = None
             else:
-                feats = self.vgg(img_u8)
+                feats = self.vgg(self._device_crops(img_u8))
         self._feats_next = None
         self.step_no += 1
+        if next_img_u8 is not None:
+            next_img_u8 = self._device_crops(next_img_u8)
         if next_img_u8 is not None and self._side is not None:
             self._feats_next = self._vgg_on_side_stream(next_img_u8)  # concurrent with everything below
+        if prefetch_img_u8 is not None and hasattr(self.ops, "upload") and torch.is_tensor(prefetch_img_u8) and not prefetch_img_u8.is_cuda:
+            # after the forward above has been queued: that forward released (in issue order) the staging buffer this upload goes into
+            self._prefetched = (prefetch_img_u8, self.ops.upload(prefetch_img_u8))
         # rank-dependent dropout stream: masks differ per shard like rows of one big batch would
         seed = (self.seed + self.step_no) * 65536 + self.rank
         if self.backend == "abi" and self.world > 1:

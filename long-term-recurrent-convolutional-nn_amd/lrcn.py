@@ -425,6 +425,8 @@ def convnet(ctx, x):
 def convnet_u8(ctx, img_u8, mean=VGG_MEAN, feats=None, normalize=False):
     """Fused read_image_data arithmetic (lrcn.jl:766-772) + convnet on uint8 crops img[n][row][col][c].  mean=None: the
     averageImage registered with set_average_image.  normalize: divide each feature row by its sum (lrcn.jl:595-597)."""
+    if torch.is_tensor(img_u8) and not img_u8.is_cuda:  # host crops: through the staging buffers (asynchronous when pinned)
+        img_u8 = upload_crops(ctx, img_u8)
     N = img_u8.shape[0]
     if feats is None:
         feats = jl_empty(N, CNNOUT)
@@ -433,6 +435,35 @@ def convnet_u8(ctx, img_u8, mean=VGG_MEAN, feats=None, normalize=False):
     if normalize:
         normalize_features(ctx, feats)
     return feats
+
+
+class StagedCrops:
+    """uint8 crops [N][224][224][3] in one of the context's two device staging buffers (lrcn_upload_crops): stands wherever a device crop
+    tensor does (convnet_u8, train_step_dp).  `host` keeps the source buffer alive until the asynchronous copy has certainly been issued
+    AND consumed (the trainer drops it after the forward that reads the staging buffer has been queued)."""
+
+    def __init__(self, ptr, N, host):
+        self.ptr, self.shape, self.host = int(ptr), (int(N), 224, 224, 3), host
+        self.is_cuda = True
+
+    def data_ptr(self):
+        return self.ptr
+
+
+def upload_crops(ctx, host_u8):
+    """The per-batch host -> device copy of the training loop (lrcn.jl:369-376) off the critical path: `host_u8` (CPU uint8 tensor
+    [N][224][224][3]; pinned = a true asynchronous DMA) is copied on the context's copy stream into a device staging buffer.  Returns at
+    once; the forward that is handed the result waits on the device (include/lrcn.h "input feed")."""
+    if host_u8.is_cuda or host_u8.dtype != torch.uint8 or not host_u8.is_contiguous() or tuple(host_u8.shape[1:]) != (224, 224, 3):
+        raise LrcnError("upload_crops takes a contiguous CPU uint8 tensor [N][224][224][3]")
+    out = C.c_void_p()
+    ctx._call("lrcn_upload_crops", C.c_void_p(host_u8.data_ptr()), int(host_u8.shape[0]), C.byref(out))
+    return StagedCrops(out.value, host_u8.shape[0], host_u8)
+
+
+def upload_wait(ctx):
+    """Block until every upload issued so far has run (a loader calls it before refilling a pinned buffer)."""
+    ctx._call("lrcn_upload_wait")
 
 
 def read_image_data_u8(ctx, img_u8, mean=VGG_MEAN):

@@ -49,7 +49,7 @@ static orc_model model_of(const lrcn_ctx *c, float *const p[9]) {
 static void sizes_of(const lrcn_ctx *c, int64_t s[9]) { lrcn_param_sizes_n(c->nl, c->cfg.E, c->cfg.H1, c->cfg.H2, c->cfg.V, s); }
 
 /* ---- lifetime / plumbing ---- */
-const char *lrcn_version(void) { return "lrcn-cpu 0.3 (oracle)"; }
+const char *lrcn_version(void) { return "lrcn-cpu 0.4 (oracle)"; }
 int lrcn_abi_version(void) { return LRCN_ABI_VERSION; }
 /* options: the host twin always makes its weights afresh and sums in a fixed order -- every valid option is accepted as a no-op */
 int lrcn_set_option(lrcn_ctx *c, int option, int64_t value) {
@@ -363,6 +363,17 @@ int lrcn_resize_crop_u8(lrcn_ctx *c, const uint8_t *src, const int64_t *offsets,
     }
     return LRCN_OK;
 }
+/* input feed (rev 4): "device" memory IS host memory here -- the crops are used where they lie, nothing is copied or queued */
+int lrcn_host_alloc(void **p, size_t bytes) { if (!p) return LRCN_EINVAL; *p = malloc(bytes ? bytes : 16); return *p ? LRCN_OK : LRCN_ENOMEM; }
+int lrcn_host_free(void *p) { free(p); return LRCN_OK; }
+int lrcn_upload_crops(lrcn_ctx *c, const uint8_t *host_u8, int N, const uint8_t **dev_out) {
+    if (!c || !host_u8 || !dev_out) return LRCN_EINVAL;
+    if (c->cfg.max_images < 1) FAIL(c, LRCN_ESTATE, "context was created with max_images = 0");
+    if (N < 1 || N > c->cfg.max_images) FAIL(c, LRCN_EINVAL, "N=%d outside [1,%d]", N, c->cfg.max_images);
+    *dev_out = host_u8;
+    return LRCN_OK;
+}
+int lrcn_upload_wait(lrcn_ctx *c) { return c ? LRCN_OK : LRCN_EINVAL; }
 int lrcn_normalize_features(lrcn_ctx *c, float *feats, int N) {
     if (!c || !feats || N < 1) return LRCN_EINVAL;
     for (int n = 0; n < N; ++n) { /* input / sum(input)  lrcn.jl:595-597 (float32 sum) */

@@ -121,3 +121,32 @@ def test_pmc_traffic_is_quoted_only_for_the_sources_it_was_measured_on(tmp_path,
     monkeypatch.setattr(bench, "csrc_digest", lambda: "0" * 16)    # as if a kernel source had changed since the measurement
     val, note = bench.pmc_traffic("bf16", 256)
     assert val is None and "stale" in note
+
+
+@pytest.mark.parametrize("how", ["sigterm", "watchdog"])
+def test_ranks_never_outlive_the_launcher(tmp_path, how):
+    """The ranks run in their own session: a SIGTERM to the parent (a harness timeout, Ctrl-C) or the watchdog must take them down with it,
+    or a hung collective keeps N processes on the GPUs.  The dry-run ranks hang on purpose and leave their pids behind."""
+    import signal
+    import time
+    env = _env()
+    env["LRCN_BENCH_DRYRUN_HANG"] = str(tmp_path / "pid")
+    args = [sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0"] + (["--watchdog-s", "8"] if how == "watchdog" else [])
+    p = subprocess.Popen(args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    pids = []
+    for _ in range(600):
+        pids = [int(open(tmp_path / f).read()) for f in os.listdir(tmp_path) if open(tmp_path / f).read().strip()]
+        if len(pids) == 2:
+            break
+        time.sleep(0.1)
+    assert len(pids) == 2, "the ranks never started"
+    if how == "sigterm":
+        p.send_signal(signal.SIGTERM)
+    p.communicate(timeout=60)
+    assert p.returncode != 0
+    for _ in range(100):
+        alive = [q for q in pids if os.path.exists("/proc/%d" % q) and "zombie" not in open("/proc/%d/status" % q).read()]
+        if not alive:
+            break
+        time.sleep(0.1)
+    assert not alive, alive

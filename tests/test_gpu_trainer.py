@@ -11,7 +11,7 @@ from lrcn_amd import lrcn as L
 pytestmark = pytest.mark.gpu
 
 
-def run_steps(monkeypatch, overlap, nsteps=4):
+def run_steps(monkeypatch, overlap, nsteps=4, inputs="hbm", prefetch=True):
     monkeypatch.setenv("LRCN_OVERLAP_VGG", "1" if overlap else "0")
     E = H = 64
     V, B, T = 300, 4, 5
@@ -27,13 +27,57 @@ def run_steps(monkeypatch, overlap, nsteps=4):
     rng = np.random.default_rng(3)
     toks = [torch.as_tensor(rng.integers(3, V, size=(T, B)).astype(np.int32)).cuda() for _ in range(nsteps)]
     losses = []
+    if inputs == "host":   # the same crops in page-locked host memory: uploaded per step on the copy stream, one step ahead
+        imgs = [t.cpu().pin_memory() for t in imgs]
     for k in range(nsteps):
-        tr.step(imgs[k], toks[k], next_img_u8=imgs[k + 1] if k + 1 < nsteps else None)
+        tr.step(imgs[k], toks[k], next_img_u8=imgs[k + 1] if k + 1 < nsteps else None,
+                prefetch_img_u8=imgs[k + 2] if (inputs == "host" and prefetch and k + 2 < nsteps) else None)
         losses.append(tr.loss_value())
     torch.cuda.synchronize()
     out = [L.from_jl(p).copy() for p in param]
     ctx.close()
     return losses, out
+
+
+@pytest.mark.parametrize("overlap,prefetch", [(True, True), (True, False), (False, True)])
+def test_pinned_host_crops_uploaded_per_step_keep_the_trajectory(monkeypatch, overlap, prefetch):
+    # lrcn_upload_crops: the per-batch H2D copy of lrcn.jl:369-376 on the library's copy stream, two staging buffers, device-side ordering
+    # against the forwards -- with the upload one step ahead (prefetch), at the step that needs it, and without the side stream: the
+    # trajectory is the resident-input one
+    la, pa = run_steps(monkeypatch, overlap=overlap, nsteps=5, inputs="host", prefetch=prefetch)
+    lb, pb = run_steps(monkeypatch, overlap=overlap, nsteps=5, inputs="hbm")
+    np.testing.assert_allclose(la, lb, rtol=1e-5)
+    for a, b in zip(pa, pb):
+        np.testing.assert_allclose(a, b, rtol=0, atol=2e-5)
+
+
+def test_upload_crops_staging_rules():
+    ctx = L.Context(8, 8, 8, 17, max_B=2, max_T=1, vgg_dtype=lrcn_amd.LRCN_BF16, max_images=3)
+    L.vgg_load(ctx, *L.synthetic_vgg_weights(seed=1))
+    g = torch.Generator(device="cpu")
+    g.manual_seed(2)
+    host = [torch.randint(0, 256, (3, 224, 224, 3), generator=g, dtype=torch.uint8).pin_memory() for _ in range(3)]
+    want = [L.from_jl(L.convnet_u8(ctx, h.cuda())) for h in host]
+    a, b, c = L.upload_crops(ctx, host[0]), L.upload_crops(ctx, host[1]), L.upload_crops(ctx, host[2])
+    assert len({a.data_ptr(), b.data_ptr(), c.data_ptr()}) == 3
+    with pytest.raises(lrcn_amd.LrcnError, match="staging"):
+        L.upload_crops(ctx, host[0])            # all three buffers hold crops no forward has been issued on
+    fa = L.from_jl(L.convnet_u8(ctx, a))
+    d = L.upload_crops(ctx, host[1])            # a's buffer is free again (its upload is ordered behind the forward's first kernel)
+    assert d.data_ptr() == a.data_ptr()
+    fb, fc, fd = L.from_jl(L.convnet_u8(ctx, b)), L.from_jl(L.convnet_u8(ctx, c)), L.from_jl(L.convnet_u8(ctx, d))
+    L.upload_wait(ctx)
+    for got, ref in zip((fa, fb, fc, fd), want + [want[1]]):
+        np.testing.assert_array_equal(got, ref)  # the VGG forward is bit-reproducible: staged crops give the resident crops' features
+    for k in range(12):                          # a long alternation of uploads and forwards through all three buffers
+        s_ = L.upload_crops(ctx, host[k % 3])
+        np.testing.assert_array_equal(L.from_jl(L.convnet_u8(ctx, s_)), want[k % 3])
+    got = L.from_jl(L.convnet_u8(ctx, host[1][:2].contiguous()))   # a CPU tensor is uploaded on the way (partial batch: other tile
+    want2 = L.from_jl(L.convnet_u8(ctx, host[1][:2].cuda()))       # shapes, so compare with the same two crops resident)
+    np.testing.assert_array_equal(got, want2)
+    with pytest.raises(lrcn_amd.LrcnError):
+        L.upload_crops(ctx, torch.zeros((4, 224, 224, 3), dtype=torch.uint8))   # N > max_images
+    ctx.close()
 
 
 def test_side_stream_vgg_overlap_keeps_the_trajectory(monkeypatch):

@@ -18,6 +18,22 @@ def rel_max_err(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
 
 
+def assert_bf16_layer(got, emu, what=""):
+    """A bf16 layer against the bf16-EMULATING oracle (bf16 operands, exact accumulation from the f32 bias, ReLU, one rounding to
+    bf16; lrcn_oracle.h): the kernel sums in f32 in another order, so a value may land on the neighbouring bf16 (one step = at most
+    2^-7 relative) when the exact sum sits at a rounding boundary -- never further, and only for a small fraction of the tensor."""
+    diff = np.abs(got - emu)
+    mx = np.abs(emu).max()
+    assert (diff <= 2.0 ** -7 * np.abs(emu) + 1e-5 * mx).all(), (what, float(diff.max()), float(mx))
+    assert (diff == 0).mean() > 0.97, (what, float((diff == 0).mean()))
+
+
+def emulated_layer(x, w, b):
+    with orc.emulate_bf16():
+        ref = orc.conv3x3(x, w, b, relu=True)
+        return ref, orc.pool2(ref), orc.conv3x3(x, w, b, relu=False)
+
+
 def small_ctx(vgg_dtype=lrcn_amd.LRCN_F32, max_images=0):
     return L.Context(8, 8, 8, 17, max_B=2, max_T=1, vgg_dtype=vgg_dtype, max_images=max_images)
 
@@ -55,6 +71,11 @@ def test_conv_layers_vs_oracle(dtype, tol, shape, glds, monkeypatch):
     ref_lin = orc.conv3x3(x, w, b, relu=False)
     got_lin = L.from_jl(L.conv3x3(ctx, L.to_jl(x), L.to_jl(w), torch.as_tensor(b).cuda(), relu=False, pool=False))
     assert (got_lin < 0).any() and rel_max_err(got_lin, ref_lin) <= tol
+    if dtype == lrcn_amd.LRCN_BF16:  # the tight check: the same arithmetic with bf16 rounding, value by value
+        e, ep, el = emulated_layer(x, w, b)
+        assert_bf16_layer(got, e, "relu")
+        assert_bf16_layer(gotp, ep, "relu + pool")
+        assert_bf16_layer(got_lin, el, "linear")
 
 
 @pytest.mark.parametrize("shape", [(16, 64, 256, 2), (28, 64, 128, 3), (12, 128, 136, 3), (10, 64, 384, 5), (8, 192, 512, 9),
@@ -70,6 +91,7 @@ def test_conv_phase_interleaved_kernel_vs_oracle(shape, monkeypatch):
     ref = orc.conv3x3(x, w, b, relu=True)
     refp = orc.pool2(ref)
     ref_lin = orc.conv3x3(x, w, b, relu=False)
+    emu = emulated_layer(x, w, b)
     outs = {}
     for knob in ("force", "0"):
         monkeypatch.setenv("LRCN_8P", knob)
@@ -78,6 +100,8 @@ def test_conv_phase_interleaved_kernel_vs_oracle(shape, monkeypatch):
         gotp = L.from_jl(L.conv3x3(ctx, L.to_jl(x), L.to_jl(w), torch.as_tensor(b).cuda(), relu=True, pool=True))
         got_lin = L.from_jl(L.conv3x3(ctx, L.to_jl(x), L.to_jl(w), torch.as_tensor(b).cuda(), relu=False, pool=False))
         assert rel_max_err(got, ref) <= 2e-2 and rel_max_err(gotp, refp) <= 2e-2 and rel_max_err(got_lin, ref_lin) <= 2e-2
+        for g_, e_, what in zip((got, gotp, got_lin), emu, ("relu", "relu + pool", "linear")):
+            assert_bf16_layer(g_, e_, "LRCN_8P=%s %s" % (knob, what))
         outs[knob] = (got, gotp, got_lin)
         ctx.close()
     # same bf16 operands, f32 accumulation in a different order: the two kernels agree to bf16 output rounding
@@ -98,6 +122,7 @@ def test_conv64_halo_patch_kernel_vs_oracle(shape, monkeypatch):
     ref = orc.conv3x3(x, w, b, relu=True)
     refp = orc.pool2(ref)
     ref_lin = orc.conv3x3(x, w, b, relu=False)
+    emu = emulated_layer(x, w, b)
     outs = {}
     for knob in ("1", "0"):
         monkeypatch.setenv("LRCN_CONV64", knob)
@@ -106,6 +131,8 @@ def test_conv64_halo_patch_kernel_vs_oracle(shape, monkeypatch):
         gotp = L.from_jl(L.conv3x3(ctx, L.to_jl(x), L.to_jl(w), torch.as_tensor(b).cuda(), relu=True, pool=True))
         got_lin = L.from_jl(L.conv3x3(ctx, L.to_jl(x), L.to_jl(w), torch.as_tensor(b).cuda(), relu=False, pool=False))
         assert rel_max_err(got, ref) <= 2e-2 and rel_max_err(gotp, refp) <= 2e-2 and rel_max_err(got_lin, ref_lin) <= 2e-2
+        for g_, e_, what in zip((got, gotp, got_lin), emu, ("relu", "relu + pool", "linear")):
+            assert_bf16_layer(g_, e_, "LRCN_CONV64=%s %s" % (knob, what))
         outs[knob] = (got, gotp, got_lin)
         ctx.close()
     for a, c in zip(outs["1"], outs["0"]):
@@ -155,6 +182,17 @@ def test_full_vgg_bf16_vs_oracle(vgg_setup):
     assert rel_max_err(got, ref) <= 3e-2
     cos = float((got * ref).sum() / (np.linalg.norm(got) * np.linalg.norm(ref)))
     assert cos > 0.999
+    # the whole stack against the bf16-emulating oracle (15 layers of bf16 operands and bf16 results, exact accumulation).  The TIGHT
+    # statement is per layer (assert_bf16_layer above: never more than one bf16 step, > 97 % of the values identical); through 15 layers
+    # those one-step flips are re-amplified by every following contraction (fc6 sums 25088 of them), so end to end the emulation is only
+    # somewhat closer than the f32 oracle (measured 5.7e-3 vs 7.6e-3 of the tensor's max) -- bounded here, not claimed equal
+    host = ([L.from_jl(t) for t in w[0]], [t.cpu().numpy() for t in w[1]], (L.from_jl(w[2][0]), w[2][1].cpu().numpy()),
+            (L.from_jl(w[3][0]), w[3][1].cpu().numpy()))
+    with orc.emulate_bf16():
+        emu = orc.vgg_forward(host[0], host[1], host[2], host[3], x[:, :, :, :1])
+    e1 = rel_max_err(got[:1], emu)
+    print("bf16 VGG vs emulating oracle: rel max err %.3e (vs f32 oracle %.3e)" % (e1, rel_max_err(got[:1], ref[:1])))
+    assert e1 <= 1e-2
 
 
 def test_fused_conv1_1_conv1_2_matches_two_launch_path(vgg_setup, monkeypatch):
