@@ -174,7 +174,10 @@ class DataParallelTrainer:
             backend = "torch"
         self.backend = backend
         self.backend_note = ""
-        if backend == "abi" and world > 1:
+        # LRCN_DP_FORCE_PIPELINE=1 (tests on a one-GPU box): a ONE-rank job runs exactly the control flow of N > 1 -- communicator, per-group
+        # [gradient event -> all-reduce -> Adam] pipeline, collectives issued for real (the sum over one rank is the identity)
+        self._multi = world > 1 or (os.environ.get("LRCN_DP_FORCE_PIPELINE", "0")[:1] == "1" and dist.is_available() and dist.is_initialized())
+        if backend == "abi" and self._multi:
             self._init_abi_comm(world, rank, group, param[0].device)
         # LRCN_OPT_FUSED_UPDATE: update! writes the next step's shadow weights, the separate shadow pass disappears from the head of the LSTM
         # chain.  Emulated rank of 8 (32 rows): 1.549 -> 1.510 ms/step (two same-box pairs).  At 256 rows it lost 1.4 % early in round 3
@@ -424,7 +427,7 @@ class DataParallelTrainer:
             self._prefetched = (prefetch_img_u8, self.ops.upload(prefetch_img_u8))
         # rank-dependent dropout stream: masks differ per shard like rows of one big batch would
         seed = (self.seed + self.step_no) * 65536 + self.rank
-        if self.backend == "abi" and self.world > 1:
+        if self.backend == "abi" and self._multi:
             # one C call: lossgradient + per-group [all-reduce over xGMI -> Adam] on the library's own streams
             self.ops.train_step_dp(self.param, self.grads, self.optim, feats, tokens, self.B_global, self.pdrop, seed)
             if next_img_u8 is not None and self._side is None:
@@ -461,7 +464,7 @@ class DataParallelTrainer:
         if os.environ.get("LRCN_DP_BUCKETS", "1")[:1] == "0":
             return False
         env = os.environ.get("LRCN_DP_GROUP_ADAM")
-        return env[:1] != "0" if env else self.world > 1
+        return env[:1] != "0" if env else self._multi
 
     def _reduce_and_update_groups(self):
         if self._bucket_streams is None:
@@ -471,7 +474,7 @@ class DataParallelTrainer:
             s = self._bucket_streams[k]
             self.ops.grad_group_wait(k, s)  # s waits for the group's event recorded inside lossgradient
             with self.ops.stream_ctx(s):
-                if self.world > 1 and b > a:
+                if self._multi and b > a:
                     dist.all_reduce(self.flat_grads[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True).wait()  # s waits for RCCL
                 self.ops.update_group(self.param, self.grads, self.optim, k, s)
         self.ops.join(self._bucket_streams)
