@@ -227,67 +227,21 @@ def metric_name(a, fake_multi=False):
     return "training images/sec (VGG16+LSTM), %s" % w
 
 
-def find_free_port():
-    import socket
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        return sk.getsockname()[1]
-
-
 def launch(a, argv):
     """`python bench.py --gpus N` with no WORLD_SIZE in the environment: this process NEVER touches the GPU (no torch import, no HIP call --
     a parent that had initialised the device could not be replaced or forked safely); it starts the N ranks as a CHILD job
     (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same flags>`),
     waits for it under a watchdog, relays rank 0's JSON line and exits with the job's code.  --dp-backend auto: first attempt with the
     C-ABI communicator, second with torch.distributed's if the first fails or hangs (only the parent can do that safely)."""
-    import signal
-    import subprocess
+    from lrcn_amd import launch as lch   # imports neither torch nor the HIP library
     backends = ["abi", "torch"] if a.dp_backend == "auto" else [a.dp_backend]
     child_argv = [x for x in argv]
     last_rc = 1
     for attempt, backend in enumerate(backends):
-        env = dict(os.environ)
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver
-        env["LRCN_DP_BACKEND"] = backend
-        env["LRCN_BENCH_LAUNCHED"] = "1"
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
-               "--master-port", str(find_free_port()), os.path.abspath(__file__)] + child_argv
-        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True, start_new_session=True)
-
-        def stop_job():
-            """End the ranks: the exact process group started above (its own session), nothing else.  Runs on EVERY way out of the wait
-            below -- watchdog, SIGTERM / SIGINT to this parent, any exception -- so that no rank is left holding a GPU."""
-            if proc.poll() is not None:
-                return
-            try:
-                os.killpg(proc.pid, signal.SIGTERM)
-                for _ in range(30):
-                    if proc.poll() is not None:
-                        break
-                    time.sleep(0.1)
-                os.killpg(proc.pid, signal.SIGKILL)
-            except (ProcessLookupError, PermissionError):
-                pass
-
-        def on_signal(signum, _frame):
-            stop_job()
-            raise SystemExit(128 + signum)
-
-        old = {sg: signal.signal(sg, on_signal) for sg in (signal.SIGTERM, signal.SIGINT)}
-        try:
-            try:
-                out, _ = proc.communicate(timeout=a.watchdog_s)
-                rc = proc.returncode
-            except subprocess.TimeoutExpired:
-                stop_job()
-                out, _ = proc.communicate()
-                rc = 124
-                print("bench.py: the %d-rank job (dp backend %s) did not finish within %.0f s and was stopped" % (a.gpus, backend, a.watchdog_s),
-                      file=sys.stderr)
-        finally:
-            stop_job()   # no-op when the job has ended
-            for sg, h in old.items():
-                signal.signal(sg, h)
+        rc, out = lch.run_ranks(__file__, child_argv, a.gpus, {"LRCN_DP_BACKEND": backend, "LRCN_BENCH_LAUNCHED": "1"}, a.watchdog_s)
+        if rc == 124:
+            print("bench.py: the %d-rank job (dp backend %s) did not finish within %.0f s and was stopped" % (a.gpus, backend, a.watchdog_s),
+                  file=sys.stderr)
         lines = [ln for ln in (out or "").splitlines() if ln.startswith("{") and '"metric"' in ln]
         if rc == 0 and lines:
             line = json.loads(lines[-1])

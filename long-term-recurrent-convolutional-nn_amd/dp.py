@@ -69,11 +69,17 @@ def flat_model_like(shapes, device="cuda", group_align=0):
 class HipOps:
     """The device operations a trainer step is made of -- all of them liblrcn_hip calls."""
 
-    def __init__(self, ctx):
+    def __init__(self, ctx, mean=L.VGG_MEAN):
         self.ctx = ctx
+        self.mean = mean   # channel means of read_image_data (lrcn.jl:770); None = the averageImage registered with the context
 
-    def vgg(self, img_u8, feats=None):
-        return L.convnet_u8(self.ctx, img_u8, feats=feats)   # host crops are uploaded through the staging buffers first
+    def vgg(self, img_u8, feats=None, normalize=False):
+        # host crops are uploaded through the staging buffers first
+        return L.convnet_u8(self.ctx, img_u8, mean=self.mean, feats=feats, normalize=normalize)
+
+    def loss(self, param, feats, tokens):
+        """Forward-only loss of one batch (average_loss's body, lrcn.jl:452-475): pdrop 0, normalised by the batch's own size."""
+        return L.loss(self.ctx, param, feats, tokens)
 
     def upload(self, host_u8):
         """Start the host -> device copy of a batch of crops on the library's copy stream (returns at once)."""
@@ -155,7 +161,8 @@ class DataParallelTrainer:
     re-initialisation -- must say so with trainer.params_touched() (restore() does it), or the next step trains on stale shadows.
     close() turns the option off again: it belongs to the context and would otherwise outlive the trainer."""
 
-    def __init__(self, ctx, param, optim, B_global, world=1, rank=0, pdrop=0.4, seed=0, group=None, ops=None, backend=None, shard_adam=None):
+    def __init__(self, ctx, param, optim, B_global, world=1, rank=0, pdrop=0.4, seed=0, group=None, ops=None, backend=None, shard_adam=None,
+                 normalize_features=False, gclip=0.0):
         """backend (world > 1): "torch" (default) = the per-group all-reduces are issued from here through torch.distributed's RCCL
         process group; "abi" = RCCL inside liblrcn_hip (lrcn_comm_init + lrcn_train_step_dp: one C call per step, what a Julia host
         would drive; the unique id travels over torch.distributed's group).  LRCN_DP_BACKEND overrides.  "abi" stays opt-in until a
@@ -165,12 +172,16 @@ class DataParallelTrainer:
         self.B_global, self.world, self.rank = B_global, world, rank
         self.pdrop, self.seed = pdrop, seed
         self.group = group
+        self.normalize_features = bool(normalize_features)   # input / sum(input) on the VGG's output (lrcn.jl:595-597)
+        # --gclip (parsed and ignored by the reference): clip the GLOBAL gradient norm, i.e. after the exchange and before update! -- which
+        # rules out the per-group [all-reduce -> Adam] pipeline: one all-reduce of the flat buffer, the norm, one Adam launch
+        self.gclip = float(gclip or 0.0)
         backend = os.environ.get("LRCN_DP_BACKEND") or backend or "torch"
         if backend == "auto":
             backend = "torch"
         if backend not in ("abi", "torch"):
             raise L.LrcnError("unknown data-parallel backend %r" % (backend,))
-        if backend == "abi" and not hasattr(self.ops, "train_step_dp"):
+        if backend == "abi" and (not hasattr(self.ops, "train_step_dp") or self.gclip > 0):
             backend = "torch"
         self.backend = backend
         self.backend_note = ""
@@ -191,7 +202,8 @@ class DataParallelTrainer:
         # (optim.m / optim.v are not used).  Never run on more than one GPU: opt-in until it has been.
         if shard_adam is None:
             shard_adam = os.environ.get("LRCN_DP_SHARD_ADAM", "0")[:1] == "1"
-        self.shard = bool(shard_adam) and self.backend == "torch" and hasattr(self.ops, "update_flat") and hasattr(self.ops, "grad_group_wait")
+        self.shard = (bool(shard_adam) and self.backend == "torch" and hasattr(self.ops, "update_flat") and hasattr(self.ops, "grad_group_wait")
+                      and not self.gclip > 0)
         env = os.environ.get("LRCN_FUSED_UPDATE")
         fused = (env[:1] != "0") if env else True
         self._fused = bool(fused and not self.shard and hasattr(self.ops, "set_fused_update"))
@@ -362,7 +374,7 @@ class DataParallelTrainer:
         return works
 
     def vgg(self, img_u8):
-        return self.ops.vgg(img_u8)
+        return self.ops.vgg(img_u8, normalize=True) if self.normalize_features else self.ops.vgg(img_u8)
 
     def _vgg_on_side_stream(self, img_u8):
         """Issue VGG(img) on the side stream into a ping-pong buffer; the main stream waits on the event only when it
@@ -377,7 +389,8 @@ class DataParallelTrainer:
         self._side.wait_stream(main)
         self.ctx.use_stream(self._side)
         try:
-            feats = self.ops.vgg(img_u8, feats=self._feats_buf[k])
+            feats = (self.ops.vgg(img_u8, feats=self._feats_buf[k], normalize=True) if self.normalize_features else
+                     self.ops.vgg(img_u8, feats=self._feats_buf[k]))
         finally:
             self.ctx.use_stream(main)
         if torch.is_tensor(img_u8) and img_u8.is_cuda:
@@ -434,6 +447,16 @@ class DataParallelTrainer:
                 self._feats_next = self.vgg(next_img_u8)
             return
         self.ops.lossgradient(self.param, feats, tokens, self.B_global, self.pdrop, seed, self.grads)
+        if self.gclip > 0:
+            if self.world > 1:
+                dist.all_reduce(self.flat_grads, op=dist.ReduceOp.SUM, group=self.group)
+            gn = float(torch.linalg.vector_norm(self.flat_grads))
+            if gn > self.gclip:
+                self.flat_grads.mul_(self.gclip / gn)
+            if next_img_u8 is not None and self._side is None:
+                self._feats_next = self.vgg(next_img_u8)
+            self.ops.update(self.param, self.grads, self.optim)
+            return
         if self.shard:
             self._reduce_scatter_update_gather()
             if next_img_u8 is not None and self._side is None:

@@ -34,6 +34,9 @@ class OracleOps:
     def last_loss(self):
         return self._loss
 
+    def loss(self, param, feats, tokens):
+        return orc.loss(self._model(param), feats.numpy(), tokens)
+
 
 class OracleGroupOps(OracleOps):
     """The same, plus the CPU stand-ins of what the per-group [all-reduce -> Adam] pipeline needs (dp.py

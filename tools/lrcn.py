@@ -7,6 +7,13 @@
     python tools/lrcn.py --coco --loadfile m.npz --generate 30 --beam_width 5 --datafiles ... --features ...
     python tools/lrcn.py --cnn --model imagenet-vgg-verydeep-16.mat --loadfile m.npz --generate 30 photo.jpg
     python tools/lrcn.py --cnn --model vgg.mat --extfeatures --imagedir train2014 --prefix COCO_train2014_ --datafiles ...
+    python tools/lrcn.py --coco --train --gpus 8 --batchsize 256 --datafiles ... --features ...           # data-parallel: 8 x 32 rows
+    python tools/lrcn.py --coco --train --gpus 8 --cnn --model vgg.mat --imagedir train2014 --prefix COCO_train2014_ --datafiles ...   # from images
+
+Training runs on dp.DataParallelTrainer (train.py = train! / train1 / average_loss, lrcn.jl:223-246, 330-397, 407-486): every bucketed
+batch is split by rows over the ranks (same T everywhere, the global batch as normaliser, gradients summed over RCCL, identical Adam).
+`--gpus N` starts the ranks itself from a parent that never touches the GPU; the torchrun form works too.  `--cnn --train --imagedir`
+trains end to end from images: the VGG forward of the next batch runs beside the LSTM step of the current one.
 
 Differences from the reference, all documented in SURVEY.md 5.6 / A.8: `--lr` (default 0.001 = what the reference's
 Adam() actually uses) and `--gclip` (default 0 = off) are honoured instead of being parsed and ignored; `--bestfile` is
@@ -54,6 +61,10 @@ def build_parser():
     p.add_argument("--imagedir", default=".", help="directory of the images for --extfeatures")
     p.add_argument("--prefix", default="", help="file-name prefix before the zero-padded id (COCO_train2014_)")
     p.add_argument("--out", default="eval", help="directory for candidates / ids files of --generate")
+    p.add_argument("--gpus", type=int, default=1, help="--train: ranks of the data-parallel job (one per GPU); batches are split by rows")
+    p.add_argument("--dp_backend", default="torch", choices=["torch", "abi"], help="collectives through torch.distributed's RCCL group or the library's own")
+    p.add_argument("--shard_adam", action="store_true", help="N > 1: reduce-scatter -> Adam on 1/N of the parameters -> all-gather (dp.py)")
+    p.add_argument("--no_normalize", action="store_true", help="--cnn --train: do not divide fc7 features by their sum (lrcn.jl:595-597 does)")
     return p
 
 
@@ -77,14 +88,41 @@ def tokenize_all(o, cap):
 
 
 def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     o = build_parser().parse_args(argv)
-    print("opts=", sorted(vars(o).items()))
+    world_env = os.environ.get("WORLD_SIZE")
+    if o.gpus > 1 and world_env is None:   # before any torch / HIP import: this parent only starts the ranks and passes their output on
+        if not o.train:
+            raise SystemExit("--gpus N is the data-parallel TRAINING job (--train)")
+        from lrcn_amd import launch
+        rc, _ = launch.run_ranks(__file__, argv, o.gpus, {"LRCN_DP_BACKEND": o.dp_backend}, float(os.environ.get("LRCN_CLI_WATCHDOG_S", "86400")),
+                                 capture=False)
+        return rc
+    world, rank, local_rank = int(world_env or "1"), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    if world != o.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (o.gpus, world))
+    say = print if rank == 0 else (lambda *a, **k: None)
+    say("opts=", sorted(vars(o).items()))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import numpy as np
     import torch
+    import torch.distributed as dist
     import lrcn_amd
     from lrcn_amd import captions as cap
+    from lrcn_amd import dp
     from lrcn_amd import formats as fmt
     from lrcn_amd import lrcn as L
+    from lrcn_amd import train as trn
+
+    # LRCN_CLI_FAKE_MULTI=1 (validation on a ONE-GPU box): every rank uses device 0 over gloo -- the N-rank control flow on the real kernels
+    fake_multi = world > 1 and os.environ.get("LRCN_CLI_FAKE_MULTI", "0")[:1] == "1"
+    torch.cuda.set_device(0 if fake_multi else local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if fake_multi:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     if o.seed > 0:
         np.random.seed(o.seed)
@@ -95,18 +133,18 @@ def main(argv=None):
         raise SystemExit("--atype fp8 is the caption-generation / feature-extraction precision; train with bf16 or f32")
     vocab, lists = None, []
     if o.datafiles:
-        print("Tokenization starts")
+        say("Tokenization starts")
         vocab, lists = tokenize_all(o, cap)
-        print("Tokenization finished")
+        say("Tokenization finished")
     adam_state = None
     host_model = None
     if o.loadfile:
-        print("Loading model from", o.loadfile)
+        say("Loading model from", o.loadfile)
         host_model, vocab, adam_state, _ = fmt.load_checkpoint(o.loadfile)
     if vocab is None:
         raise SystemExit("need --datafiles or --loadfile (no vocabulary)")
     V = len(vocab)
-    print("%d unique words" % V)
+    say("%d unique words" % V)
     if len(o.hidden) != 2 or o.hidden[1] % 2:
         raise SystemExit("--hidden takes two sizes, the second even (LRCN-2f, lrcn.jl:496-504)")
     H1, H2 = o.hidden
@@ -114,10 +152,10 @@ def main(argv=None):
     ctx = L.Context(o.embed, H1, H2, V, max_B=max(o.batchsize, o.beam_width * (gen_chunk if o.generate > 0 else 1), 10), lstm_dtype=dt, vgg_dtype=vdt,
                     max_images=max(o.batchsize, 1) if o.cnn else 0)
     param = L.initweights(ctx, seed=o.seed if o.seed > 0 else 42) if host_model is None else L.model_from_arrays(host_model)
-    print("LSTM is initialized")
+    say("LSTM is initialized")
     mean = L.VGG_MEAN
     if o.cnn:
-        print("Reading", o.model)
+        say("Reading", o.model)
         if o.model.startswith("synthetic"):  # "synthetic[:seed]": He-normal weights (no pretrained file offline) -- tests / benchmarks
             L.vgg_load(ctx, *L.synthetic_vgg_weights(seed=int(o.model.split(":")[1]) if ":" in o.model else 1, bias_std=0.05))
         else:
@@ -129,7 +167,7 @@ def main(argv=None):
             if fmt.load_vgg_mat.average_image is not None:  # the reference subtracts the full array (lrcn.jl:113, 770)
                 L.set_average_image(ctx, fmt.load_vgg_mat.average_image)
                 mean = None
-        print("Cnn is initialized")
+        say("Cnn is initialized")
 
     def load_crops(paths):
         """read_image_data (lrcn.jl:750-765) for a batch: decode on the host, resize / crop / grey->RGB on the GPU."""
@@ -193,50 +231,52 @@ def main(argv=None):
         print("image features extracted")
         return 0
 
-    # ---------------------------------------------------------------- train! (lrcn.jl:223-246)
+    # ---------------------------------------------------------------- train! (lrcn.jl:223-246) on dp.DataParallelTrainer
     if lists and o.train:
-        print("Batching starts")
+        say("Batching starts")
         seqs = [cap.minibatch(c, vocab, o.batchsize) for c in lists]
-        print("Batching finished")
+        say("Batching finished")
+        B_global = seqs[0][3]   # splits with <= 30000 captions are forced to batch 10 (lrcn.jl:260-270)
+        if B_global % world:
+            raise SystemExit("the batch of %d captions does not split over %d ranks" % (B_global, world))
         optim = L.initparams(param)
         optim.lr = o.lr
-        if adam_state is not None:
-            for dst, src in zip(optim.m, adam_state["m"]):
-                dst.copy_(L.to_jl(src))
-            for dst, src in zip(optim.v, adam_state["v"]):
-                dst.copy_(L.to_jl(src))
-            optim.t = adam_state["step"]
-        grads = L.zeros_like_model(param)
+        from_images = bool(o.cnn) and not o.features
+        seed = o.seed if o.seed > 0 else 0
+        trainer = dp.DataParallelTrainer(ctx, param, optim, B_global, world, rank, pdrop=o.dropout, seed=seed, backend=o.dp_backend, ops=dp.HipOps(ctx, mean=mean),
+                                         shard_adam=bool(o.shard_adam) and world > 1, normalize_features=from_images and not o.no_normalize,
+                                         gclip=o.gclip)
+        if adam_state is not None:   # resume: moments and step count (the reference never saved them)
+            trainer.restore(adam=(adam_state["m"], adam_state["v"], adam_state["step"]))
+        splits = [list(cap.batches(sq[0], sq[1], sq[2], sq[3])) for sq in seqs[:2]]
 
-        def average_loss(seq, table):
-            blocks = [(feature_rows(table, ids), toks) for ids, toks in cap.batches(seq[0], seq[1], seq[2], seq[3])]
-            return L.average_loss(ctx, param, blocks)
+        def image_path(i):
+            return os.path.join(o.imagedir, "%s%012d.jpg" % (o.prefix, i) if o.prefix else "%d.jpg" % i)
 
-        for epoch in range(1, o.epochs + 1):
-            seq, t0, nimg = seqs[0], time.time(), 0
-            blocks = list(cap.batches(seq[0], seq[1], seq[2], seq[3]))
-            for k in rng.permutation(len(blocks)):  # shuffle(1:batch_size:length(lengths)), lrcn.jl:351
-                ids, toks = blocks[k]
-                if o.gclip > 0:
-                    g, _ = L.lossgradient(ctx, param, feature_rows(feats[0], ids), toks, pdrop=o.dropout, seed=epoch * 1000003 + int(k),
-                                          grads=grads)
-                    gn = float(torch.sqrt(sum((t.float() ** 2).sum() for t in g)))
-                    if gn > o.gclip:
-                        for t in g:
-                            t.mul_(o.gclip / gn)
-                    L.update(ctx, param, g, optim)
-                else:
-                    L.train_step(ctx, param, optim, grads, feature_rows(feats[0], ids), toks, pdrop=o.dropout, seed=epoch * 1000003 + int(k))
-                nimg += len(ids)
-            ctx.sync()
-            dt_s = time.time() - t0
-            if o.savefile:
+        def crops_of(ids):
+            return load_crops([image_path(i) for i in ids])
+
+        if from_images:   # end to end: ids -> crops -> VGG on the device; average_loss runs the same forward batch by batch
+            def eval_f(ids):
+                return L.convnet_u8(ctx, crops_of(ids), mean=mean, normalize=not o.no_normalize)
+            kw = dict(crops_of=crops_of, eval_feats_of=[eval_f] * len(splits))
+        else:
+            if not feats:
+                raise SystemExit("--train needs --features (precomputed fc7 features) or --cnn --imagedir (train from images)")
+            tables = [feats[0], feats[min(1, len(feats) - 1)]]
+            kw = dict(feats_of=lambda ids: feature_rows(tables[0], ids), eval_feats_of=[(lambda ids, t=t: feature_rows(t, ids)) for t in tables[:len(splits)]])
+
+        def save(epoch):
+            if o.savefile and rank == 0:
                 fmt.save_checkpoint(o.savefile, [L.from_jl(p) for p in param], vocab,
                                     adam={"m": [L.from_jl(t) for t in optim.m], "v": [L.from_jl(t) for t in optim.v], "step": optim.t})
-            losses = [average_loss(seqs[0], feats[0])]
-            if len(seqs) > 1:
-                losses.append(average_loss(seqs[1], feats[min(1, len(feats) - 1)]))
-            print("(:epoch, %d, :loss, %s)  [%.0f captions/s]" % (epoch, ", ".join("%.4f" % v for v in losses), nimg / max(dt_s, 1e-9)))
+
+        trn.train(trainer, splits, o.epochs, seed, save=save, log=say, sync=ctx.sync, **kw)
+        trainer.close()
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return 0
     if o.savefile and not o.train:
         fmt.save_checkpoint(o.savefile, [L.from_jl(p) for p in param], vocab)
     return 0
