@@ -171,6 +171,10 @@ def parse_args(argv=None):
     ap.add_argument("--pdrop", type=float, default=0.4)
     ap.add_argument("--layers", type=int, default=None, choices=[1, 2])  # 1 = LRCN-1f (this repo's definition of configs[1]'s "1-layer LSTM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--vgg-chunk-images", type=int, default=int(os.environ.get("LRCN_VGG_CHUNK_IMAGES", "256")),
+                    help="a rank whose own batch is smaller than this runs the VGG forward of its next m = chunk // batch steps as ONE forward (the "
+                         "frozen extractor does not depend on the parameters) and feeds one feature block per step: 32 rows per GPU -> 4 steps per "
+                         "forward.  Every image still passes through the VGG exactly once inside the timed region.  0 / 1 = one forward per step")
     ap.add_argument("--inputs", default="host", choices=["host", "hbm"],
                     help="where a step finds its crops: 'host' (default; BASELINE.md section 3) = pinned host memory, uploaded per step on the library's "
                          "copy stream one step ahead of the VGG forward that reads them (lrcn_upload_crops); 'hbm' = already resident in device memory")
@@ -371,20 +375,26 @@ def main(argv=None):
     rows = dp.shard_rows(Bg, world * a.emulate_world, rank)
     B = rows.stop - rows.start
 
-    ctx = L.Context(E, H, H, V, max_B=B, max_T=T, lstm_dtype=dt, vgg_dtype=dt, max_images=B, n_layers=a.layers)
+    # training batches per VGG forward: 8 at 32 rows per GPU, 4 at 64; one from 128 rows (measured: no gain there, dp.vgg_wg_cap_for)
+    m_chunk = max(1, a.vgg_chunk_images // B) if B <= 64 else 1
+    Bv = m_chunk * B
+    ctx = L.Context(E, H, H, V, max_B=B, max_T=T, lstm_dtype=dt, vgg_dtype=dt, max_images=Bv, n_layers=a.layers)
     vgg_w = L.synthetic_vgg_weights(seed=1)
     L.vgg_load(ctx, *vgg_w)
     param = L.initweights(ctx, seed=42)          # identical on every rank (same seed)
     optim = L.initparams(param)
     backend = a.dp_backend if a.dp_backend != "auto" else "torch"   # 'auto' is resolved by launch(); a torchrun-launched job cannot retry
+    emu_shard = bool(a.shard_adam) and a.emulate_world > 1   # one process: rank 0's side of the sharded update, collectives stubbed by copies
     trainer = dp.DataParallelTrainer(ctx, param, optim, Bg, world, rank, pdrop=a.pdrop, seed=7, backend=backend,
-                                     shard_adam=bool(a.shard_adam) and world > 1)
+                                     shard_adam=bool(a.shard_adam) and (world > 1 or emu_shard), vgg_chunk=m_chunk, rows=B,
+                                     emulate_shards=a.emulate_world if emu_shard else 0)
 
     # synthetic inputs: uint8 crops uniform seed 1234; Zipf(1.0) word ids >= 3, seed 7; one T per batch
     g = torch.Generator(device="cuda")
     g.manual_seed(1234)
     n_sets = 2
-    imgs_dev = [torch.randint(0, 256, (Bg, 224, 224, 3), generator=g, device="cuda", dtype=torch.uint8)[rows].contiguous()
+    # one "chunk" = the crops of m_chunk consecutive steps of this rank (m_chunk = 1: one batch)
+    imgs_dev = [torch.cat([torch.randint(0, 256, (Bg, 224, 224, 3), generator=g, device="cuda", dtype=torch.uint8)[rows] for _ in range(m_chunk)]).contiguous()
                 for _ in range(n_sets)]
     # --inputs host: the same crops in page-locked host memory; every step uploads the batch AFTER next on the copy stream
     imgs_all = [t.cpu().pin_memory() for t in imgs_dev] if a.inputs == "host" else imgs_dev
@@ -395,6 +405,7 @@ def main(argv=None):
                                 .copy()).cuda() for _ in range(n_sets)]
 
     step_ev = []
+    chunk_i = [0]   # index of the chunk whose features are being consumed
     host_t = [] if os.environ.get("LRCN_BENCH_HOST_TIMES") else None   # development: when the host ENTERED each step (issue-side timeline)
 
     def run(nsteps, events=False):
@@ -405,8 +416,10 @@ def main(argv=None):
             k = trainer.step_no  # global step index: batch k uses image/token set k mod n_sets, also across warm-up -> timed region
             if host_t is not None:
                 host_t.append(time.perf_counter())
-            trainer.step(imgs_all[k % n_sets], toks_all[k % n_sets], next_img_u8=imgs_all[(k + 1) % n_sets],
-                         prefetch_img_u8=imgs_all[(k + 2) % n_sets] if a.inputs == "host" else None)
+            ci = chunk_i[0]
+            if trainer.step(imgs_all[ci % n_sets][:B], toks_all[k % n_sets], next_img_u8=imgs_all[(ci + 1) % n_sets],
+                            prefetch_img_u8=imgs_all[(ci + 2) % n_sets] if a.inputs == "host" else None):
+                chunk_i[0] = ci + 1
             if events:  # one event per step on the main stream (no host sync): per-step intervals -> the median SURVEY 8(d) asks for
                 e = torch.cuda.Event(enable_timing=True)
                 e.record()
@@ -459,7 +472,7 @@ def main(argv=None):
         # dominant kernel family: the 12 convolution launches conv1_2..conv5_3 (2 x conv64_kernel + 10 x gemm8p_kernel<CONV3>)
         # bf16: conv1_1 runs inside conv1_2's launch (conv64.hip FUSE), so its FLOPs belong to the 12 timed launches
         fused11 = a.dtype == "bf16" and os.environ.get("LRCN_FUSE11", "1")[:1] != "0" and os.environ.get("LRCN_CONV64", "1")[:1] != "0"
-        flops_per_launch = (VGG_CONV_GFLOP_PER_IMAGE - (0.0 if fused11 else CONV11_GFLOP_PER_IMAGE)) * 1e9 * B / 12.0
+        flops_per_launch = (VGG_CONV_GFLOP_PER_IMAGE - (0.0 if fused11 else CONV11_GFLOP_PER_IMAGE)) * 1e9 * Bv / 12.0
         avg_launch_s = conv_ms.value * 1e-3 / max(conv_n.value, 1)
         achieved = flops_per_launch / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
         peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
@@ -479,13 +492,17 @@ def main(argv=None):
                                    % (workload_name(a), "LRCN-2f (2-layer)" if a.layers == 2 else "LRCN-1f (1-layer)", H, V, T, Bg,
                                       world, a.pdrop),
                        "global_batch": Bg, "per_gpu_batch": B, "seq_len": T + 1, "parallelism": "dp%d" % world,
+                       "vgg_forward": ("one forward per step (%d images)" % B) if m_chunk == 1 else
+                                      ("one forward per %d steps (%d images: the crops of the next %d batches of this rank; one feature block per step)" % (m_chunk, Bv, m_chunk)),
                        "last_loss": loss,
                        "inputs": ("pinned host, H2D per step on a copy stream (%.1f MB per step, uploaded one step ahead of the forward that reads it)"
                                   % (B * 224 * 224 * 3 / 1e6)) if a.inputs == "host" else "resident in HBM",
                        "setup_spinup": "%d untimed VGG forwards (%.0f ms) before the warm-up steps; not training steps" % (spun, a.spinup_ms)},
             "rccl": {"world": world, "backend": ("none (one rank: no collective)" if world == 1 else
                                                  ("gloo on ONE shared GPU (LRCN_BENCH_FAKE_MULTI: validation, not a measurement)" if fake_multi else trainer.backend)),
-                     "update": "sharded (reduce-scatter -> Adam on 1/N -> all-gather)" if trainer.shard else "replicated (all-reduce -> Adam)",
+                     "update": ("EMULATED sharded update (Adam on 1/%d of every gradient group; reduce-scatter / all-gather stubbed by device copies of the "
+                                "bytes a rank receives; the other shards' parameters are not updated)" % a.emulate_world) if emu_shard else
+                               ("sharded (reduce-scatter -> Adam on 1/N -> all-gather)" if trainer.shard else "replicated (all-reduce -> Adam)"),
                      "launched_by": "bench.py" if os.environ.get("LRCN_BENCH_LAUNCHED") else ("torch.distributed.run" if world > 1 else "direct")},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": traffic, "traffic_source": traffic_note,

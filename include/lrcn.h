@@ -192,6 +192,11 @@ int lrcn_comm_probe(lrcn_ctx *ctx);
 /* Collective over the `world` contexts: binds ctx to rank `rank` of the communicator named by the id. */
 int lrcn_comm_init(lrcn_ctx *ctx, int world, int rank, const void *unique_id);
 int lrcn_comm_destroy(lrcn_ctx *ctx);
+/* The stream on which the context issues every collective and every per-group update of lrcn_allreduce_grads / lrcn_train_step_dp (rev 4;
+ * default: a stream of its own).  HIP multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, default 4) and two streams on one
+ * queue run in order: a host that also runs the VGG forward of the next step on a side stream hands in an update stream that it has
+ * checked NOT to share that side stream's queue (lrcn_amd/dp.py streams_share_a_queue), or a group's Adam waits for the whole forward. */
+int lrcn_comm_set_stream(lrcn_ctx *ctx, void *hip_stream);
 /* In-place all-reduce(SUM) of gradient group `group` (0 .. LRCN_GRAD_GROUPS-1; -1 = all groups) of the most recent lrcn_loss_grad:
  * the group's stream waits for its gradient-ready event, then runs the collective (a no-op without a communicator / with one rank).
  * Asynchronous; lrcn_comm_join makes the context's stream wait for everything issued on the group streams. */
@@ -231,6 +236,12 @@ int lrcn_vgg_forward(lrcn_ctx *ctx, const float *x, int N, float *feats);
 int lrcn_preprocess_u8(lrcn_ctx *ctx, const uint8_t *img, int N, const float mean[3], float *out);
 /* Both of the above fused (no (224,224,3,N) float round trip): the training-path entry. */
 int lrcn_vgg_forward_u8(lrcn_ctx *ctx, const uint8_t *img, int N, const float mean[3], float *feats);
+/* The same forward for the crops of SEVERAL training batches at once (rev 4): N = m * block_rows images in, m consecutive
+ * block_rows x 4096 column-major feature arrays out (block b at feats + b * block_rows * 4096), each optionally divided by its row sums
+ * (lrcn.jl:595-597).  The frozen extractor does not depend on the LSTM parameters, so a data-parallel rank whose own batch is small
+ * (32 rows of a 256 batch on 8 GPUs) runs the convolutions for the next m steps in one forward at the efficiency of a large batch
+ * (VGG alone on one MI355X: 32 images 1.13 ms = 880 TFLOP/s, 128 images 3.38 ms = 1172 TFLOP/s) and feeds one block per step. */
+int lrcn_vgg_forward_u8_blocks(lrcn_ctx *ctx, const uint8_t *img, int N, const float mean[3], int block_rows, int normalize, float *feats);
 /* The full VGG averageImage (lrcn.jl:113: vgg["meta"]["normalization"]["averageImage"], (224,224,3) column-major, device pointer;
  * copied).  Once set, the *_u8 entry points subtract it instead of mean[3] (mean may then be NULL), exactly where the reference does:
  * before its last H <-> W permutedims (lrcn.jl:770-771), i.e. pixel (row r, col q, c) meets averageImage(q, r, c).  NULL turns it off. */

@@ -78,6 +78,7 @@ SIGNATURES = {
     "lrcn_comm_unique_id": (C.c_int, [C.c_void_p]),
     "lrcn_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "lrcn_comm_destroy": (C.c_int, [C.c_void_p]),
+    "lrcn_comm_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "lrcn_allreduce_grads": (C.c_int, [C.c_void_p, P9, C.c_int]),
     "lrcn_comm_join": (C.c_int, [C.c_void_p]),
     "lrcn_train_step_dp": (C.c_int, [C.c_void_p, P9, P9, P9, P9, C.c_void_p, C.POINTER(C.c_float), C.c_int, C.c_void_p, C.c_void_p, C.c_int,
@@ -91,6 +92,7 @@ SIGNATURES = {
     "lrcn_vgg_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "lrcn_preprocess_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_void_p]),
     "lrcn_vgg_forward_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_void_p]),
+    "lrcn_vgg_forward_u8_blocks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_void_p]),
     "lrcn_set_average_image": (C.c_int, [C.c_void_p, C.c_void_p]),
     "lrcn_resize_crop_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                       C.c_int, C.c_void_p]),

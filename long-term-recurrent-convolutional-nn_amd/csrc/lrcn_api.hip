@@ -153,6 +153,10 @@ struct lrcn_ctx {
     int stage_next = 0;
     LrcnComm *comm = nullptr;
     hipStream_t comm_stream = nullptr;  // every collective of the communicator is issued on this ONE stream, in group order
+    bool comm_stream_owned = false;     // created here (destroyed here), or handed in through lrcn_comm_set_stream
+    // bucket[g] == comm_stream for every g since round 4: the groups become final in order, so one stream runs [wait, all-reduce, Adam] of
+    // group after group and loses nothing, while five streams on HIP's four hardware queues meant that one of them shared a queue with the
+    // VGG side stream and its Adam waited for the whole forward (dp.py streams_share_a_queue)
     hipStream_t bucket[LRCN_GRAD_GROUPS] = {};
     hipEvent_t ar_done[LRCN_GRAD_GROUPS] = {};
     hipEvent_t bucket_done[LRCN_GRAD_GROUPS] = {};
@@ -920,9 +924,7 @@ void lrcn_destroy(lrcn_ctx *c) {
         if (e) (void)hipEventDestroy(e);
     for (auto &e : c->ar_done)
         if (e) (void)hipEventDestroy(e);
-    for (auto &b : c->bucket)
-        if (b) (void)hipStreamDestroy(b);
-    if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
+    if (c->comm_stream && c->comm_stream_owned) (void)hipStreamDestroy(c->comm_stream);
     for (auto &e : c->prof_ev) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
@@ -1256,9 +1258,12 @@ bool dp_force_pipeline() {
 }
 
 int ensure_buckets(lrcn_ctx *c) {
-    if (!c->comm_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    if (!c->comm_stream) {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+        c->comm_stream_owned = true;
+    }
     for (int g = 0; g < LRCN_GRAD_GROUPS; ++g) {
-        if (!c->bucket[g]) HIPCHK(c, hipStreamCreateWithFlags(&c->bucket[g], hipStreamNonBlocking));
+        c->bucket[g] = c->comm_stream;
         if (!c->bucket_done[g]) HIPCHK(c, hipEventCreateWithFlags(&c->bucket_done[g], hipEventDisableTiming));
         if (!c->ar_done[g]) HIPCHK(c, hipEventCreateWithFlags(&c->ar_done[g], hipEventDisableTiming));
     }
@@ -1335,6 +1340,20 @@ int lrcn_comm_init(lrcn_ctx *c, int world, int rank, const void *unique_id) {
     char err[256] = "";
     c->comm = comm_create(world, rank, unique_id, err, sizeof(err));
     if (!c->comm) FAIL(c, LRCN_EHIP, "%s", err);
+    return ensure_buckets(c);
+}
+
+int lrcn_comm_set_stream(lrcn_ctx *c, void *hip_stream) {
+    DeviceGuard dg(c);
+    if (!c || !hip_stream) return LRCN_EINVAL;
+    for (bool p : c->bucket_pending)
+        if (p) FAIL(c, LRCN_ESTATE, "a gradient exchange is in flight: call lrcn_comm_join first");
+    if (c->comm_stream && c->comm_stream_owned) {
+        HIPCHK(c, hipStreamSynchronize(c->comm_stream));
+        (void)hipStreamDestroy(c->comm_stream);
+    }
+    c->comm_stream = reinterpret_cast<hipStream_t>(hip_stream);
+    c->comm_stream_owned = false;
     return ensure_buckets(c);
 }
 
@@ -2183,6 +2202,23 @@ int lrcn_vgg_forward_u8(lrcn_ctx *c, const uint8_t *img, int N, const float mean
     if (r) return r;
     k_transpose_f32(c->stream, c->featsRM, 4096, N, 4096, feats, N);
     KCHK(c, "vgg_forward_u8");
+    return LRCN_OK;
+}
+
+int lrcn_vgg_forward_u8_blocks(lrcn_ctx *c, const uint8_t *img, int N, const float mean[3], int block_rows, int normalize, float *feats) {
+    DeviceGuard dg(c);
+    if (!c || !img || !feats || (!mean && !c->avg_on)) return LRCN_EINVAL;
+    int r = vgg_check(c, N);
+    if (r) return r;
+    if (block_rows < 1 || N % block_rows) FAIL(c, LRCN_EINVAL, "block_rows=%d must divide N=%d", block_rows, N);
+    r = vgg_body(c, N, img, true, mean);
+    if (r) return r;
+    for (int b = 0; b < N / block_rows; ++b) {  // block b: rows [b block_rows, (b+1) block_rows) as its own block_rows x 4096 column-major array
+        float *dst = feats + (int64_t)b * block_rows * LRCN_CNNOUT;
+        k_transpose_f32(c->stream, c->featsRM + (int64_t)b * block_rows * LRCN_CNNOUT, 4096, block_rows, 4096, dst, block_rows);
+        if (normalize) k_normalize_rows(c->stream, dst, block_rows, LRCN_CNNOUT);
+    }
+    KCHK(c, "vgg_forward_u8_blocks");
     return LRCN_OK;
 }
 

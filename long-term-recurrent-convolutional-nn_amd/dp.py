@@ -9,6 +9,7 @@ synchronous-SGD semantics: RCCL runs on its own stream, the compute stream waits
 On the GPU the VGG forward of step k+1 also runs on a SIDE HIP stream, concurrently with the LSTM step k (hundreds of small,
 latency-bound launches that leave most CUs idle): the frozen extractor shares nothing with the LSTM but read-only weights.
 """
+import collections
 import ctypes as C
 import os
 
@@ -27,13 +28,54 @@ def shard_rows(B_global, world, rank):
     return slice(rank * b, (rank + 1) * b)
 
 
-def vgg_wg_cap_for(device):
+def vgg_wg_cap_for(device, rows=256, chunk=1):
     """Convolution-grid cap for the side-stream VGG forward: 7/8 of the CUs (224 of 256).  The capped kernels walk their
     tiles persistently and leave 32 CUs on which the LSTM step's chain of small dependent launches never queues behind
     27-us convolution workgroups.  Measured on one MI355X (ms/step, cap 0 -> 224): B=32 1.86 -> 1.72, B=64 2.78 -> 2.49,
-    B=128 4.60 -> 4.44, B=256 8.58 -> 8.31 (same box); 192 and 240 are slower than either (tile-count quantisation)."""
+    B=128 4.60 -> 4.44, B=256 8.58 -> 8.31 (same box); 192 and 240 are slower than either (tile-count quantisation).
+    Several batches per forward (chunk > 1, rows <= 64 per step): the forward of 256 images then runs beside 8 (4) whole LSTM steps,
+    whose Adam and time-batched GEMMs want CUs too -- round 4, same box, ms/step at 32 rows with 8 steps per forward: cap 224 1.65,
+    196 1.53, 176 1.49, 160 1.37, 147 1.38, 128 1.43 (one forward per step, cap 224: 1.60); at 64 rows with 4 steps per forward:
+    224 2.47, 196 2.19, 176 2.17, 160 2.29 (one per step: 2.28)."""
     ncu = torch.cuda.get_device_properties(device).multi_processor_count
+    if chunk > 1 and rows <= 32:
+        return (ncu * 5 // 8) & ~7      # 160 of 256
+    if chunk > 1 and rows <= 64:
+        return (ncu * 11 // 16) & ~7    # 176 of 256
     return (ncu * 7 // 8) & ~7
+
+
+def streams_share_a_queue(a, b, device):
+    """HIP multiplexes its streams onto a few hardware queues (GPU_MAX_HW_QUEUES, default 4): two streams on one queue run IN ORDER, whatever
+    the program says.  Measured, not assumed: a ~2 ms sleep kernel on `a`, then a tiny kernel on `b` -- if b's finishes only after a's, they
+    share a queue.  (Round 4: a gradient-group stream that shared the VGG side stream's queue made its Adam wait for the whole forward --
+    one step in eight took 9 ms instead of 1.1 with 8 steps per forward.)"""
+    torch.cuda.synchronize(device)
+    e0, e_long, e_short = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    y = torch.zeros(16, device=device)
+    with torch.cuda.stream(a):
+        e0.record()
+        torch.cuda._sleep(4_000_000)
+        e_long.record()
+    with torch.cuda.stream(b):
+        y.add_(1.0)
+        e_short.record()
+    torch.cuda.synchronize(device)
+    return e0.elapsed_time(e_short) > 0.5 * e0.elapsed_time(e_long)
+
+
+def independent_stream(device, avoid, tries=12):
+    """A new stream that shares its hardware queue with none of `avoid` (streams whose work must never be serialised with it).  The
+    rejected candidates stay alive so that the next candidate lands on another queue.  None if every try collides."""
+    keep = []
+    for _ in range(tries):
+        s = torch.cuda.Stream(device=device)
+        if not any(streams_share_a_queue(o, s, device) or streams_share_a_queue(s, o, device) for o in avoid if o is not None):
+            independent_stream._rejected = getattr(independent_stream, "_rejected", []) + keep
+            return s
+        keep.append(s)
+    independent_stream._rejected = getattr(independent_stream, "_rejected", []) + keep
+    return None
 
 
 # lossgradient finalises the gradients in this order of groups of (adjacent) parameters -- include/lrcn.h, LRCN_GRAD_GROUPS
@@ -81,6 +123,10 @@ class HipOps:
         """Forward-only loss of one batch (average_loss's body, lrcn.jl:452-475): pdrop 0, normalised by the batch's own size."""
         return L.loss(self.ctx, param, feats, tokens)
 
+    def vgg_blocks(self, img_u8, rows, feats=None, normalize=False):
+        """One forward for the crops of several batches -> list of rows x 4096 feature blocks (lrcn_vgg_forward_u8_blocks)."""
+        return L.convnet_u8_blocks(self.ctx, img_u8, rows, mean=self.mean, feats=feats, normalize=normalize)
+
     def upload(self, host_u8):
         """Start the host -> device copy of a batch of crops on the library's copy stream (returns at once)."""
         return L.upload_crops(self.ctx, host_u8)
@@ -118,17 +164,25 @@ class HipOps:
         """`stream` waits until the gradients of GRAD_GROUPS[group] of the last lossgradient are final."""
         self.ctx._call("lrcn_grad_group_wait", group, C.c_void_p(stream.cuda_stream))
 
-    # the [all-reduce -> Adam] pipeline of the torch.distributed backend runs on one stream per gradient group
-    def make_streams(self, n):
-        return [torch.cuda.Stream(device=self.ctx.device) for _ in range(n)]
+    # the [all-reduce -> Adam] pipeline of the torch.distributed backend: ONE update stream for all gradient groups (they become final in
+    # order, so one stream loses nothing), chosen so that it does not share a hardware queue with the VGG side stream -- see
+    # streams_share_a_queue.  LRCN_DP_GROUP_STREAMS=1: one stream per group, as rounds 2-3 had it.
+    def make_streams(self, n, avoid=()):
+        if os.environ.get("LRCN_DP_GROUP_STREAMS", "0")[:1] == "1":
+            return [torch.cuda.Stream(device=self.ctx.device) for _ in range(n)]
+        s = independent_stream(torch.device("cuda", self.ctx.device), list(avoid)) or torch.cuda.Stream(device=self.ctx.device)
+        return [s] * n
 
     def stream_ctx(self, stream):
         return torch.cuda.stream(stream)
 
     def join(self, streams):
         main = torch.cuda.current_stream(self.ctx.device)
+        seen = []
         for s in streams:
-            main.wait_stream(s)  # the next step's shadow-weight pass reads the updated parameters
+            if not any(s is t for t in seen):
+                main.wait_stream(s)  # the next step's shadow-weight pass reads the updated parameters
+                seen.append(s)
 
     # the C-ABI backend: RCCL inside liblrcn_hip (lrcn_comm_init / lrcn_train_step_dp)
     def comm_probe(self):
@@ -136,6 +190,13 @@ class HipOps:
 
     def comm_init(self, world, rank, unique_id):
         L.comm_init(self.ctx, world, rank, unique_id)
+
+    def comm_set_stream(self, avoid=()):
+        """Give the library's communicator an update stream that shares its hardware queue with none of `avoid` (the VGG side stream)."""
+        s = independent_stream(torch.device("cuda", self.ctx.device), list(avoid))
+        if s is not None:
+            L.comm_set_stream(self.ctx, s)
+            self._comm_stream = s   # kept alive for the communicator's lifetime
 
     def set_fused_update(self, on):
         """LRCN_OPT_FUSED_UPDATE: Adam writes the next step's shadow weights; the trainer owns the parameters between steps."""
@@ -162,7 +223,7 @@ class DataParallelTrainer:
     close() turns the option off again: it belongs to the context and would otherwise outlive the trainer."""
 
     def __init__(self, ctx, param, optim, B_global, world=1, rank=0, pdrop=0.4, seed=0, group=None, ops=None, backend=None, shard_adam=None,
-                 normalize_features=False, gclip=0.0):
+                 normalize_features=False, gclip=0.0, vgg_chunk=1, rows=None, emulate_shards=0):
         """backend (world > 1): "torch" (default) = the per-group all-reduces are issued from here through torch.distributed's RCCL
         process group; "abi" = RCCL inside liblrcn_hip (lrcn_comm_init + lrcn_train_step_dp: one C call per step, what a Julia host
         would drive; the unique id travels over torch.distributed's group).  LRCN_DP_BACKEND overrides.  "abi" stays opt-in until a
@@ -176,6 +237,10 @@ class DataParallelTrainer:
         # --gclip (parsed and ignored by the reference): clip the GLOBAL gradient norm, i.e. after the exchange and before update! -- which
         # rules out the per-group [all-reduce -> Adam] pipeline: one all-reduce of the flat buffer, the norm, one Adam launch
         self.gclip = float(gclip or 0.0)
+        # emulate_shards = N > 1 (one process, world = 1; bench.py --emulate-world N --shard-adam): rank 0's side of an N-rank SHARDED update
+        # with the two collectives stubbed by device copies of the bytes a rank receives -- Adam on 1/N of every gradient group, the other
+        # (N-1)/N of the parameters are NOT updated.  A timing aid, never a training mode.
+        self._emu_shards = int(emulate_shards) if world == 1 and emulate_shards and emulate_shards > 1 else 0
         backend = os.environ.get("LRCN_DP_BACKEND") or backend or "torch"
         if backend == "auto":
             backend = "torch"
@@ -210,16 +275,18 @@ class DataParallelTrainer:
         if self._fused:
             self.ops.set_fused_update(True)
         shapes = [tuple(t.shape) for t in param]
+        self._W = self._emu_shards or max(world, 1)   # number of parameter shards of the sharded update
         if self.shard:
-            align = 4 * max(world, 1)  # every rank's slice is a whole number of 16-byte chunks
+            align = 4 * self._W  # every rank's slice is a whole number of 16-byte chunks
             dev = param[0].device
             self.flat_param, pviews, self._ranges = flat_model_like(shapes, device=dev, group_align=align)
             for k, v in enumerate(pviews):
                 v.copy_(param[k])
                 param[k] = v           # the caller's list now refers to the flat buffer
             self.flat_grads, self.grads, _ = flat_model_like(shapes, device=dev, group_align=align)
-            n_of = [(b - a) // max(world, 1) for a, b in self._ranges]
+            n_of = [(b - a) // self._W for a, b in self._ranges]
             self._shapes, self._align = shapes, align
+            self._emu_scratch = torch.empty(max(b - a for a, b in self._ranges), device=dev, dtype=torch.float32) if self._emu_shards else None
             self._m = [torch.zeros(n, device=dev, dtype=torch.float32) for n in n_of]
             self._v = [torch.zeros(n, device=dev, dtype=torch.float32) for n in n_of]
             self._gshard = [torch.zeros(n, device=dev, dtype=torch.float32) for n in n_of]
@@ -227,15 +294,16 @@ class DataParallelTrainer:
         else:
             self.flat_grads, self.grads = flat_model_like(shapes, device=param[0].device)
         self.step_no = 0
-        self._feats_next = None
+        self._feat_q = collections.deque()   # (features of an upcoming step, event of the forward that makes them or None), in step order
+        self._chunk_no = 0
         self._side = self.ops.side_stream() if hasattr(self.ops, "side_stream") else None
         if self._side is not None and hasattr(self.ops, "set_vgg_wg_cap"):
             env = os.environ.get("LRCN_VGG_WG_CAP")
-            cap = int(env) if env is not None else vgg_wg_cap_for(param[0].device)
+            cap = int(env) if env is not None else vgg_wg_cap_for(param[0].device, int(rows) if rows else B_global // max(world, 1), int(vgg_chunk))
             self.ops.set_vgg_wg_cap(cap)
-        self._vgg_done = None    # event: the side stream finished the VGG forward whose output is _feats_next
-        self._feats_buf = [None, None]  # ping-pong outputs of the side-stream VGG
+        self._feats_buf = [None, None]  # ping-pong outputs of the side-stream VGG (one chunk each)
         self._bucket_streams = None
+        self._abi_stream_set = False
         self._prefetched = None  # (host tensor, staged device crops): the upload started by the previous step's prefetch_img_u8
 
     # ---- parameter / optimizer state hand-over (checkpoints) ----
@@ -264,7 +332,7 @@ class DataParallelTrainer:
 
     def _scatter_optim_state(self):
         """Sharded update: this rank's 1/N slices of the optimizer's moments (group-padded flat layout, as the parameters)."""
-        W, r = max(self.world, 1), self.rank
+        W, r = self._W, self.rank
         for src, dst in ((self.optim.m, self._m), (self.optim.v, self._v)):
             flat, views, _ = flat_model_like(self._shapes, device=self.flat_param.device, group_align=self._align)
             for vw, t in zip(views, src):
@@ -279,8 +347,10 @@ class DataParallelTrainer:
         from `optim` holds the real state.  A no-op for the replicated update, whose optim.m / optim.v are the state."""
         if not self.shard:
             return
-        W = max(self.world, 1)
+        W = self._W
         coll = self.world > 1
+        if self._emu_shards:
+            raise L.LrcnError("emulate_shards is a timing aid: there is no whole optimizer state to gather")
         for shards, dst in ((self._m, self.optim.m), (self._v, self.optim.v)):
             flat, views, _ = flat_model_like(self._shapes, device=self.flat_param.device, group_align=self._align)
             for k, (a, b) in enumerate(self._ranges):
@@ -342,6 +412,12 @@ class DataParallelTrainer:
                 import sys
                 print("lrcn_amd.dp: %s; using torch.distributed collectives" % self.backend_note, file=sys.stderr)
 
+    def _make_update_streams(self):
+        try:
+            return self.ops.make_streams(len(GRAD_GROUPS), avoid=[self._side])
+        except TypeError:   # stand-in ops of the CPU tests
+            return self.ops.make_streams(len(GRAD_GROUPS))
+
     def _group_slices(self):
         """Flat-buffer ranges of the gradient groups, in the order lossgradient finalises them."""
         sizes = [g.numel() for g in self.grads]
@@ -359,7 +435,7 @@ class DataParallelTrainer:
         works = []
         gpu = hasattr(self.ops, "grad_group_wait") and hasattr(self.ops, "make_streams")
         if gpu and self._bucket_streams is None:
-            self._bucket_streams = self.ops.make_streams(len(GRAD_GROUPS))
+            self._bucket_streams = self._make_update_streams()
         for k, (a, b) in enumerate(self._group_slices()):
             if a == b:
                 continue  # LRCN-1f has no W2 / b2: nothing to exchange for that group
@@ -376,30 +452,43 @@ class DataParallelTrainer:
     def vgg(self, img_u8):
         return self.ops.vgg(img_u8, normalize=True) if self.normalize_features else self.ops.vgg(img_u8)
 
-    def _vgg_on_side_stream(self, img_u8):
-        """Issue VGG(img) on the side stream into a ping-pong buffer; the main stream waits on the event only when it
-        consumes the features (next step)."""
+    def _vgg_blocks(self, img_u8, rows, out=None):
+        """VGG forward of the crops of m = N / rows batches -> m feature blocks (rows x 4096 each)."""
+        if img_u8.shape[0] == rows or not hasattr(self.ops, "vgg_blocks"):
+            if img_u8.shape[0] != rows:
+                raise L.LrcnError("crops for %d rows given, the step has %d (these ops cannot run several batches in one forward)" % (img_u8.shape[0], rows))
+            return [self.ops.vgg(img_u8, feats=out, normalize=True) if self.normalize_features else self.ops.vgg(img_u8, feats=out)]
+        if img_u8.shape[0] % rows:
+            raise L.LrcnError("crops for %d rows are not a whole number of %d-row batches" % (img_u8.shape[0], rows))
+        return self.ops.vgg_blocks(img_u8, rows, feats=out, normalize=self.normalize_features)
+
+    def _vgg_on_side_stream(self, img_u8, rows):
+        """Issue the VGG forward of the next chunk of crops (one or several batches) on the side stream into a ping-pong buffer and queue
+        its feature blocks; the main stream waits on the event only when it consumes the first of them."""
         main = torch.cuda.current_stream(self.ctx.device)
-        k = self.step_no & 1
-        if self._feats_buf[k] is None or self._feats_buf[k].shape[0] != img_u8.shape[0]:
-            self._feats_buf[k] = L.jl_empty(img_u8.shape[0], L.CNNOUT)
-        # The crops (and the previous consumer of this buffer) are ordered before the forward.  Measured and not kept (round 3): three
+        k = self._chunk_no & 1
+        self._chunk_no += 1
+        n = img_u8.shape[0] * L.CNNOUT
+        if self._feats_buf[k] is None or self._feats_buf[k].numel() != n:
+            self._feats_buf[k] = (torch.empty(n, device=self.param[0].device, dtype=torch.float32) if img_u8.shape[0] != rows
+                                  else L.jl_empty(rows, L.CNNOUT))
+        # The crops (and the previous consumers of this buffer) are ordered before the forward.  Measured and not kept (round 3): three
         # rotating buffers with the side stream waiting only for the step TWO back, so that the VGG forward may run a step ahead of the
         # LSTM chain -- 7.115 / 7.117 -> 7.122 / 7.132 ms per step: both chains are as long as each other at 256 rows, nothing to run ahead of.
         self._side.wait_stream(main)
         self.ctx.use_stream(self._side)
         try:
-            feats = (self.ops.vgg(img_u8, feats=self._feats_buf[k], normalize=True) if self.normalize_features else
-                     self.ops.vgg(img_u8, feats=self._feats_buf[k]))
+            blocks = self._vgg_blocks(img_u8, rows, out=self._feats_buf[k])
         finally:
             self.ctx.use_stream(main)
         if torch.is_tensor(img_u8) and img_u8.is_cuda:
             # the crops were allocated on the main stream but are read by the side stream: tell the caching allocator, so a
             # caller that drops them right after step() cannot have the block recycled under the running convolution
             img_u8.record_stream(self._side)   # (staged crops live in the library's own buffers: nothing to record)
-        self._vgg_done = torch.cuda.Event()
-        self._vgg_done.record(self._side)
-        return feats
+        ev = torch.cuda.Event()
+        ev.record(self._side)
+        for b in blocks:
+            self._feat_q.append((b, ev))
 
     def _device_crops(self, img):
         """Device crops for a batch that may still be in (pinned) host memory: the staged copy that the previous step's prefetch_img_u8
@@ -414,38 +503,57 @@ class DataParallelTrainer:
 
     def step(self, img_u8, tokens, next_img_u8=None, feats=None, prefetch_img_u8=None):
         """One synchronous-SGD step on this rank's shard.  img_u8: this rank's uint8 crops (or feats given);
-        next_img_u8: the NEXT step's crops, whose VGG forward runs beside this step's LSTM work and all-reduce.
-        img_u8 is IGNORED when the previous step() prefetched this batch's features through its next_img_u8.
+        next_img_u8: the crops of the NEXT step(s), whose VGG forward runs beside this step's LSTM work and all-reduce.
+        img_u8 is IGNORED when an earlier step() already produced this batch's features through its next_img_u8.
+
+        Several batches per forward.  next_img_u8 may hold the crops of m >= 1 consecutive steps (m * B rows): the frozen extractor does
+        not depend on the parameters, so a rank whose own batch is small (32 rows of 256 on 8 GPUs) runs the convolutions of its next m
+        steps in ONE forward, at a large batch's efficiency, beside m LSTM steps, and consumes one feature block per step.  The forward of
+        a chunk is issued when the blocks in hand no longer cover m steps (i.e. with the first block of the previous chunk); until then
+        next_img_u8 is ignored.  Returns True when this call consumed next_img_u8 -- the caller then moves on to the following chunk.
+
         Crops may be CPU tensors (pinned for a true asynchronous copy): the reference uploads every batch's inputs inside its loop
-        (lrcn.jl:369-376); here the copy runs on the library's copy stream.  prefetch_img_u8: the crops of the step AFTER next (the
-        tensor that will be passed as next_img_u8 to the next call): their upload starts now, a whole step before the VGG forward that
-        reads them, so the forward never waits for PCIe.  A host buffer handed over must stay unchanged until its forward has been
-        queued AND the copy has run (HipOps.ctx: lrcn.upload_wait) -- a loader rotates at least three pinned buffers."""
+        (lrcn.jl:369-376); here the copy runs on the library's copy stream.  prefetch_img_u8: the chunk AFTER next_img_u8 (the tensor
+        that will be passed as next_img_u8 once this one has been consumed): its upload starts when next_img_u8 is consumed, a whole
+        chunk before the VGG forward that reads it, so the forward never waits for PCIe.  A host buffer handed over must stay unchanged
+        until its forward has been queued AND the copy has run (lrcn.upload_wait) -- a loader rotates at least three pinned buffers."""
+        rows = int(tokens.shape[1])
         if feats is None:
-            if self._feats_next is not None:
-                feats = self._feats_next
-                if self._vgg_done is not None:
-                    torch.cuda.current_stream(self.ctx.device).wait_event(self._vgg_done)
-                    self._vgg_done = None
+            if self._feat_q:
+                feats, ev = self._feat_q.popleft()
+                if ev is not None:
+                    torch.cuda.current_stream(self.ctx.device).wait_event(ev)
             else:
-                feats = self.vgg(self._device_crops(img_u8))
-        self._feats_next = None
+                blocks = self._vgg_blocks(self._device_crops(img_u8), rows)
+                feats = blocks[0]
+                self._feat_q.extend((b, None) for b in blocks[1:])
         self.step_no += 1
-        if next_img_u8 is not None:
-            next_img_u8 = self._device_crops(next_img_u8)
-        if next_img_u8 is not None and self._side is not None:
-            self._feats_next = self._vgg_on_side_stream(next_img_u8)  # concurrent with everything below
-        if prefetch_img_u8 is not None and hasattr(self.ops, "upload") and torch.is_tensor(prefetch_img_u8) and not prefetch_img_u8.is_cuda:
-            # after the forward above has been queued: that forward released (in issue order) the staging buffer this upload goes into
-            self._prefetched = (prefetch_img_u8, self.ops.upload(prefetch_img_u8))
+        consumed, deferred = False, None
+        if next_img_u8 is not None and len(self._feat_q) < max(1, next_img_u8.shape[0] // rows):
+            consumed = True
+            nxt = self._device_crops(next_img_u8)
+            if self._side is not None:
+                self._vgg_on_side_stream(nxt, rows)  # concurrent with everything below
+            else:
+                deferred = nxt   # in-order variant: issued after lossgradient (overlaps the gradient exchange only; frozen VGG)
+            if prefetch_img_u8 is not None and hasattr(self.ops, "upload") and torch.is_tensor(prefetch_img_u8) and not prefetch_img_u8.is_cuda:
+                # after the forward above has been queued: that forward released (in issue order) the staging buffer this upload goes into
+                self._prefetched = (prefetch_img_u8, self.ops.upload(prefetch_img_u8))
+
+        def inorder_vgg():
+            if deferred is not None:
+                self._feat_q.extend((b, None) for b in self._vgg_blocks(deferred, rows))
+
         # rank-dependent dropout stream: masks differ per shard like rows of one big batch would
         seed = (self.seed + self.step_no) * 65536 + self.rank
         if self.backend == "abi" and self._multi:
+            if not self._abi_stream_set and hasattr(self.ops, "comm_set_stream"):
+                self.ops.comm_set_stream(avoid=[self._side])
+                self._abi_stream_set = True
             # one C call: lossgradient + per-group [all-reduce over xGMI -> Adam] on the library's own streams
             self.ops.train_step_dp(self.param, self.grads, self.optim, feats, tokens, self.B_global, self.pdrop, seed)
-            if next_img_u8 is not None and self._side is None:
-                self._feats_next = self.vgg(next_img_u8)
-            return
+            inorder_vgg()
+            return consumed
         self.ops.lossgradient(self.param, feats, tokens, self.B_global, self.pdrop, seed, self.grads)
         if self.gclip > 0:
             if self.world > 1:
@@ -453,28 +561,25 @@ class DataParallelTrainer:
             gn = float(torch.linalg.vector_norm(self.flat_grads))
             if gn > self.gclip:
                 self.flat_grads.mul_(self.gclip / gn)
-            if next_img_u8 is not None and self._side is None:
-                self._feats_next = self.vgg(next_img_u8)
+            inorder_vgg()
             self.ops.update(self.param, self.grads, self.optim)
-            return
+            return consumed
         if self.shard:
             self._reduce_scatter_update_gather()
-            if next_img_u8 is not None and self._side is None:
-                self._feats_next = self.vgg(next_img_u8)
-            return
+            inorder_vgg()
+            return consumed
         if self._group_pipeline():
             # per gradient group, on its own stream: [wait for the group's event] -> [all-reduce] -> [Adam of that group], all
             # while the rest of the backward pass runs (it reads the bf16/f32 shadows, never the f32 parameters)
             self._reduce_and_update_groups()
-            if next_img_u8 is not None and self._side is None:
-                self._feats_next = self.vgg(next_img_u8)
-            return
+            inorder_vgg()
+            return consumed
         works = self._allreduce_async()
-        if next_img_u8 is not None and self._side is None:
-            self._feats_next = self.vgg(next_img_u8)  # in-order variant: overlaps the all-reduce only (frozen VGG)
+        inorder_vgg()
         for w in works:
             w.wait()  # the compute stream waits for RCCL
         self.ops.update(self.param, self.grads, self.optim)
+        return consumed
 
     def _group_pipeline(self):
         """Per-group [all-reduce -> Adam] needs the device-side gradient-group events and the per-group update entry point
@@ -491,7 +596,7 @@ class DataParallelTrainer:
 
     def _reduce_and_update_groups(self):
         if self._bucket_streams is None:
-            self._bucket_streams = self.ops.make_streams(len(GRAD_GROUPS))
+            self._bucket_streams = self._make_update_streams()
         self.optim.t += 1
         for k, (a, b) in enumerate(self._group_slices()):
             s = self._bucket_streams[k]
@@ -506,9 +611,9 @@ class DataParallelTrainer:
         """The sharded form of _reduce_and_update_groups: per group, on its own stream, [wait for the group's gradients] ->
         [reduce-scatter(SUM)] -> [Adam on this rank's slice] -> [all-gather of the parameters]; then one join."""
         if self._bucket_streams is None:
-            self._bucket_streams = self.ops.make_streams(len(GRAD_GROUPS))
+            self._bucket_streams = self._make_update_streams()
         self.optim.t += 1
-        W, r = max(self.world, 1), self.rank
+        W, r = self._W, self.rank
         # a one-rank process group given explicitly (tests on a one-GPU box): the collectives are issued all the same
         coll = self.world > 1 or (self.group is not None and dist.is_initialized())
         nccl = coll and dist.get_backend(self.group) == "nccl"
@@ -521,7 +626,9 @@ class DataParallelTrainer:
             mine = self.flat_param[a + r * n:a + (r + 1) * n]
             with self.ops.stream_ctx(s):
                 g_all = self.flat_grads[a:b]
-                if not coll:
+                if self._emu_shards:   # stub of the reduce-scatter: this rank's slice arrives (n floats)
+                    self._gshard[k].copy_(g_all[:n])
+                elif not coll:
                     self._gshard[k].copy_(g_all)
                 elif nccl:
                     dist.reduce_scatter_tensor(self._gshard[k], g_all, op=dist.ReduceOp.SUM, group=self.group)
@@ -530,7 +637,9 @@ class DataParallelTrainer:
                     dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=self.group)
                     self._gshard[k].copy_(tmp[r * n:(r + 1) * n])
                 self.ops.update_flat(mine, self._gshard[k], self._m[k], self._v[k], self.optim, s)
-                if coll:
+                if self._emu_shards:   # stub of the all-gather: (N-1) n floats arrive (device copy of as many bytes; values discarded)
+                    self._emu_scratch[:b - a - n].copy_(self.flat_param[a + n:b])
+                elif coll:
                     if nccl:
                         dist.all_gather_into_tensor(self.flat_param[a:b], mine, group=self.group)
                     else:

@@ -327,6 +327,11 @@ def comm_init(ctx, world, rank, unique_id):
     ctx._call("lrcn_comm_init", int(world), int(rank), buf)
 
 
+def comm_set_stream(ctx, stream):
+    """The stream for the context's collectives and per-group updates (lrcn_comm_set_stream); the caller keeps `stream` alive."""
+    ctx._call("lrcn_comm_set_stream", C.c_void_p(stream.cuda_stream))
+
+
 def comm_destroy(ctx):
     ctx._call("lrcn_comm_destroy")
 
@@ -435,6 +440,21 @@ def convnet_u8(ctx, img_u8, mean=VGG_MEAN, feats=None, normalize=False):
     if normalize:
         normalize_features(ctx, feats)
     return feats
+
+
+def convnet_u8_blocks(ctx, img_u8, block_rows, mean=VGG_MEAN, feats=None, normalize=False):
+    """The VGG forward for the crops of m = N / block_rows training batches at once (lrcn_vgg_forward_u8_blocks) -> list of m feature
+    tensors block_rows x 4096 (column-major views into one buffer `feats` of m * block_rows * 4096 floats)."""
+    if torch.is_tensor(img_u8) and not img_u8.is_cuda:
+        img_u8 = upload_crops(ctx, img_u8)
+    N = img_u8.shape[0]
+    m = N // block_rows
+    if feats is None:
+        feats = torch.empty(m * block_rows * CNNOUT, device="cuda", dtype=torch.float32)
+    mm = (C.c_float * 3)(*mean) if mean is not None else None
+    ctx._call("lrcn_vgg_forward_u8_blocks", C.c_void_p(img_u8.data_ptr()), N, mm, int(block_rows), int(bool(normalize)), C.c_void_p(feats.data_ptr()))
+    n = block_rows * CNNOUT
+    return [feats[b * n:(b + 1) * n].view(CNNOUT, block_rows).permute(1, 0) for b in range(m)]
 
 
 class StagedCrops:

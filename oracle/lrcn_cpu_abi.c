@@ -236,6 +236,7 @@ int lrcn_comm_init(lrcn_ctx *c, int world, int rank, const void *id) {
     return LRCN_OK;
 }
 int lrcn_comm_destroy(lrcn_ctx *c) { return c ? LRCN_OK : LRCN_EINVAL; }
+int lrcn_comm_set_stream(lrcn_ctx *c, void *s) { (void)s; return c ? LRCN_OK : LRCN_EINVAL; } /* no streams on the host */
 int lrcn_allreduce_grads(lrcn_ctx *c, float *const grads[9], int group) {
     return (c && grads && group >= -1 && group < LRCN_GRAD_GROUPS) ? LRCN_OK : LRCN_EINVAL; /* sum over one rank */
 }
@@ -360,6 +361,16 @@ int lrcn_resize_crop_u8(lrcn_ctx *c, const uint8_t *src, const int64_t *offsets,
                     out[(((size_t)n * S + r) * S + q) * 3 + k] = (uint8_t)(((2 * nh - fy) * top + fy * bot + 2 * nh * nw) / (4 * nh * nw));
                 }
             }
+    }
+    return LRCN_OK;
+}
+int lrcn_vgg_forward_u8_blocks(lrcn_ctx *c, const uint8_t *img, int N, const float mean[3], int block_rows, int normalize, float *feats) {
+    if (!c || !img || !feats) return LRCN_EINVAL;
+    if (block_rows < 1 || N % block_rows) FAIL(c, LRCN_EINVAL, "block_rows=%d must divide N=%d", block_rows, N);
+    for (int b = 0; b < N / block_rows; ++b) { /* images are independent: block by block through the one-batch entry point */
+        int r = lrcn_vgg_forward_u8(c, img + (size_t)b * block_rows * 224 * 224 * 3, block_rows, mean, feats + (size_t)b * block_rows * LRCN_CNNOUT);
+        if (r) return r;
+        if (normalize) lrcn_normalize_features(c, feats + (size_t)b * block_rows * LRCN_CNNOUT, block_rows);
     }
     return LRCN_OK;
 }

@@ -11,11 +11,11 @@ from lrcn_amd import lrcn as L
 pytestmark = pytest.mark.gpu
 
 
-def run_steps(monkeypatch, overlap, nsteps=4, inputs="hbm", prefetch=True):
+def run_steps(monkeypatch, overlap, nsteps=4, inputs="hbm", prefetch=True, chunk=1, vgg_dtype=lrcn_amd.LRCN_BF16):
     monkeypatch.setenv("LRCN_OVERLAP_VGG", "1" if overlap else "0")
     E = H = 64
     V, B, T = 300, 4, 5
-    ctx = L.Context(E, H, H, V, max_B=B, max_T=T, lstm_dtype=lrcn_amd.LRCN_BF16, vgg_dtype=lrcn_amd.LRCN_BF16, max_images=B)
+    ctx = L.Context(E, H, H, V, max_B=B, max_T=T, lstm_dtype=lrcn_amd.LRCN_BF16, vgg_dtype=vgg_dtype, max_images=B * chunk)
     L.vgg_load(ctx, *L.synthetic_vgg_weights(seed=1))
     param = L.initweights(ctx, seed=42)
     optim = L.initparams(param)
@@ -29,6 +29,20 @@ def run_steps(monkeypatch, overlap, nsteps=4, inputs="hbm", prefetch=True):
     losses = []
     if inputs == "host":   # the same crops in page-locked host memory: uploaded per step on the copy stream, one step ahead
         imgs = [t.cpu().pin_memory() for t in imgs]
+    if chunk > 1:   # the crops of `chunk` consecutive steps per VGG forward; the trainer says when it has taken the chunk offered
+        p, consumed = 1, []
+        offer = {}
+        for k in range(nsteps):
+            if p < nsteps and p not in offer:
+                offer[p] = torch.cat(imgs[p:p + chunk])
+                if inputs == "host":
+                    offer[p] = offer[p].pin_memory()
+            if tr.step(imgs[k], toks[k], next_img_u8=offer.get(p) if p < nsteps else None):
+                consumed.append((k, p))
+                p += chunk
+            losses.append(tr.loss_value())
+        assert consumed and consumed[0] == (0, 1) and all(b - a == chunk for (_, a), (_, b) in zip(consumed, consumed[1:])), consumed
+        nsteps = 0
     for k in range(nsteps):
         tr.step(imgs[k], toks[k], next_img_u8=imgs[k + 1] if k + 1 < nsteps else None,
                 prefetch_img_u8=imgs[k + 2] if (inputs == "host" and prefetch and k + 2 < nsteps) else None)
@@ -49,6 +63,17 @@ def test_pinned_host_crops_uploaded_per_step_keep_the_trajectory(monkeypatch, ov
     np.testing.assert_allclose(la, lb, rtol=1e-5)
     for a, b in zip(pa, pb):
         np.testing.assert_allclose(a, b, rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("chunk,overlap,inputs", [(2, True, "hbm"), (3, True, "host"), (3, False, "hbm")])
+def test_vgg_forward_of_several_batches_at_once_keeps_the_trajectory(monkeypatch, chunk, overlap, inputs):
+    # next_img_u8 with the crops of `chunk` consecutive steps: ONE VGG forward (lrcn_vgg_forward_u8_blocks), one feature block per step.
+    # fp32 VGG so that the forward's batch size does not show in the features; 8 steps = chunks of full and partial length.
+    la, pa = run_steps(monkeypatch, overlap=overlap, nsteps=8, inputs=inputs, chunk=chunk, vgg_dtype=lrcn_amd.LRCN_F32)
+    lb, pb = run_steps(monkeypatch, overlap=overlap, nsteps=8, vgg_dtype=lrcn_amd.LRCN_F32)
+    np.testing.assert_allclose(la, lb, rtol=2e-5)
+    for a, b in zip(pa, pb):
+        np.testing.assert_allclose(a, b, rtol=0, atol=5e-5)
 
 
 def test_upload_crops_staging_rules():
