@@ -377,6 +377,9 @@ def main(argv=None):
 
     # training batches per VGG forward: 8 at 32 rows per GPU, 4 at 64; one from 128 rows (measured: no gain there, dp.vgg_wg_cap_for)
     m_chunk = max(1, a.vgg_chunk_images // B) if B <= 64 else 1
+    m_chunk = 1 << (m_chunk.bit_length() - 1)   # a power of two of batches (tile counts stay round: 160 images measured slower than 128)
+    while a.steps % m_chunk:   # ... that divides the timed step count: the timed region then holds exactly K batches of VGG forward and K LSTM steps
+        m_chunk //= 2
     Bv = m_chunk * B
     ctx = L.Context(E, H, H, V, max_B=B, max_T=T, lstm_dtype=dt, vgg_dtype=dt, max_images=Bv, n_layers=a.layers)
     vgg_w = L.synthetic_vgg_weights(seed=1)

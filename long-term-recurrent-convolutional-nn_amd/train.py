@@ -29,21 +29,32 @@ def shard_block(block, world, rank):
     return list(ids[rows.start:rows.stop]), np.ascontiguousarray(np.asarray(toks)[:, rows.start:rows.stop])
 
 
-def train1(trainer, blocks, order, feats_of=None, crops_of=None):
+def batches_per_forward(rows, chunk_images=256):
+    """How many consecutive batches of `rows` captions one VGG forward should cover (dp.DataParallelTrainer.step): from 128 rows per GPU
+    one (no gain measured), below that as many as fit into `chunk_images` crops -- 8 at 32 rows (one rank of 8 at batch 256), 4 at 64."""
+    return max(1, int(chunk_images) // int(rows)) if rows <= 64 else 1
+
+
+def train1(trainer, blocks, order, feats_of=None, crops_of=None, lookahead=1):
     """One epoch (lrcn.jl:350-396).  feats_of(ids) -> this rank's feature rows on the device, or crops_of(ids) -> uint8 crops
-    [B][224][224][3] (device, or pinned host): then the VGG forward of batch k+1 runs beside the LSTM step of batch k.
-    Returns the number of captions this rank trained on."""
+    [len(ids)][224][224][3] (device, or pinned host): then the VGG forward of the NEXT `lookahead` batches (one forward for all of them)
+    runs beside the LSTM steps of the current ones.  Returns the number of captions this rank trained on."""
     W, r = trainer.world, trainer.rank
     n = 0
-    nxt = None
-    for pos, k in enumerate(order):
-        ids, toks = shard_block(blocks[k], W, r)
+    shards = [shard_block(blocks[k], W, r) for k in order]
+    nxt_pos, nxt = 1, None          # position (in `order`) of the first batch whose crops have not been handed to the trainer yet
+    for pos, (ids, toks) in enumerate(shards):
         if crops_of is None:
             trainer.step(None, toks, feats=feats_of(ids))
         else:
-            cur = nxt if nxt is not None else crops_of(ids)
-            nxt = crops_of(shard_block(blocks[order[pos + 1]], W, r)[0]) if pos + 1 < len(order) else None
-            trainer.step(cur, toks, next_img_u8=nxt)
+            nxt_pos = max(nxt_pos, pos + 1)
+            if nxt is None and nxt_pos < len(shards):
+                nxt = crops_of(sum((s[0] for s in shards[nxt_pos:nxt_pos + lookahead]), []))
+            # the first batch's own crops are only read when no earlier step produced its features (the very first step of the epoch)
+            cur = crops_of(ids) if (pos == 0 or not trainer._feat_q) else None
+            if trainer.step(cur, toks, next_img_u8=nxt):
+                nxt_pos += lookahead
+                nxt = None
         n += len(ids)
     return n
 
@@ -66,7 +77,7 @@ def average_loss(trainer, blocks, feats_of):
     return total / max(count, 1)
 
 
-def train(trainer, splits, epochs, seed, feats_of=None, crops_of=None, eval_feats_of=None, save=None, log=print, sync=None):
+def train(trainer, splits, epochs, seed, feats_of=None, crops_of=None, eval_feats_of=None, save=None, log=print, sync=None, lookahead=1):
     """train! (lrcn.jl:223-246).  splits: [(blocks of the training split), (blocks of the dev split)?], blocks = [(ids, tokens)].
     feats_of / crops_of: the training inputs (one of them); eval_feats_of[i](ids): features of split i for average_loss (default:
     feats_of).  save(epoch): called on every rank after each epoch (rank 0 writes; a sharded update gathers its moments first).
@@ -76,7 +87,7 @@ def train(trainer, splits, epochs, seed, feats_of=None, crops_of=None, eval_feat
     ev = eval_feats_of or [feats_of] * len(splits)
     for epoch in range(1, epochs + 1):
         t0 = time.time()
-        n = train1(trainer, splits[0], epoch_order(len(splits[0]), seed, epoch), feats_of=feats_of, crops_of=crops_of)
+        n = train1(trainer, splits[0], epoch_order(len(splits[0]), seed, epoch), feats_of=feats_of, crops_of=crops_of, lookahead=lookahead)
         if sync is not None:
             sync()
         dt_s = time.time() - t0

@@ -150,7 +150,7 @@ def main(argv=None):
     H1, H2 = o.hidden
     gen_chunk = 256  # images decoded together by the batched beam search (1280 hypothesis rows at beam 5: the decode GEMMs fill the chip)
     ctx = L.Context(o.embed, H1, H2, V, max_B=max(o.batchsize, o.beam_width * (gen_chunk if o.generate > 0 else 1), 10), lstm_dtype=dt, vgg_dtype=vdt,
-                    max_images=max(o.batchsize, 1) if o.cnn else 0)
+                    max_images=max(o.batchsize, 256 if o.train else 1) if o.cnn else 0)   # training: room for the crops of several batches per forward
     param = L.initweights(ctx, seed=o.seed if o.seed > 0 else 42) if host_model is None else L.model_from_arrays(host_model)
     say("LSTM is initialized")
     mean = L.VGG_MEAN
@@ -243,7 +243,10 @@ def main(argv=None):
         optim.lr = o.lr
         from_images = bool(o.cnn) and not o.features
         seed = o.seed if o.seed > 0 else 0
+        # small per-GPU batches: the VGG forward of several upcoming batches as one forward (dp.DataParallelTrainer.step)
+        lookahead = trn.batches_per_forward(B_global // world) if from_images else 1
         trainer = dp.DataParallelTrainer(ctx, param, optim, B_global, world, rank, pdrop=o.dropout, seed=seed, backend=o.dp_backend, ops=dp.HipOps(ctx, mean=mean),
+                                         vgg_chunk=lookahead,
                                          shard_adam=bool(o.shard_adam) and world > 1, normalize_features=from_images and not o.no_normalize,
                                          gclip=o.gclip)
         if adam_state is not None:   # resume: moments and step count (the reference never saved them)
@@ -271,7 +274,7 @@ def main(argv=None):
                 fmt.save_checkpoint(o.savefile, [L.from_jl(p) for p in param], vocab,
                                     adam={"m": [L.from_jl(t) for t in optim.m], "v": [L.from_jl(t) for t in optim.v], "step": optim.t})
 
-        trn.train(trainer, splits, o.epochs, seed, save=save, log=say, sync=ctx.sync, **kw)
+        trn.train(trainer, splits, o.epochs, seed, save=save, log=say, sync=ctx.sync, lookahead=lookahead, **kw)
         trainer.close()
         if world > 1:
             dist.barrier()
