@@ -708,6 +708,16 @@ __device__ __forceinline__ bool gemm8p_tile(const GemmArgs &g, unsigned char *sm
     }
 
     // ---------------------------------------------------------------- epilogue B: direct stores (f32 / accumulate / odd N)
+    // A persistent walk (the LSTM GEMMs beside the capped convolution grids: f32 outputs, K = 1000 -> 16 K-tiles per tile, so the per-tile
+    // prologue and epilogue are a third of a tile's time) prepares the NEXT tile here: the direct epilogue does not touch LDS, so the ring is
+    // free, and the next tile's addresses and first K-tile's DMA run under the issue of this tile's 64 store instructions per lane instead
+    // of after them.  LRCN_DBG=16 turns it off (A/B).
+    bool early_b = false;
+    if (next_tile >= 0 && gridDim.y == 1 && !(g.dbg & 16)) {  // workgroup-uniform
+        setup(next_tile, ta);
+        issue_first();
+        early_b = true;
+    }
 #pragma unroll
     for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
@@ -769,7 +779,7 @@ __device__ __forceinline__ bool gemm8p_tile(const GemmArgs &g, unsigned char *sm
                         }
                     }
                 }
-    return false;
+    return early_b;
 }
 
 // One workgroup per output tile, or -- g.wg_cap > 0 -- a capped, persistent grid that walks the tiles: the data-parallel
