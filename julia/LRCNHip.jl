@@ -8,7 +8,7 @@
 module LRCNHip
 
 const lib = get(ENV, "LRCN_HIP_LIB", "liblrcn_hip.so")
-const ABI_VERSION = 3   # include/lrcn.h LRCN_ABI_VERSION: the revision the struct layouts below were written against
+const ABI_VERSION = 4   # include/lrcn.h LRCN_ABI_VERSION: the revision the struct layouts below were written against
 function __init__()
     v = ccall((:lrcn_abi_version, lib), Cint, ())
     v == ABI_VERSION || error("liblrcn_hip implements ABI revision $v, LRCNHip.jl was written against $ABI_VERSION")
@@ -174,5 +174,28 @@ function train_step_dp(ctx, param, grads, mom, var, feats, tokens, T, B, step; i
         normalize ? 1 : 0, pointer(feats), pointer(tokens), T, B, batchsize, d, step, lr, beta1, beta2, eps, out))
     out[]
 end
+
+# ---- ABI revision 4: the input feed, several batches per VGG forward, the communicator's stream ----
+# page-locked host memory for the crops a loader decodes into (the source of an asynchronous upload)
+function host_alloc(bytes::Integer)
+    p = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = ccall((:lrcn_host_alloc, lib), Cint, (Ref{Ptr{Cvoid}}, Csize_t), p, bytes)
+    rc == 0 || error("lrcn_host_alloc failed ($rc)")
+    p[]
+end
+host_free(p) = ccall((:lrcn_host_free, lib), Cint, (Ptr{Cvoid},), p)
+# the per-batch host -> device copy of lrcn.jl:369-376 on the context's copy stream; returns device crops for convnet_u8 / train_step_dp
+function upload_crops(ctx, host_u8::Ptr{UInt8}, N::Integer)
+    dev = Ref{Ptr{UInt8}}(C_NULL)
+    check(ctx, ccall((:lrcn_upload_crops, lib), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Cint, Ref{Ptr{UInt8}}), ctx.h, host_u8, N, dev))
+    dev[]
+end
+upload_wait(ctx) = check(ctx, ccall((:lrcn_upload_wait, lib), Cint, (Ptr{Cvoid},), ctx.h))
+# VGG forward for the crops of N / block_rows consecutive batches; feats: N * 4096 floats = one block_rows x 4096 array per batch
+convnet_u8_blocks(ctx, img::Ptr{UInt8}, N::Integer, block_rows::Integer, feats; mean = Cfloat[123.68, 116.779, 103.939], normalize = true) =
+    check(ctx, ccall((:lrcn_vgg_forward_u8_blocks, lib), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Cint, Ptr{Cfloat}, Cint, Cint, Ptr{Cfloat}),
+                ctx.h, img, N, mean, block_rows, normalize ? 1 : 0, pointer(feats)))
+# the stream (hipStream_t) on which the context issues its collectives and per-group updates
+comm_set_stream(ctx, stream::Ptr{Cvoid}) = check(ctx, ccall((:lrcn_comm_set_stream, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), ctx.h, stream))
 
 end # module
