@@ -414,9 +414,49 @@ class DataParallelTrainer:
 
     def _make_update_streams(self):
         try:
-            return self.ops.make_streams(len(GRAD_GROUPS), avoid=[self._side])
+            streams = self.ops.make_streams(len(GRAD_GROUPS), avoid=[self._side])
         except TypeError:   # stand-in ops of the CPU tests
             return self.ops.make_streams(len(GRAD_GROUPS))
+        self._bucket_streams = streams
+        self._keep_collectives_off_the_vgg_queue()
+        return streams
+
+    def _keep_collectives_off_the_vgg_queue(self, rounds=4):
+        """torch.distributed runs an RCCL collective on a stream of ITS OWN choosing (a pool stream), which may share a hardware queue with
+        the VGG side stream -- every all-reduce would then wait for the convolutions queued before it (with several batches per forward: for
+        milliseconds).  That stream cannot be asked for, so it is MEASURED, with the collective the step issues: a ~2 ms sleep kernel on the
+        side stream, then a small all-reduce behind the update stream; if it only completes when the sleep does, this rank takes another
+        side stream (one that shares no queue with the update stream either) and the ranks try again -- the same number of rounds on every
+        rank (the outcome is agreed by an all-reduce), so the collectives stay matched.  RCCL over a real N > 1 group only."""
+        knob = os.environ.get("LRCN_DP_QUEUE_PROBE", "1")   # 0 = never; force = also on a one-rank group (tests)
+        if knob[:1] == "0" or not ((self.world > 1 or knob == "force") and self._side is not None and dist.is_available() and dist.is_initialized()
+                                   and dist.get_backend(self.group) == "nccl" and isinstance(self._side, torch.cuda.Stream)):
+            return
+        dev = self.param[0].device
+        upd = self._bucket_streams[0]
+        t = torch.zeros(1024, device=dev)
+        self.queue_probe = []
+        for _ in range(rounds):
+            torch.cuda.synchronize(dev)
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            with torch.cuda.stream(self._side):
+                e0.record()
+                torch.cuda._sleep(4_000_000)
+                e1.record()
+            with torch.cuda.stream(upd):
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True).wait()
+                e2.record()
+            torch.cuda.synchronize(dev)
+            late = e0.elapsed_time(e2) > 0.5 * e0.elapsed_time(e1)
+            flag = torch.tensor([1.0 if late else 0.0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+            self.queue_probe.append(bool(late))
+            if float(flag.item()) == 0.0:
+                return
+            if late:   # this rank's collective stream sits behind the side stream: move the VGG forward to another queue
+                prio = int(os.environ.get("LRCN_VGG_STREAM_PRIO", "0"))
+                cand = independent_stream(dev, [upd]) if prio == 0 else None
+                self._side = cand if cand is not None else torch.cuda.Stream(device=dev, priority=prio)
 
     def _group_slices(self):
         """Flat-buffer ranges of the gradient groups, in the order lossgradient finalises them."""

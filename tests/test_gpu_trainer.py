@@ -320,6 +320,7 @@ def test_abi_and_torch_backends_side_by_side_on_a_one_rank_rccl_group(monkeypatc
     s.close()
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     monkeypatch.setenv("LRCN_DP_FORCE_PIPELINE", "1")
+    monkeypatch.setenv("LRCN_DP_QUEUE_PROBE", "force")   # the N > 1 probe that keeps RCCL's stream off the VGG side stream's hardware queue
     monkeypatch.delenv("LRCN_DP_BACKEND", raising=False)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
@@ -339,6 +340,8 @@ def test_abi_and_torch_backends_side_by_side_on_a_one_rank_rccl_group(monkeypatc
             for f, t in batches:
                 tr.step(None, torch.as_tensor(t).cuda(), feats=L.to_jl(f))
                 losses.append(tr.loss_value())
+            if backend == "torch":
+                assert tr.queue_probe and tr.queue_probe[-1] is False, tr.queue_probe   # ran, and ended on a side stream the collective does not wait for
             torch.cuda.synchronize()
             out = [L.from_jl(p).copy() for p in param]
             if backend == "abi":
