@@ -11,7 +11,13 @@ cd "$root"
 python3 bench.py > "$out/bench_line.json" 2> "$out/bench.err" || { tail "$out/bench.err"; exit 1; }
 # the driver's own shape (5 warm-up + 20 timed steps) and the other BASELINE configs, one line each
 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > "$out/bench_line_driver_shape.json" 2>> "$out/bench.err"
-python3 bench.py --emulate-world 8 --steps 100 --warmup 20 --no-cpu-baseline > "$out/bench_line_emulated_rank_of_8.json" 2>> "$out/bench.err"
+python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --inputs hbm > "$out/bench_line_driver_shape_inputs_hbm.json" 2>> "$out/bench.err"
+python3 bench.py --emulate-world 8 --steps 96 --warmup 16 --no-cpu-baseline > "$out/bench_line_emulated_rank_of_8.json" 2>> "$out/bench.err"
+python3 bench.py --emulate-world 8 --steps 96 --warmup 16 --no-cpu-baseline --shard-adam > "$out/bench_line_emulated_rank_of_8_sharded_update.json" 2>> "$out/bench.err"
+python3 bench.py --emulate-world 8 --steps 96 --warmup 16 --no-cpu-baseline --vgg-chunk-images 0 > "$out/bench_line_emulated_rank_of_8_one_forward_per_step.json" 2>> "$out/bench.err"
+python3 bench.py --emulate-world 8 --steps 20 --warmup 5 --no-cpu-baseline > "$out/bench_line_emulated_rank_of_8_driver_shape.json" 2>> "$out/bench.err"
+python3 bench.py --emulate-world 4 --steps 48 --warmup 16 --no-cpu-baseline > "$out/bench_line_emulated_rank_of_4.json" 2>> "$out/bench.err"
+python3 bench.py --emulate-world 2 --steps 40 --warmup 10 --no-cpu-baseline > "$out/bench_line_emulated_rank_of_2.json" 2>> "$out/bench.err"
 python3 bench.py --config c2 --no-cpu-baseline > "$out/bench_line_c2.json" 2>> "$out/bench.err"
 python3 bench.py --config c3 --no-cpu-baseline > "$out/bench_line_c3.json" 2>> "$out/bench.err"
 python3 bench.py --config c5 > "$out/bench_line_c5.json" 2>> "$out/bench.err"
@@ -19,7 +25,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o p -- python3 "$root/bench.py" --steps 25 --warmup 5 --no-cpu-baseline > "$out/bench_under_rocprof.json" 2> "$out/stats.log"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/fetch" -o p -- python3 "$root/bench.py" --steps 8 --warmup 2 --no-cpu-baseline > /dev/null 2> "$out/fetch.log"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/write" -o p -- python3 "$root/bench.py" --steps 8 --warmup 2 --no-cpu-baseline > /dev/null 2> "$out/write.log"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats32" -o p -- python3 "$root/bench.py" --emulate-world 8 --steps 50 --warmup 10 --no-cpu-baseline > "$out/bench_under_rocprof_b32.json" 2> "$out/stats32.log"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats32" -o p -- python3 "$root/bench.py" --emulate-world 8 --steps 48 --warmup 16 --no-cpu-baseline > "$out/bench_under_rocprof_b32.json" 2> "$out/stats32.log"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/statsc2" -o p -- python3 "$root/bench.py" --config c2 --steps 20 --warmup 5 --no-cpu-baseline > "$out/bench_under_rocprof_c2.json" 2> "$out/statsc2.log"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/statsc5" -o p -- python3 "$root/bench.py" --config c5 --steps 30 > "$out/bench_under_rocprof_c5.json" 2> "$out/statsc5.log"
 cd "$root"
