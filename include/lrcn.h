@@ -192,6 +192,15 @@ int lrcn_comm_probe(lrcn_ctx *ctx);
 /* Collective over the `world` contexts: binds ctx to rank `rank` of the communicator named by the id. */
 int lrcn_comm_init(lrcn_ctx *ctx, int world, int rank, const void *unique_id);
 int lrcn_comm_destroy(lrcn_ctx *ctx);
+/* Sparse exchange of the embedding gradient (rev 4).  A rank's contribution to d Wembed is its (T+1) B rows of d(x_lstm) -- 1.5 MB at 32
+ * rows per GPU against the 42.6 MB dense V x E gradient, which is also the one gradient group that becomes final LAST and whose all-reduce
+ * therefore cannot hide behind the backward pass.  lrcn_set_embed_rows_buffer(rows, tok, capacity): from now on lrcn_loss_grad writes those
+ * rows ((T+1) B x E, row-major, dropout multiplier applied) and their token ids into the caller's buffers and does NOT write grads[6]
+ * (NULL, NULL, 0 turns it off).  The host all-gathers rows and ids over the ranks (rank order) and calls lrcn_embed_grad_from_rows on
+ * every rank: the n_rows <= 8192 rows are summed per token in ONE fixed order (sorted (token, row) keys), so every rank obtains the same
+ * bits an all-reduce would have delivered, as the dense V x E column-major gradient `grad_wembed`, on `hip_stream` (NULL = the context's). */
+int lrcn_set_embed_rows_buffer(lrcn_ctx *ctx, float *rows, int32_t *tok, int capacity_rows);
+int lrcn_embed_grad_from_rows(lrcn_ctx *ctx, const float *rows, const int32_t *tok, int n_rows, float *grad_wembed, void *hip_stream);
 /* The stream on which the context issues every collective and every per-group update of lrcn_allreduce_grads / lrcn_train_step_dp (rev 4;
  * default: a stream of its own).  HIP multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, default 4) and two streams on one
  * queue run in order: a host that also runs the VGG forward of the next step on a side stream hands in an update stream that it has

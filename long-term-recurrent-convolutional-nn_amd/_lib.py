@@ -79,6 +79,8 @@ SIGNATURES = {
     "lrcn_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "lrcn_comm_destroy": (C.c_int, [C.c_void_p]),
     "lrcn_comm_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "lrcn_set_embed_rows_buffer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "lrcn_embed_grad_from_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "lrcn_allreduce_grads": (C.c_int, [C.c_void_p, P9, C.c_int]),
     "lrcn_comm_join": (C.c_int, [C.c_void_p]),
     "lrcn_train_step_dp": (C.c_int, [C.c_void_p, P9, P9, P9, P9, C.c_void_p, C.POINTER(C.c_float), C.c_int, C.c_void_p, C.c_void_p, C.c_int,

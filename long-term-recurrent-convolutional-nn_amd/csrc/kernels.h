@@ -25,6 +25,7 @@ void k_embed_scatter(hipStream_t st, const float *dxemb, int64_t ld_dx, const in
 // then one dense transpose that writes EVERY element of dwembed (no memset needed).  sort_keys != NULL ((T+1)*B <= 8192 keys of scratch):
 // the rows of a token are added in row order by plain stores instead -- a fixed summation order (LRCN_OPT_DETERMINISTIC); false = too
 // many rows for the one-workgroup sort, nothing was launched.
+void k_embed_rows_export(hipStream_t st, const float *dxemb, int64_t ld_dx, int S, int B, int E, DropSpec d, float *out);
 bool k_embed_scatter_rm(hipStream_t st, const float *dxemb, int64_t ld_dx, const int32_t *tok_in, int S, int B, int E, int V, DropSpec d,
                         float *stage, int64_t ld_s, float *dwembed, unsigned long long *sort_keys);
 

@@ -72,6 +72,12 @@ struct lrcn_ctx {
     float *dWe_rm = nullptr;                // [V][ldE] f32, all zero between calls: row-major staging of the embedding gradient
     unsigned long long *sort_keys = nullptr;  // [maxS * maxB] (token, row) keys of the ordered embedding-gradient sums
     double *logp_rows = nullptr;            // [maxS * maxB] per-row log p(target): the ordered loss sum of LRCN_OPT_DETERMINISTIC
+    // sparse exchange of the embedding gradient (lrcn_set_embed_rows_buffer): lossgradient writes its (T+1) B rows of d(x_lstm) and their
+    // token ids HERE instead of scattering them into the dense gradient; lrcn_embed_grad_from_rows sums the rows of all ranks in a fixed order
+    float *emb_rows_out = nullptr;
+    int32_t *emb_tok_out = nullptr;
+    int emb_rows_cap = 0;
+    unsigned long long *imp_keys = nullptr;  // [8192] sort keys of lrcn_embed_grad_from_rows
     // activations
     int32_t *tok = nullptr, *tok_in = nullptr, *tok_tgt = nullptr;
     void *F = nullptr, *FT = nullptr;
@@ -264,7 +270,8 @@ int gemm(lrcn_ctx *c, int dtype, const void *A, int64_t lda, const void *B, int6
         static const char *kb = getenv("LRCN_BG_ROUTE");
         // from 256 rows per GPU only: below, the VGG forward's own grids are small, more CUs are free, and the LSTM chain is the critical
         // path -- the hints measured 1.64 -> 1.79 ms/step at 32 rows, 2.39 -> 2.43 at 64, 4.11 -> 4.12 at 128, 7.31 -> 7.20 at 256
-        if (c->vgg_wg_cap >= 8 && c->vgg_loaded && c->cur_B >= 256 && !(kb && kb[0] == '0')) {
+        static const char *kmb = getenv("LRCN_BG_MINB");  // kernel-development knob: rows per GPU from which the hints apply (default 256)
+        if (c->vgg_wg_cap >= 8 && c->vgg_loaded && c->cur_B >= (kmb ? atoi(kmb) : 256) && !(kb && kb[0] == '0')) {
             static int ncu = 0;
             if (!ncu) {
                 hipDeviceProp_t pr;
@@ -723,7 +730,12 @@ int loss_impl(lrcn_ctx *c, const float *const p[9], const float *feats, const in
             GEMM(c, dt, c->dxcT, ldB, c->FT, ldB, grads[5], LRCN_CNNOUT, h, LRCN_CNNOUT, B, nullptr, true, false, false, false, par);
             HIPCHK(c, hipEventRecord(c->grad_ev[2], sw));  // group 2: Wcnn
         }
-        {
+        if (c->emb_rows_out) {
+            // data-parallel host with the sparse exchange on: hand out this rank's rows and ids; grads[6] is NOT written by this call
+            if (M > c->emb_rows_cap) FAIL(c, LRCN_EINVAL, "embedding-row buffer holds %d rows, this call has %d", c->emb_rows_cap, M);
+            k_embed_rows_export(st, c->dXemb, c->ldX1, S, B, E, two ? d1 : none, c->emb_rows_out);
+            HIPCHK(c, hipMemcpyAsync(c->emb_tok_out, c->tok_in, sizeof(int32_t) * (size_t)M, hipMemcpyDeviceToDevice, st));
+        } else {
             // dWembed: per-token sums in an E-contiguous staging array, then one transpose into the column-major gradient (kernels.hip).
             // LRCN_EMBED_SCATTER=0: the direct scatter (one float atomic per element, 64 cache lines per wave instruction: 99 vs ~25 us).
             static const char *ks = getenv("LRCN_EMBED_SCATTER");
@@ -1341,6 +1353,30 @@ int lrcn_comm_init(lrcn_ctx *c, int world, int rank, const void *unique_id) {
     c->comm = comm_create(world, rank, unique_id, err, sizeof(err));
     if (!c->comm) FAIL(c, LRCN_EHIP, "%s", err);
     return ensure_buckets(c);
+}
+
+int lrcn_set_embed_rows_buffer(lrcn_ctx *c, float *rows, int32_t *tok, int capacity_rows) {
+    if (!c) return LRCN_EINVAL;
+    if ((rows == nullptr) != (tok == nullptr) || capacity_rows < 0) FAIL(c, LRCN_EINVAL, "rows and tok must both be given (capacity >= 0) or both NULL");
+    c->emb_rows_out = rows;
+    c->emb_tok_out = tok;
+    c->emb_rows_cap = rows ? capacity_rows : 0;
+    return LRCN_OK;
+}
+
+int lrcn_embed_grad_from_rows(lrcn_ctx *c, const float *rows, const int32_t *tok, int n_rows, float *grad_wembed, void *stream) {
+    DeviceGuard dg(c);
+    if (!c || !rows || !tok || !grad_wembed) return LRCN_EINVAL;
+    if (n_rows < 1 || n_rows > 8192) FAIL(c, LRCN_EINVAL, "n_rows=%d outside [1, 8192] (the ordered sum sorts its keys in one workgroup)", n_rows);
+    if (!c->dWe_rm) DALLOC(c, c->dWe_rm, sizeof(float) * (size_t)c->V * c->ldE);
+    if (!c->imp_keys) DALLOC(c, c->imp_keys, sizeof(unsigned long long) * 8192);
+    hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : c->stream;
+    DropSpec none{};
+    // ordered: every rank sums the same rows in the same order -> bit-identical dense gradients (what an all-reduce guarantees)
+    if (!k_embed_scatter_rm(st, rows, c->E, tok, n_rows, 1, c->E, c->V, none, c->dWe_rm, c->ldE, grad_wembed, c->imp_keys))
+        FAIL(c, LRCN_EINVAL, "embed_grad_from_rows: too many rows (%d)", n_rows);
+    KCHK(c, "embed_grad_from_rows");
+    return LRCN_OK;
 }
 
 int lrcn_comm_set_stream(lrcn_ctx *c, void *hip_stream) {

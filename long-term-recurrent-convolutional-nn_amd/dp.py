@@ -191,6 +191,12 @@ class HipOps:
     def comm_init(self, world, rank, unique_id):
         L.comm_init(self.ctx, world, rank, unique_id)
 
+    def set_embed_rows_buffer(self, rows, tok):
+        L.set_embed_rows_buffer(self.ctx, rows, tok)
+
+    def embed_grad_from_rows(self, rows, tok, n_rows, grad, stream):
+        L.embed_grad_from_rows(self.ctx, rows, tok, n_rows, grad, stream)
+
     def comm_set_stream(self, avoid=()):
         """Give the library's communicator an update stream that shares its hardware queue with none of `avoid` (the VGG side stream)."""
         s = independent_stream(torch.device("cuda", self.ctx.device), list(avoid))
@@ -304,6 +310,28 @@ class DataParallelTrainer:
         self._feats_buf = [None, None]  # ping-pong outputs of the side-stream VGG (one chunk each)
         self._bucket_streams = None
         self._abi_stream_set = False
+        # Sparse exchange of the embedding gradient (N > 1, torch backend, per-group pipeline): Wembed's 42.6 MB gradient is the group that
+        # becomes final LAST, so its all-reduce is the exposed one; what a rank contributes is (T+1) B rows of d(x_lstm) (1.5 MB at 32 rows).
+        # The ranks all-gather rows + token ids (12 MB in all at 8 x 32 rows) and every rank sums them in one fixed order.
+        # LRCN_DP_SPARSE_EMBED=0 / 1 forces it off / on (1: also on a one-rank group, for tests).
+        env_sp = os.environ.get("LRCN_DP_SPARSE_EMBED")
+        want = (env_sp[:1] != "0") if env_sp else world > 1
+        self._sparse_embed = bool(want and self.backend == "torch" and not self.shard and not self.gclip > 0 and self._multi_or_forced_sparse(env_sp)
+                                  and hasattr(self.ops, "embed_grad_from_rows") and hasattr(self.ops, "update_group") and ctx is not None
+                                  and self._group_pipeline())   # the per-group [exchange -> Adam] pipeline is where the rows are summed
+        if self._sparse_embed:
+            W = max(world, 1)
+            cap = (ctx.max_T + 1) * ctx.max_B
+            if W * cap > 8192:
+                self._sparse_embed = False   # the ordered sum sorts its keys in one workgroup (8192)
+            else:
+                dev = param[0].device
+                E = ctx.E
+                self._emb_rows = torch.zeros(cap * E, device=dev, dtype=torch.float32)
+                self._emb_tok = torch.zeros(cap, device=dev, dtype=torch.int32)
+                self._emb_rows_all = torch.zeros(W * cap * E, device=dev, dtype=torch.float32)
+                self._emb_tok_all = torch.zeros(W * cap, device=dev, dtype=torch.int32)
+                self.ops.set_embed_rows_buffer(self._emb_rows, self._emb_tok)
         self._prefetched = None  # (host tensor, staged device crops): the upload started by the previous step's prefetch_img_u8
 
     # ---- parameter / optimizer state hand-over (checkpoints) ----
@@ -370,6 +398,12 @@ class DataParallelTrainer:
 
     def close(self):
         """Give the context back as it was: the fused-update option belongs to the context and would outlive the trainer."""
+        if getattr(self, "_sparse_embed", False):
+            try:
+                self.ops.set_embed_rows_buffer(None, None)
+            except Exception:
+                pass
+            self._sparse_embed = False
         if getattr(self, "_fused", False) and hasattr(self.ops, "set_fused_update"):
             try:
                 self.ops.set_fused_update(False)
@@ -411,6 +445,29 @@ class DataParallelTrainer:
             if rank == 0:
                 import sys
                 print("lrcn_amd.dp: %s; using torch.distributed collectives" % self.backend_note, file=sys.stderr)
+
+    def _multi_or_forced_sparse(self, env_sp):
+        return self._multi or (env_sp is not None and env_sp[:1] == "1")
+
+    def _gather_embed_rows(self, M):
+        """All-gather of this step's embedding-gradient rows and token ids over the ranks (rank order) -> (rows_all, tok_all, n_rows)."""
+        E = self.ctx.E
+        mine_r, mine_t = self._emb_rows[:M * E], self._emb_tok[:M]
+        if not (dist.is_available() and dist.is_initialized()):
+            return mine_r, mine_t, M
+        W = dist.get_world_size(self.group)   # the group's own size (a test may tell the trainer another `world` than its group has)
+        all_r, all_t = self._emb_rows_all[:W * M * E], self._emb_tok_all[:W * M]
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_gather_into_tensor(all_r, mine_r, group=self.group)
+            dist.all_gather_into_tensor(all_t, mine_t, group=self.group)
+        else:   # gloo (ranks sharing one GPU, CPU tests): through host memory
+            hr, ht = mine_r.cpu(), mine_t.cpu()
+            pr, pt = [torch.empty_like(hr) for _ in range(W)], [torch.empty_like(ht) for _ in range(W)]
+            dist.all_gather(pr, hr, group=self.group)
+            dist.all_gather(pt, ht, group=self.group)
+            all_r.copy_(torch.cat(pr))
+            all_t.copy_(torch.cat(pt))
+        return all_r, all_t, W * M
 
     def _make_update_streams(self):
         try:
@@ -558,6 +615,7 @@ class DataParallelTrainer:
         chunk before the VGG forward that reads it, so the forward never waits for PCIe.  A host buffer handed over must stay unchanged
         until its forward has been queued AND the copy has run (lrcn.upload_wait) -- a loader rotates at least three pinned buffers."""
         rows = int(tokens.shape[1])
+        self._cur_M = (int(tokens.shape[0]) + 1) * rows
         if feats is None:
             if self._feat_q:
                 feats, ev = self._feat_q.popleft()
@@ -642,7 +700,11 @@ class DataParallelTrainer:
             s = self._bucket_streams[k]
             self.ops.grad_group_wait(k, s)  # s waits for the group's event recorded inside lossgradient
             with self.ops.stream_ctx(s):
-                if self._multi and b > a:
+                if k == 4 and self._sparse_embed:
+                    # the embedding gradient travels as rows: all-gather, then the ordered per-token sum into the dense gradient (every rank)
+                    rows_all, tok_all, n = self._gather_embed_rows(self._cur_M)
+                    self.ops.embed_grad_from_rows(rows_all, tok_all, n, self.grads[6], s)
+                elif self._multi and b > a:
                     dist.all_reduce(self.flat_grads[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True).wait()  # s waits for RCCL
                 self.ops.update_group(self.param, self.grads, self.optim, k, s)
         self.ops.join(self._bucket_streams)

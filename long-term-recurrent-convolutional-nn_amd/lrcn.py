@@ -327,6 +327,21 @@ def comm_init(ctx, world, rank, unique_id):
     ctx._call("lrcn_comm_init", int(world), int(rank), buf)
 
 
+def set_embed_rows_buffer(ctx, rows, tok):
+    """Sparse exchange of the embedding gradient (lrcn_set_embed_rows_buffer): lossgradient writes its (T+1) B rows of d(x_lstm) and their token
+    ids into `rows` (float32, capacity x E) / `tok` (int32, capacity) instead of the dense gradient of Wembed; (None, None) turns it off."""
+    if rows is None:
+        ctx._call("lrcn_set_embed_rows_buffer", None, None, 0)
+    else:
+        ctx._call("lrcn_set_embed_rows_buffer", C.c_void_p(rows.data_ptr()), C.c_void_p(tok.data_ptr()), int(tok.numel()))
+
+
+def embed_grad_from_rows(ctx, rows, tok, n_rows, grad_wembed, stream=None):
+    """The dense d Wembed (V x E column-major) from the rows of ALL ranks, summed per token in one fixed order (lrcn_embed_grad_from_rows)."""
+    ctx._call("lrcn_embed_grad_from_rows", C.c_void_p(rows.data_ptr()), C.c_void_p(tok.data_ptr()), int(n_rows), _ptr(grad_wembed),
+              C.c_void_p(stream.cuda_stream) if stream is not None else None)
+
+
 def comm_set_stream(ctx, stream):
     """The stream for the context's collectives and per-group updates (lrcn_comm_set_stream); the caller keeps `stream` alive."""
     ctx._call("lrcn_comm_set_stream", C.c_void_p(stream.cuda_stream))

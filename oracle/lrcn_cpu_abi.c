@@ -236,6 +236,26 @@ int lrcn_comm_init(lrcn_ctx *c, int world, int rank, const void *id) {
     return LRCN_OK;
 }
 int lrcn_comm_destroy(lrcn_ctx *c) { return c ? LRCN_OK : LRCN_EINVAL; }
+/* sparse exchange of the embedding gradient: the export side lives inside the HIP lossgradient (the oracle's loss has no such hook), so the
+ * host twin refuses to turn it on; the import side is the plain ordered sum it stands for */
+int lrcn_set_embed_rows_buffer(lrcn_ctx *c, float *rows, int32_t *tok, int capacity_rows) {
+    if (!c) return LRCN_EINVAL;
+    (void)capacity_rows;
+    if (rows || tok) FAIL(c, LRCN_ESTATE, "the host twin has no sparse embedding-gradient export");
+    return LRCN_OK;
+}
+int lrcn_embed_grad_from_rows(lrcn_ctx *c, const float *rows, const int32_t *tok, int n_rows, float *grad_wembed, void *stream) {
+    (void)stream;
+    if (!c || !rows || !tok || !grad_wembed) return LRCN_EINVAL;
+    if (n_rows < 1 || n_rows > 8192) FAIL(c, LRCN_EINVAL, "n_rows=%d outside [1, 8192]", n_rows);
+    const int V = c->cfg.V, E = c->cfg.E;
+    memset(grad_wembed, 0, sizeof(float) * (size_t)V * E);
+    for (int r = 0; r < n_rows; ++r) { /* rows in order: the same sums the device takes per token */
+        if (tok[r] < 0 || tok[r] >= V) FAIL(c, LRCN_EINVAL, "token id %d outside [0, %d)", tok[r], V);
+        for (int e = 0; e < E; ++e) grad_wembed[(size_t)tok[r] + (size_t)e * V] += rows[(size_t)r * E + e];
+    }
+    return LRCN_OK;
+}
 int lrcn_comm_set_stream(lrcn_ctx *c, void *s) { (void)s; return c ? LRCN_OK : LRCN_EINVAL; } /* no streams on the host */
 int lrcn_allreduce_grads(lrcn_ctx *c, float *const grads[9], int group) {
     return (c && grads && group >= -1 && group < LRCN_GRAD_GROUPS) ? LRCN_OK : LRCN_EINVAL; /* sum over one rank */

@@ -361,3 +361,67 @@ def test_abi_and_torch_backends_side_by_side_on_a_one_rank_rccl_group(monkeypatc
                     np.testing.assert_array_equal(a, b, err_msg="tensor %d, fused update %s" % (k, fused))
     finally:
         dist.destroy_process_group()
+
+
+def test_sparse_embedding_gradient_exchange_equals_the_dense_one(monkeypatch):
+    """lrcn_set_embed_rows_buffer / lrcn_embed_grad_from_rows: the embedding gradient leaves lossgradient as (T+1) B rows + token ids and is
+    rebuilt by an ordered per-token sum.  (1) The trainer with the exchange forced on (one rank: the gather is the identity) follows the
+    dense trajectory; (2) two half-batches exported separately, their rows concatenated in rank order and summed, give the sum of the two
+    dense gradients -- what an all-reduce over two ranks delivers -- and the same bits when asked twice."""
+    E = H = 64
+    V, B, T, K = 300, 8, 5, 3
+    rng = np.random.default_rng(3)
+    batches = [((rng.standard_normal((B, 4096)) * 0.01).astype(np.float32), rng.integers(3, 40, size=(T, B)).astype(np.int32)) for _ in range(K)]
+
+    def run(sparse):
+        monkeypatch.setenv("LRCN_DP_SPARSE_EMBED", "1" if sparse else "0")
+        monkeypatch.setenv("LRCN_DP_GROUP_ADAM", "1")
+        ctx = L.Context(E, H, H, V, max_B=B, max_T=T, lstm_dtype=lrcn_amd.LRCN_BF16)
+        param = L.initweights(ctx, seed=42)
+        tr = dp.DataParallelTrainer(ctx, param, L.initparams(param), B, 1, 0, pdrop=0.4, seed=7, backend="torch")
+        assert tr._sparse_embed == sparse
+        losses = []
+        for f, t in batches:
+            tr.step(None, torch.as_tensor(t).cuda(), feats=L.to_jl(f))
+            losses.append(tr.loss_value())
+        torch.cuda.synchronize()
+        out = [L.from_jl(p).copy() for p in param]
+        tr.close()
+        ctx.close()
+        return losses, out
+
+    la, pa = run(True)
+    lb, pb = run(False)
+    np.testing.assert_allclose(la, lb, rtol=1e-6)
+    for a, b in zip(pa, pb):
+        np.testing.assert_allclose(a, b, rtol=0, atol=2e-6)
+    # (2) two ranks' worth of rows through the entry points themselves
+    ctx = L.Context(E, H, H, V, max_B=B, max_T=T, lstm_dtype=lrcn_amd.LRCN_BF16)
+    param = L.initweights(ctx, seed=42)
+    f, t = batches[0]
+    halves = [slice(0, B // 2), slice(B // 2, B)]
+    dense = []
+    for h in halves:
+        g, _ = L.lossgradient(ctx, param, L.to_jl(f[h]), np.ascontiguousarray(t[:, h]), norm_B=B, pdrop=0.4, seed=11)
+        dense.append(L.from_jl(g[6]).astype(np.float64))
+    M = (T + 1) * (B // 2)
+    rows = torch.zeros(2 * M * E, device="cuda")
+    tok = torch.zeros(2 * M, device="cuda", dtype=torch.int32)
+    mine_r, mine_t = torch.zeros(M * E, device="cuda"), torch.zeros(M, device="cuda", dtype=torch.int32)
+    L.set_embed_rows_buffer(ctx, mine_r, mine_t)
+    for i, h in enumerate(halves):
+        g, _ = L.lossgradient(ctx, param, L.to_jl(f[h]), np.ascontiguousarray(t[:, h]), norm_B=B, pdrop=0.4, seed=11)
+        rows[i * M * E:(i + 1) * M * E].copy_(mine_r)
+        tok[i * M:(i + 1) * M].copy_(mine_t)
+    L.set_embed_rows_buffer(ctx, None, None)
+    out = [L.jl_empty(V, E), L.jl_empty(V, E)]
+    for o in out:
+        L.embed_grad_from_rows(ctx, rows, tok, 2 * M, o)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(L.from_jl(out[0]), L.from_jl(out[1]))                       # ordered: the same bits every time
+    want = dense[0] + dense[1]
+    np.testing.assert_allclose(L.from_jl(out[0]), want, rtol=0, atol=1e-6 * np.abs(want).max())
+    assert np.abs(want).max() > 0
+    with pytest.raises(lrcn_amd.LrcnError):
+        L.embed_grad_from_rows(ctx, rows, tok, 9000, out[0])
+    ctx.close()
