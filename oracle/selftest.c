@@ -97,6 +97,24 @@ int main(void) {
     orc_preprocess_u8(img, 8, 2, mean, pre);
     if (pre[0] != -1.f) ++fails;
 
+    /* the same calls with the bf16 emulation on (rounded operand copies of every contraction, rounded conv operands): same bounds, other
+     * code paths; the emulated loss stays within bf16 distance of the plain one */
+    {
+        const double l_plain = orc_loss(&m, feats, tok, T, B, B, m1, m2, NULL);
+        orc_set_emulate_bf16(1);
+        const double l_emu = orc_loss(&m, feats, tok, T, B, B, m1, m2, &g);
+        orc_forward_logits(&m, feats, tok, T, B, logits);
+        orc_lrcn_step(&m, B, h, c, h2, c2, xc, x, m1, m2, lg);
+        orc_conv3x3(cx, W, Hh, Cin, N, cw, cb, Cout, 1, cy);
+        orc_fc(fw, fb, 7, 11, 2, fx, 1, fy);
+        orc_set_emulate_bf16(0);
+        if (!(l_emu == l_emu) || l_emu == l_plain || (l_emu - l_plain) / l_plain > 2e-2 || (l_plain - l_emu) / l_plain > 2e-2) {
+            fprintf(stderr, "emulated loss %g vs %g\n", l_emu, l_plain);
+            ++fails;
+        }
+        if (orc_bf16_round(1.00390625f) != 1.0f || orc_bf16_round(1.01171875f) != 1.015625f) ++fails; /* ties to even */
+    }
+
     free(img); free(pre); free(fw); free(fb); free(fx); free(fy); free(cx); free(cw); free(cb); free(cy); free(py);
     free(mom); free(var); free(h2); free(c2); free(xc); free(lg); free(x); free(h); free(c); free(ho); free(co); free(ga);
     free(logits); free(m1); free(m2); free(feats);
