@@ -329,12 +329,14 @@ def test_abi_and_torch_backends_side_by_side_on_a_one_rank_rccl_group(monkeypatc
         rng = np.random.default_rng(3)
         batches = [((rng.standard_normal((B, 4096)) * 0.01).astype(np.float32), rng.integers(3, V, size=(T, B)).astype(np.int32)) for _ in range(K)]
 
-        def run(backend, fused):
+        def run(backend, fused, sparse="0"):
             monkeypatch.setenv("LRCN_FUSED_UPDATE", fused)
+            monkeypatch.setenv("LRCN_DP_SPARSE_EMBED", sparse)   # "1": Wembed's gradient travels as rows (all_gather_into_tensor over RCCL)
             ctx = L.Context(E, H, H, V, max_B=B, max_T=T, lstm_dtype=lrcn_amd.LRCN_BF16)
             param = L.initweights(ctx, seed=42)
             tr = dp.DataParallelTrainer(ctx, param, L.initparams(param), B, 1, 0, pdrop=0.4, seed=7, group=dist.group.WORLD, backend=backend)
             assert tr.backend == backend and tr._multi, (tr.backend, tr.backend_note)
+            assert tr._sparse_embed == (sparse == "1" and backend == "torch")
             assert tr._group_pipeline() or backend == "abi"
             losses = []
             for f, t in batches:
@@ -359,6 +361,10 @@ def test_abi_and_torch_backends_side_by_side_on_a_one_rank_rccl_group(monkeypatc
                     np.testing.assert_allclose(a, b, rtol=0, atol=1e-7)
                 else:
                     np.testing.assert_array_equal(a, b, err_msg="tensor %d, fused update %s" % (k, fused))
+        ls, ps = run("torch", "1", sparse="1")   # the sparse exchange of the embedding gradient over the RCCL group
+        np.testing.assert_allclose(ls, la, rtol=1e-6)
+        for k, (a, b) in enumerate(zip(ps, pa)):
+            np.testing.assert_allclose(a, b, rtol=0, atol=2e-6 if k == 6 else 1e-7, err_msg="tensor %d, sparse exchange" % k)
     finally:
         dist.destroy_process_group()
 
