@@ -97,6 +97,8 @@ struct PrepDesc {
 struct PrepPlan {
     PrepDesc d[PREP_MAX];
     int n;
+    int total;                      // tiles of all descriptors (set by the launchers)
+    int grid_cap;                   // k_adam_shadows: > 0 = at most this many workgroups walk the tiles (an update beside the backward pass)
     float lr, b1, b2, eps, c1, c2;  // k_adam_shadows
 };
 void k_prepare_weights(hipStream_t st, int dtype, PrepPlan &plan);

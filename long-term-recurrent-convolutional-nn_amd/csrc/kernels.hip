@@ -456,12 +456,17 @@ __global__ void transpose_kernel(const Tin *in, int64_t ld_in, int R, int C, Tou
 template <typename T, bool ADAM = false> __global__ __launch_bounds__(256) void prepare_weights_kernel(const PrepPlan plan) {
     // 64 x 64 tiles, 16 bytes in / 8 bytes out per thread access (bf16); generic element-wise path for f32 shadows and edges
     __shared__ float tile[64][65];
+    // plan.total tiles walked by gridDim.x workgroups: one tile per workgroup, or -- a capped grid (k_adam_shadows' grid_cap) -- a few
+    // workgroups that walk them all, so that an update running BESIDE the backward pass streams at a fraction of the chip's bandwidth
+    // instead of taking every CU from the latency-bound kernels of the recurrence
+    for (int bid = blockIdx.x; bid < plan.total; bid += gridDim.x) {
+    if (bid != (int)blockIdx.x) __syncthreads();  // the previous tile's transposed stores have read `tile`
     int d = 0;
 #pragma unroll
     for (int k = 1; k < PREP_MAX; ++k)
-        if (k < plan.n && (int)blockIdx.x >= plan.d[k].tile0) d = k;
+        if (k < plan.n && bid >= plan.d[k].tile0) d = k;
     const PrepDesc &P = plan.d[d];
-    const int t = blockIdx.x - P.tile0;
+    const int t = bid - P.tile0;
     const int tc = (P.C + 63) / 64;
     const int r0 = (t / tc) * 64, c0 = (t % tc) * 64;
     const int q = threadIdx.x & 15, rr = threadIdx.x >> 4;  // 16 column quads x 16 row groups
@@ -540,7 +545,7 @@ template <typename T, bool ADAM = false> __global__ __launch_bounds__(256) void 
 #pragma unroll
         for (int k = 0; k < 4; ++k) tile[rr + 16 * i][4 * q + k] = v[k];
     }
-    if (!P.tA && !P.tB) return;
+    if (!P.tA && !P.tB) continue;
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -564,6 +569,7 @@ template <typename T, bool ADAM = false> __global__ __launch_bounds__(256) void 
             for (int k = 0; k < 4; ++k)
                 if (r + k < P.R) dst[r + k] = from_f32<T>(tile[4 * q + k][rr + 16 * i]);
         }
+    }
     }
 }
 
@@ -1305,6 +1311,7 @@ void k_prepare_weights(hipStream_t st, int dtype, PrepPlan &plan) {
         tiles += cdiv(plan.d[k].R, 64) * cdiv(plan.d[k].C, 64);
     }
     if (tiles == 0) return;
+    plan.total = tiles;
     DISPATCH_T(dtype, hipLaunchKernelGGL(prepare_weights_kernel<T>, dim3(tiles), dim3(256), 0, st, plan));
 }
 void k_adam_shadows(hipStream_t st, int dtype, PrepPlan &plan, int step, float lr, float b1, float b2, float eps) {
@@ -1317,7 +1324,9 @@ void k_adam_shadows(hipStream_t st, int dtype, PrepPlan &plan, int step, float l
     plan.lr = lr; plan.b1 = b1; plan.b2 = b2; plan.eps = eps;
     plan.c1 = (float)(1.0 - pow((double)b1, (double)step));
     plan.c2 = (float)(1.0 - pow((double)b2, (double)step));
-    DISPATCH_T(dtype, hipLaunchKernelGGL((prepare_weights_kernel<T, true>), dim3(tiles), dim3(256), 0, st, plan));
+    plan.total = tiles;
+    const int grid = (plan.grid_cap > 0 && plan.grid_cap < tiles) ? plan.grid_cap : tiles;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((prepare_weights_kernel<T, true>), dim3(grid), dim3(256), 0, st, plan));
 }
 void k_cast_rows(hipStream_t st, int dtype, const float *in, int64_t ld_in, int R, int C, void *out, int64_t ld_out) {
     const dim3 grid(cdiv(ld_out, 256) > 64 ? 64 : cdiv(ld_out, 256), R);

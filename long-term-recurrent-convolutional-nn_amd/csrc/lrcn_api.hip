@@ -425,6 +425,16 @@ int adam_fused(lrcn_ctx *c, float *const p[9], const float *const g[9], float *c
         d.src = p[k]; d.g = g[k]; d.m = m[k]; d.v = v[k];
         d.R = 1; d.C = (int)sz[k]; d.cs = (int)sz[k];
     }
+    // A group's update issued on its own stream runs BESIDE the rest of the backward pass (the per-group pipeline).  Kernel-development knob
+    // LRCN_ADAM_GROUP_WGS = n > 0: only n persistent workgroups walk the tiles of groups 0..3, so that the update does not take every CU from
+    // the recurrence's latency-bound kernels.  MEASURED AND LEFT OFF (emulated rank of 8, per-group pipeline, ms per step): uncapped 1.40 /
+    // 1.41, 192 workgroups 1.44 / 1.46, 128: 1.50, 96: 1.63, 64: 1.96, 32: 2.93 -- the capped stream of Wout's 340 MB is still running when
+    // the step joins its update stream; the groups' updates are on the critical path, not beside it.
+    {
+        static const char *kg = getenv("LRCN_ADAM_GROUP_WGS");
+        const int cap = kg ? atoi(kg) : 0;
+        plan.grid_cap = (group >= 0 && group < LRCN_GRAD_GROUPS - 1 && st != c->stream) ? cap : 0;
+    }
     k_adam_shadows(st, c->dt, plan, step, lr, b1, b2, eps);
     KCHK(c, "adam (fused with the shadow pass)");
     return LRCN_OK;
