@@ -72,6 +72,10 @@ int lrcn_set_stream(lrcn_ctx *ctx, void *hip_stream);  /* hipStream_t; NULL = nu
  * tiles persistently.  The data-parallel step sets a cap below the CU count at small per-GPU batches so that the LSTM
  * stream's chain of small dependent launches finds idle CUs while the VGG forward of the next step runs beside it. */
 int lrcn_vgg_set_wg_cap(lrcn_ctx *ctx, int cap);
+/* The stream on which lrcn_loss_grad runs its weight / bias gradient GEMMs beside the reverse recurrences (rev 4; default: a stream of the
+ * context's own).  Like lrcn_comm_set_stream: a host that runs other work on side streams hands in one that shares a hardware queue with
+ * none of them (HIP multiplexes streams onto GPU_MAX_HW_QUEUES queues; two streams on one queue run in order). */
+int lrcn_set_wg_stream(lrcn_ctx *ctx, void *hip_stream);
 int lrcn_sync(lrcn_ctx *ctx);
 int lrcn_malloc(void **dev_ptr, size_t bytes);
 int lrcn_free(void *dev_ptr);

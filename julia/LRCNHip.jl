@@ -198,6 +198,7 @@ convnet_u8_blocks(ctx, img::Ptr{UInt8}, N::Integer, block_rows::Integer, feats; 
 # the stream (hipStream_t) on which the context issues its collectives and per-group updates
 comm_set_stream(ctx, stream::Ptr{Cvoid}) = check(ctx, ccall((:lrcn_comm_set_stream, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), ctx.h, stream))
 
+set_wg_stream(ctx, stream::Ptr{Cvoid}) = check(ctx, ccall((:lrcn_set_wg_stream, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), ctx.h, stream))
 # sparse exchange of the embedding gradient: lossgradient writes its (T+1) B rows of d(x_lstm) + token ids into (rows, tok) instead of grads[7];
 # all-gather them over the ranks (rank order), then embed_grad_from_rows! on every rank rebuilds the dense V x E gradient in one fixed order
 set_embed_rows_buffer(ctx, rows, tok, capacity::Integer) =

@@ -44,6 +44,7 @@ SIGNATURES = {
     "lrcn_destroy": (None, [C.c_void_p]),
     "lrcn_last_error": (C.c_char_p, [C.c_void_p]),
     "lrcn_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "lrcn_set_wg_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "lrcn_sync": (C.c_int, [C.c_void_p]),
     "lrcn_malloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
     "lrcn_free": (C.c_int, [C.c_void_p]),

@@ -134,6 +134,7 @@ struct lrcn_ctx {
     // weight-gradient stream: the dW / db GEMMs of lossgradient feed nothing but update!, so they run on their own stream beside the
     // reverse recurrences (which are chains of small launches that leave CUs idle); own split-K workspace, fork / join by events
     hipStream_t wg_stream = nullptr;
+    bool wg_stream_owned = true;   // false: handed in through lrcn_set_wg_stream (not destroyed here)
     hipEvent_t wg_fork[4] = {}, wg_done = nullptr;
     void *wg_ws = nullptr;
     void *pin = nullptr;      // pinned host staging for results larger than HIP's fast pageable-copy path (lrcn_beam_search_batch)
@@ -935,7 +936,7 @@ void lrcn_destroy(lrcn_ctx *c) {
         if (e) (void)hipEventDestroy(e);
     if (c->wg_done) (void)hipEventDestroy(c->wg_done);
     if (c->pin) (void)hipHostFree(c->pin);
-    if (c->wg_stream) (void)hipStreamDestroy(c->wg_stream);
+    if (c->wg_stream && c->wg_stream_owned) (void)hipStreamDestroy(c->wg_stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     for (int j = 0; j < lrcn_ctx::kStage; ++j) {
         if (c->up_done[j]) (void)hipEventDestroy(c->up_done[j]);
@@ -1101,6 +1102,17 @@ int lrcn_set_stream(lrcn_ctx *c, void *s) {
     DeviceGuard dg(c);
     if (!c) return LRCN_EINVAL;
     c->stream = reinterpret_cast<hipStream_t>(s);
+    return LRCN_OK;
+}
+int lrcn_set_wg_stream(lrcn_ctx *c, void *s) {
+    DeviceGuard dg(c);
+    if (!c || !s) return LRCN_EINVAL;
+    if (c->wg_stream) {
+        HIPCHK(c, hipStreamSynchronize(c->wg_stream));
+        if (c->wg_stream_owned) (void)hipStreamDestroy(c->wg_stream);
+    }
+    c->wg_stream = reinterpret_cast<hipStream_t>(s);
+    c->wg_stream_owned = false;
     return LRCN_OK;
 }
 int lrcn_sync(lrcn_ctx *c) {

@@ -197,6 +197,12 @@ class HipOps:
     def embed_grad_from_rows(self, rows, tok, n_rows, grad, stream):
         L.embed_grad_from_rows(self.ctx, rows, tok, n_rows, grad, stream)
 
+    def set_wg_stream(self, avoid=()):
+        s = independent_stream(torch.device("cuda", self.ctx.device), list(avoid))
+        if s is not None:
+            self.ctx._call("lrcn_set_wg_stream", C.c_void_p(s.cuda_stream))
+            self._wg_stream = s   # kept alive for the context's lifetime
+
     def comm_set_stream(self, avoid=()):
         """Give the library's communicator an update stream that shares its hardware queue with none of `avoid` (the VGG side stream)."""
         s = independent_stream(torch.device("cuda", self.ctx.device), list(avoid))
@@ -308,6 +314,11 @@ class DataParallelTrainer:
             cap = int(env) if env is not None else vgg_wg_cap_for(param[0].device, int(rows) if rows else B_global // max(world, 1), int(vgg_chunk))
             self.ops.set_vgg_wg_cap(cap)
         self._feats_buf = [None, None]  # ping-pong outputs of the side-stream VGG (one chunk each)
+        # the library's weight-gradient stream must not share a hardware queue with the VGG side stream either (its dW GEMMs would run in
+        # order with the convolutions): hand it a probed one.  LRCN_DP_WG_STREAM_PROBE=0: leave the library's own.
+        if (self._side is not None and isinstance(self._side, torch.cuda.Stream) and ctx is not None and hasattr(self.ops, "set_wg_stream")
+                and os.environ.get("LRCN_DP_WG_STREAM_PROBE", "1")[:1] != "0"):
+            self.ops.set_wg_stream(avoid=[self._side, torch.cuda.current_stream(ctx.device)])
         self._bucket_streams = None
         self._abi_stream_set = False
         # Sparse exchange of the embedding gradient (N > 1, torch backend, per-group pipeline): Wembed's 42.6 MB gradient is the group that

@@ -95,6 +95,7 @@ void lrcn_destroy(lrcn_ctx *c) {
     free(c);
 }
 int lrcn_set_stream(lrcn_ctx *c, void *s) { (void)s; return c ? LRCN_OK : LRCN_EINVAL; }      /* no streams on the host */
+int lrcn_set_wg_stream(lrcn_ctx *c, void *s) { (void)s; return c ? LRCN_OK : LRCN_EINVAL; }
 int lrcn_vgg_set_wg_cap(lrcn_ctx *c, int cap) { (void)cap; return c ? LRCN_OK : LRCN_EINVAL; }
 int lrcn_sync(lrcn_ctx *c) { return c ? LRCN_OK : LRCN_EINVAL; }
 int lrcn_malloc(void **p, size_t bytes) { *p = malloc(bytes ? bytes : 16); return *p ? LRCN_OK : LRCN_ENOMEM; }
