@@ -418,3 +418,45 @@ def test_emulation_is_needed_for_the_tight_bound():
     with pytest.raises(AssertionError):
         assert_bf16_matches_emulation(val, grads, f32_loss, f32_g, "against the un-emulated oracle")
     ctx.close()
+
+
+def test_bf16_single_step_and_beam_search_vs_emulating_oracle():
+    # lrcn() one timestep and the beam-search decode in bf16 against the bf16-emulating oracle (the oracle's step rounds its contraction
+    # operands on entry, the LSTM-2 input twice, exactly as step_internal does; the state it hands back is f32, as the ABI's is).
+    rng = np.random.default_rng(17)
+    E, H1, H2, V, B = 48, 64, 64, 157, 6
+    m = orc.init_weights(E, H1, H2, V, seed=4)
+    for n in ("W1", "W2", "Wout"):
+        m.p[n] *= 2.0
+    ctx = L.Context(E, H1, H2, V, max_B=max(B, 5), max_T=2, lstm_dtype=lrcn_amd.LRCN_BF16)
+    param = L.model_from_arrays(m.p)
+    state_ref = [orc.fa(rng.standard_normal((B, H)).astype(np.float32) * 0.3) for H in (H1, H1, H2, H2)]
+    state = [L.to_jl(s) for s in state_ref]
+    x_cnn = rng.standard_normal((B, H2 // 2)).astype(np.float32)
+    with orc.emulate_bf16():
+        for _ in range(3):   # state carried over three calls
+            x_lstm = rng.standard_normal((B, E)).astype(np.float32)
+            m1 = ((rng.random((B, E)) > 0.4) / 0.6).astype(np.float32)
+            m2 = ((rng.random((B, H2)) > 0.4) / 0.6).astype(np.float32)
+            got = L.from_jl(L.lrcn(ctx, param, state, L.to_jl(x_cnn), L.to_jl(x_lstm), L.to_jl(m1), L.to_jl(m2)))
+            ref = orc.lrcn_step(m, state_ref, x_cnn, x_lstm, m1, m2)
+            # one flipped bf16 of h (2^-8 relative) moves a logit by ~|Wout| 2^-8 |h|: bounded well below the 3e-2 the plain oracle needs
+            np.testing.assert_allclose(got, ref, rtol=0, atol=4e-3 * np.abs(ref).max())
+            for a, b in zip(state, state_ref):
+                np.testing.assert_allclose(L.from_jl(a), b, rtol=0, atol=2e-3)
+    plain = orc.lrcn_step(m, [s.copy() for s in state_ref], x_cnn, x_lstm, m1, m2)
+    assert np.abs(plain - ref).max() > 0   # the emulation is doing something
+    # beam search: peaky distributions (no near-ties), decode of the emulating oracle = decode of the bf16 kernels
+    m.p["Wout"][:] *= 3.0
+    param = L.model_from_arrays(m.p)
+    feats = (rng.standard_normal((5, 4096)) * 0.05).astype(np.float32)
+    same = 0
+    for i in range(5):
+        toks, p = L.beam_search(ctx, param, L.to_jl(feats[i:i + 1]), 3, 8)
+        with orc.emulate_bf16():
+            rt, rp = orc.beam_search(m, feats[i], 3, 8)
+        if toks == list(rt):
+            same += 1
+            assert abs(p - rp) <= 5e-2 * abs(rp) + 1e-30, (i, p, rp)
+    assert same >= 4, same   # a near-tie may still fall the other way in bf16: at most one of five
+    ctx.close()
