@@ -332,7 +332,7 @@ class DataParallelTrainer:
                                   and self._group_pipeline())   # the per-group [exchange -> Adam] pipeline is where the rows are summed
         if self._sparse_embed:
             W = max(world, 1)
-            cap = (ctx.max_T + 1) * min(ctx.max_B, int(rows) if rows else max(1, B_global // W))   # this rank's rows of a training batch
+            cap = (ctx.max_T + 1) * min(ctx.max_B, int(rows) if rows else ctx.max_B)   # `rows` = this rank's rows of a training batch, if told
             if W * cap > 8192:
                 self._sparse_embed = False   # the ordered sum sorts its keys in one workgroup (8192)
             else:

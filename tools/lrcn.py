@@ -246,7 +246,7 @@ def main(argv=None):
         # small per-GPU batches: the VGG forward of several upcoming batches as one forward (dp.DataParallelTrainer.step)
         lookahead = trn.batches_per_forward(B_global // world) if from_images else 1
         trainer = dp.DataParallelTrainer(ctx, param, optim, B_global, world, rank, pdrop=o.dropout, seed=seed, backend=o.dp_backend, ops=dp.HipOps(ctx, mean=mean),
-                                         vgg_chunk=lookahead,
+                                         vgg_chunk=lookahead, rows=B_global // world,
                                          shard_adam=bool(o.shard_adam) and world > 1, normalize_features=from_images and not o.no_normalize,
                                          gclip=o.gclip)
         if adam_state is not None:   # resume: moments and step count (the reference never saved them)
