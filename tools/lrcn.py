@@ -61,6 +61,8 @@ def build_parser():
     p.add_argument("--imagedir", default=".", help="directory of the images for --extfeatures")
     p.add_argument("--prefix", default="", help="file-name prefix before the zero-padded id (COCO_train2014_)")
     p.add_argument("--out", default="eval", help="directory for candidates / ids files of --generate")
+    p.add_argument("--workers", type=int, default=max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))),
+                   help="threads that decode images for --cnn --train / --extfeatures")
     p.add_argument("--gpus", type=int, default=1, help="--train: ranks of the data-parallel job (one per GPU); batches are split by rows")
     p.add_argument("--dp_backend", default="torch", choices=["torch", "abi"], help="collectives through torch.distributed's RCCL group or the library's own")
     p.add_argument("--shard_adam", action="store_true", help="N > 1: reduce-scatter -> Adam on 1/N of the parameters -> all-gather (dp.py)")
@@ -169,13 +171,24 @@ def main(argv=None):
                 mean = None
         say("Cnn is initialized")
 
+    decode_pool = []
+
     def load_crops(paths):
-        """read_image_data (lrcn.jl:750-765) for a batch: decode on the host, resize / crop / grey->RGB on the GPU."""
+        """read_image_data (lrcn.jl:750-765) for a batch: decode on the host -- in parallel over the CPUs this process may use (PIL's
+        decoders release the GIL); the reference decodes image by image -- then resize / crop / grey->RGB on the GPU."""
         from PIL import Image
-        ims = []
-        for pth in paths:
+
+        def decode(pth):
             im = Image.open(pth)
-            ims.append(np.asarray(im if im.mode in ("L", "RGB", "RGBA") else im.convert("RGB")))
+            return np.asarray(im if im.mode in ("L", "RGB", "RGBA") else im.convert("RGB"))
+
+        if len(paths) < 4 or o.workers <= 1:
+            ims = [decode(p_) for p_ in paths]
+        else:
+            if not decode_pool:
+                from concurrent.futures import ThreadPoolExecutor
+                decode_pool.append(ThreadPoolExecutor(max_workers=o.workers))
+            ims = list(decode_pool[0].map(decode, paths))
         return L.resize_crop_u8(ctx, ims)
     feats = [fmt.load_features(p) for p in o.features]
     idx2word = cap.index_to_word(vocab)
