@@ -369,6 +369,10 @@ def main(argv=None):
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
+    if os.environ.get("LRCN_BENCH_MAIN_STREAM", "0")[:1] == "1":
+        # development: run the whole job on a stream of its own instead of the device's null stream (whose work orders itself against the
+        # first few other streams of a process: tools/stream_alias_probe.py)
+        torch.cuda.set_stream(torch.cuda.Stream())
     dt = lrcn_amd.LRCN_BF16 if a.dtype == "bf16" else lrcn_amd.LRCN_F32
     E = H = a.hidden
     V, T, Bg = a.vocab, a.T, a.global_batch
