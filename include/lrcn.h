@@ -290,6 +290,13 @@ int lrcn_normalize_features(lrcn_ctx *ctx, float *feats, int N);
 int lrcn_conv3x3(lrcn_ctx *ctx, const float *x, int W, int H, int Cin, int N, const float *w, const float *b,
                  int Cout, int relu, int pool, float *y);
 
+/* Parity probe of the product path's FIRST launch in bf16 (conv64f.hip: read_image_data's mean subtraction, conv1_1 + ReLU, conv1_2 + ReLU
+ * and the 2x2 max-pool in one kernel; lrcn.jl:770 + 724-726 twice): img = N decoded crops [n][S][S][3] uint8 as lrcn_vgg_forward_u8 takes
+ * them (device memory), S a multiple of 16, w11 (3,3,3,64) / w12 (3,3,64,64) and the biases in the reference layouts (device float) ->
+ * y (S/2,S/2,64,N).  Rounds where the stack rounds: crops - mean, conv1_1's output, the pooled output (bf16), f32 accumulation. */
+int lrcn_conv1_fused(lrcn_ctx *ctx, const uint8_t *img, int N, int S, const float mean[3], const float *w11, const float *b11,
+                     const float *w12, const float *b12, float *y);
+
 /* ---- fp8 convolution stack (BASELINE config 5; the reference has no reduced-precision path, lrcn.jl:724-728 is Float32) ----
  * vgg_dtype = LRCN_FP8: conv2_2 .. conv5_3 (Cin % 128 == 0, 79 % of the VGG FLOPs) run as v_mfma_f32_16x16x128_f8f6f4 on
  * OCP e4m3 operands: weights e4m3(w / sw[co]) with sw[co] = amax_co / 448, activations e4m3(x / sa) with one sa per layer,

@@ -109,6 +109,8 @@ SIGNATURES = {
     "lrcn_debug_stamps": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int64]),
     "lrcn_bench_conv": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "lrcn_bench_gemm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "lrcn_conv1_fused": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p]),
     "lrcn_conv3x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "lrcn_vgg_set_wg_cap": (C.c_int, [C.c_void_p, C.c_int]),

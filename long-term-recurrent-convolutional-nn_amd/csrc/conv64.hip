@@ -340,7 +340,11 @@ template <bool POOL, bool FUSE> __global__ __launch_bounds__(512) void conv64_ke
     auto tile_at = [&](int j) { return j < my_tiles ? b0 + j * G : -1; };
 
     f32x4v acc[4][2];
-    uint4 af[2][4];
+#ifndef CONV64_PF
+#define CONV64_PF 1  // half-taps of fragment reads in flight ahead of the MFMAs (2: three fragment buffers)
+#endif
+    constexpr int NAF = CONV64_PF + 1;
+    uint4 af[NAF][4];
 
     // ---- prologue: patches 0 and 1 ----
     if constexpr (FUSE) {
@@ -399,7 +403,7 @@ template <bool POOL, bool FUSE> __global__ __launch_bounds__(512) void conv64_ke
             const unsigned ad = ar[kh & 1][kw][s];
             static_for<0, 4>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
-                af[h & 1][i] = lds_read16<((2 * (i / 2) + kh) * 18 + 8 * (i % 2) + kw) * 128>(ad);
+                af[h % NAF][i] = lds_read16<((2 * (i / 2) + kh) * 18 + 8 * (i % 2) + kw) * 128>(ad);
             });
         };
         auto mfma_half = [&](auto hc) {
@@ -409,7 +413,7 @@ template <bool POOL, bool FUSE> __global__ __launch_bounds__(512) void conv64_ke
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
-                    const bf16x8 av = __builtin_bit_cast(bf16x8, af[h & 1][i]);
+                    const bf16x8 av = __builtin_bit_cast(bf16x8, af[h % NAF][i]);
                     const bf16x8 bv = __builtin_bit_cast(bf16x8, breg[t][s][n]);
                     acc[i][n] = POOL ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[i][n], 0, 0, 0)
                                      : __builtin_amdgcn_mfma_f32_16x16x32_bf16(bv, av, acc[i][n], 0, 0, 0);
@@ -419,11 +423,11 @@ template <bool POOL, bool FUSE> __global__ __launch_bounds__(512) void conv64_ke
             constexpr int LO = decltype(lo)::value, HI = decltype(hi)::value;
             static_for<LO, HI>([&](auto hc) {
                 constexpr int h = decltype(hc)::value;
-                if constexpr (h + 1 < 18) {
-                    read_half(std::integral_constant<int, h + 1>{});
-                    wait_lgkm<4>();
+                if constexpr (h + CONV64_PF < 18) {
+                    read_half(std::integral_constant<int, h + CONV64_PF>{});
+                    wait_lgkm<4 * CONV64_PF>();
                 } else {
-                    wait_lgkm<0>();
+                    wait_lgkm<4 * (17 - h)>();
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_setprio(1);
@@ -436,6 +440,7 @@ template <bool POOL, bool FUSE> __global__ __launch_bounds__(512) void conv64_ke
         // ---------------- first half of the patch ----------------
         if (!FUSE && wq == 1) issue_patch(tile_at(j + 2), (j + 2) % 3);
         read_half(std::integral_constant<int, 0>{});
+        if constexpr (CONV64_PF > 1) read_half(std::integral_constant<int, 1>{});
         run_halves(std::integral_constant<int, 0>{}, std::integral_constant<int, SPLIT>{});
         if (!FUSE && wq == 1) wait_vmcnt<NPIECE + NST>();  // retires this wave's pieces of patch j+1
         stamp(1);
@@ -605,6 +610,10 @@ hipError_t launch_conv64_fused11(hipStream_t stream, const void *img16, const vo
                                  const float *bias, void *out, int N, int S, const void *zero_page, int wg_cap, unsigned long long *stamps) {
     if (!img16 || !w11 || !b11 || !w || !out || !zero_page || N < 1 || S < 16 || (S % 16)) return hipErrorInvalidValue;
     if ((int64_t)N * (S + 4) * (S + 4) * 3 >= (1ll << 31)) return hipErrorInvalidValue;
+    {
+        const char *gen = getenv("LRCN_FUSE11_GEN");  // 2: conv64f.hip (second generation, in development); default: this file's alternating kernel
+        if (gen && gen[0] == '2') return launch_conv64f(stream, img16, w11, w, bias, out, N, S, zero_page, wg_cap, stamps);
+    }
     Conv64Args a{};
     a.w = reinterpret_cast<const bf16_t *>(w);
     a.bias = bias;

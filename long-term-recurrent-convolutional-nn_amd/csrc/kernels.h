@@ -161,7 +161,7 @@ void k_resize_crop_u8(hipStream_t st, const uint8_t *src, const void *meta, int 
 // feats (N x F column-major f32): every row divided by its sum (lrcn.jl:595-597)
 void k_normalize_rows(hipStream_t st, float *feats, int N, int F);
 // conv1_1 weight -> [64][32] bf16 in the K order of the fused conv1_1+conv1_2 kernel (conv64.hip, FUSE)
-void k_repack_conv11_w_fused(hipStream_t st, const float *w, void *out);
+void k_repack_conv11_w_fused(hipStream_t st, const float *w, const float *b, void *out);  // b: conv1_1 bias (pieces at k' = 27..29), may be NULL
 // fc6 weight (4096 x 25088 column-major, k_ref = x + 7y + 49c) -> [4096][25088] T with k = (y*7+x)*512 + c
 void k_repack_fc6_w(hipStream_t st, int dtype, const float *w, void *out);
 // conv1_1 im2col from uint8 crops img[n][row][col][3]: A[m][k = tap*3+c] (T, ld), m window-major over (y=col, x=row);

@@ -789,9 +789,11 @@ __global__ void img_u8_to_bf16_kernel(const uint8_t *img, int64_t n, float m0, f
             out[opix(i / 3) * 3 + i % 3] = (bf16_t)((float)img[i] - (i % 3 == 0 ? m0 : (i % 3 == 1 ? m1 : m2)));
     }
 }
-// conv1_1 weights for the fused conv1_1+conv1_2 kernel (conv64.hip FUSE): out[co][k'], k' = 8 lq + j:
-//   lq < 3: kw = lq, kh = j / 3, c = j % 3 (the first 8 bytes of the 9-byte run of image row kw);  lq = 3: j < 3 -> kw = j, kh = 2, c = 2
-__global__ void repack_conv11_w_fused_kernel(const float *w, bf16_t *out) {
+// conv1_1 weights for the fused conv1_1+conv1_2 kernels (conv64.hip FUSE, conv64f.hip): out[co][k'], k' = 8 lq + j:
+//   lq < 3: kw = lq, kh = j / 3, c = j % 3 (the first 8 bytes of the 9-byte run of image row kw);  lq = 3: j < 3 -> kw = j, kh = 2, c = 2;
+//   k' = 27, 28, 29: the f32 bias of channel co cut into three bf16 pieces, hi + mid + lo = b exactly (24 bits of mantissa in 3 x 8) --
+//   conv64f.hip's im2col fragment holds 1.0 there, so the bias enters the f32 accumulation as data; conv64.hip's fragment holds 0 there.
+__global__ void repack_conv11_w_fused_kernel(const float *w, const float *b, bf16_t *out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 64 * 32) return;
     const int k = i & 31, co = i >> 5, lq = k >> 3, j = k & 7;
@@ -803,6 +805,13 @@ __global__ void repack_conv11_w_fused_kernel(const float *w, bf16_t *out) {
         kw = j; kh = 2; c = 2;
     }
     if (kw >= 0) v = w[kw + 3 * (kh + 3 * (c + 3 * co))];  // reference layout (3,3,3,64) column-major: a = kw (dim 1), b = kh (dim 2)
+    if (lq == 3 && j >= 3 && j < 6 && b) {
+        float rest = b[co];
+        for (int piece = 3; piece <= j; ++piece) {
+            v = (float)(bf16_t)rest;
+            rest -= v;
+        }
+    }
     out[i] = (bf16_t)v;
 }
 template <typename T> __global__ void repack_fc6_w_kernel(const float *w, T *out) {
@@ -1407,8 +1416,8 @@ void k_beam_init(hipStream_t st, int32_t *seq, int32_t *last, float *p, int R, i
 void k_normalize_rows(hipStream_t st, float *feats, int N, int F) {
     hipLaunchKernelGGL(normalize_rows_kernel, dim3(N), dim3(256), 0, st, feats, N, F);
 }
-void k_repack_conv11_w_fused(hipStream_t st, const float *w, void *out) {
-    hipLaunchKernelGGL(repack_conv11_w_fused_kernel, dim3(8), dim3(256), 0, st, w, (bf16_t *)out);
+void k_repack_conv11_w_fused(hipStream_t st, const float *w, const float *b, void *out) {
+    hipLaunchKernelGGL(repack_conv11_w_fused_kernel, dim3(8), dim3(256), 0, st, w, b, (bf16_t *)out);
 }
 void k_repack_fc6_w(hipStream_t st, int dtype, const float *w, void *out) {
     DISPATCH_T(dtype, hipLaunchKernelGGL(repack_fc6_w_kernel<T>, dim3(25088 / 32, 4096 / 32), dim3(256), 0, st, w, (T *)out));

@@ -1703,7 +1703,7 @@ int lrcn_vgg_load(lrcn_ctx *c, const float *const cw[13], const float *const cb[
             k_repack_conv11_w(st, vdt, cw[0], 64, L.w, 32);
             if (vdt == GEMM_T_BF16) {
                 DALLOC(c, L.w_fused, 2 * 64 * 32);
-                k_repack_conv11_w_fused(st, cw[0], L.w_fused);
+                k_repack_conv11_w_fused(st, cw[0], cb[0], L.w_fused);
             }
         } else {
             DALLOC(c, L.w, ve * (size_t)L.Cout * 9 * Cin);
@@ -2405,6 +2405,44 @@ int lrcn_conv3x3(lrcn_ctx *c, const float *x, int W, int H, int Cin, int N, cons
     }
     cleanup();
     if (e != hipSuccess) FAIL(c, LRCN_EHIP, "conv3x3: %s", hipGetErrorString(e));
+    return LRCN_OK;
+}
+
+int lrcn_conv1_fused(lrcn_ctx *c, const uint8_t *img, int N, int S, const float mean[3], const float *w11, const float *b11, const float *w12,
+                     const float *b12, float *y) {
+    DeviceGuard dg(c);
+    if (!c || !img || !mean || !w11 || !b11 || !w12 || !b12 || !y) return LRCN_EINVAL;
+    if (N < 1 || S < 16 || (S % 16) || (int64_t)N * (S + 4) * (S + 4) * 3 >= (1ll << 31)) FAIL(c, LRCN_EINVAL, "conv1_fused: S must be a multiple of 16, N >= 1");
+    void *img16 = nullptr, *wf = nullptr, *wp = nullptr, *out = nullptr;
+    float *bd = nullptr;
+    const int So = S / 2;
+    const size_t img16_bytes = 2 * ((size_t)N * (S + 4) * (S + 4) * 3 + 8);
+    auto cleanup = [&]() {
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipFree(img16);
+        (void)hipFree(wf);
+        (void)hipFree(wp);
+        (void)hipFree(out);
+        (void)hipFree(bd);
+    };
+    if (hipMalloc(&img16, img16_bytes) != hipSuccess || hipMalloc(&wf, 2 * 64 * 32) != hipSuccess || hipMalloc(&wp, 2 * (size_t)64 * 9 * 64) != hipSuccess ||
+        hipMalloc(&out, 2 * (size_t)N * So * So * 64) != hipSuccess || hipMalloc((void **)&bd, sizeof(float) * 128) != hipSuccess) {
+        cleanup();
+        FAIL(c, LRCN_ENOMEM, "conv1_fused scratch");
+    }
+    (void)hipMemsetAsync(img16, 0, img16_bytes, c->stream);  // the 2-pixel frame is conv1_1's zero padding
+    (void)hipMemcpyAsync(bd, b11, sizeof(float) * 64, hipMemcpyDeviceToDevice, c->stream);
+    (void)hipMemcpyAsync(bd + 64, b12, sizeof(float) * 64, hipMemcpyDeviceToDevice, c->stream);
+    k_img_u8_to_bf16(c->stream, img, (int64_t)N * S * S * 3, mean[0], mean[1], mean[2], nullptr, S, img16);
+    k_repack_conv11_w_fused(c->stream, w11, bd, wf);
+    k_repack_conv_w(c->stream, GEMM_T_BF16, w12, 64, 64, 64, wp);
+    hipError_t e = launch_conv64_fused11(c->stream, img16, wf, bd, wp, bd + 64, out, N, S, c->zero_page, c->vgg_wg_cap);
+    if (e == hipSuccess) {
+        k_nhwc_to_ref(c->stream, GEMM_T_BF16, out, So, So, 64, N, 64, y);
+        e = hipGetLastError();
+    }
+    cleanup();
+    if (e != hipSuccess) FAIL(c, LRCN_EHIP, "conv1_fused: %s", hipGetErrorString(e));
     return LRCN_OK;
 }
 

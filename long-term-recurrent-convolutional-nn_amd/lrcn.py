@@ -557,6 +557,16 @@ def conv3x3(ctx, x, w, b, relu=True, pool=False):
     return y
 
 
+def conv1_fused(ctx, img_u8, mean, w11, b11, w12, b12):
+    """The bf16 stack's first launch as a probe (conv64f.hip): crops [N][S][S][3] uint8 (device) -> pool1 (S/2, S/2, 64, N); w11 (3,3,3,64),
+    w12 (3,3,64,64) in the reference layouts (lrcn.jl:770 + 724-726 twice)."""
+    N, S = img_u8.shape[0], img_u8.shape[1]
+    y = jl_empty(S // 2, S // 2, 64, N)
+    m = (C.c_float * 3)(*[float(v) for v in mean])
+    ctx._call("lrcn_conv1_fused", C.c_void_p(img_u8.data_ptr()), N, S, m, _ptr(w11), _ptr(b11), _ptr(w12), _ptr(b12), _ptr(y))
+    return y
+
+
 def vgg_set_wg_cap(ctx, cap):
     """Cap the VGG convolution grids at `cap` workgroups (0 = off): include/lrcn.h lrcn_vgg_set_wg_cap."""
     ctx._call("lrcn_vgg_set_wg_cap", int(cap))

@@ -429,6 +429,22 @@ int lrcn_conv3x3(lrcn_ctx *c, const float *x, int W, int H, int Cin, int N, cons
     free(t);
     return LRCN_OK;
 }
+int lrcn_conv1_fused(lrcn_ctx *c, const uint8_t *img, int N, int S, const float mean[3], const float *w11, const float *b11, const float *w12,
+                     const float *b12, float *y) {
+    /* read_image_data's arithmetic, conv1_1 + ReLU, conv1_2 + ReLU, pool (lrcn.jl:770, 724-726) -- with orc_set_emulate_bf16(1) rounded where
+     * the bf16 stack rounds (orc_conv3x3 rounds its operands and its result itself) */
+    if (!c || !img || !mean || !w11 || !b11 || !w12 || !b12 || !y) return LRCN_EINVAL;
+    if (N < 1 || S < 16 || (S % 16)) FAIL(c, LRCN_EINVAL, "conv1_fused: S must be a multiple of 16, N >= 1");
+    const size_t px = (size_t)S * S * N;
+    float *x = (float *)malloc(sizeof(float) * px * 3), *t1 = (float *)malloc(sizeof(float) * px * 64), *t2 = (float *)malloc(sizeof(float) * px * 64);
+    if (!x || !t1 || !t2) { free(x); free(t1); free(t2); FAIL(c, LRCN_ENOMEM, "conv1_fused scratch"); }
+    orc_preprocess_u8(img, S, N, mean, x);
+    orc_conv3x3(x, S, S, 3, N, w11, b11, 64, 1, t1);
+    orc_conv3x3(t1, S, S, 64, N, w12, b12, 64, 1, t2);
+    orc_pool2(t2, S, S, 64, N, y);
+    free(x); free(t1); free(t2);
+    return LRCN_OK;
+}
 int lrcn_train_step_dp(lrcn_ctx *c, float *const p[9], float *const g[9], float *const m[9], float *const v[9], const uint8_t *img_u8,
                        const float mean[3], int normalize, float *feats, const int32_t *tokens, int T, int B, int norm_B,
                        const lrcn_dropout *drop, int step, float lr, float b1, float b2, float eps, double *loss_host) {

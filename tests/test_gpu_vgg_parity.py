@@ -217,6 +217,45 @@ def test_fused_conv1_1_conv1_2_matches_two_launch_path(vgg_setup, monkeypatch):
     assert rel_max_err(outs["1"], outs["0"]) <= 1.5e-2
 
 
+@pytest.mark.parametrize("gen", ["2", "1"])
+@pytest.mark.parametrize("S,N,cap", [(16, 1, 0), (32, 3, 0), (48, 2, 8), (64, 5, 8), (224, 1, 24)])
+def test_fused_conv1_launch_vs_emulating_oracle(S, N, cap, gen, monkeypatch):
+    # the bf16 stack's first launch by itself (lrcn_conv1_fused): mean subtraction + conv1_1 + ReLU + conv1_2 + ReLU + pool in ONE kernel --
+    # gen 2 = conv64f.hip (producer slices inside every wave's half-tap loop, bias in the K padding), gen 1 = conv64.hip FUSE (alternating
+    # wave groups) -- value by value against the bf16-EMULATING oracle.  cap = 8 / 24 workgroups: every workgroup walks several tiles
+    # (patch-buffer toggling, raw windows three patches ahead, the tail where no tile is left to produce); S = 16: a single tile that is all border.
+    monkeypatch.setenv("LRCN_FUSE11_GEN", gen)
+    rng = np.random.default_rng(S * 10 + N)
+    img = rng.integers(0, 256, size=(N, S, S, 3), dtype=np.uint8)
+    img[0, : S // 4] = 255  # a saturated and a dark band: ReLU cut-off at the borders
+    img[-1, -S // 4:] = 0
+    w11 = (rng.standard_normal((3, 3, 3, 64)) * np.sqrt(2.0 / 27)).astype(np.float32)
+    w12 = (rng.standard_normal((3, 3, 64, 64)) * np.sqrt(2.0 / 576)).astype(np.float32)
+    b11 = (rng.standard_normal(64) * 20.0).astype(np.float32)  # of the size of the activations: a bias lost or doubled cannot hide
+    b12 = (rng.standard_normal(64) * 20.0).astype(np.float32)
+    mean = np.array(L.VGG_MEAN, np.float32)
+    x = orc.preprocess_u8(img, mean)
+    ref = orc.pool2(orc.conv3x3(orc.conv3x3(x, w11, b11, relu=True), w12, b12, relu=True))
+    with orc.emulate_bf16():
+        a1 = orc.conv3x3(x, w11, b11, relu=True)
+        emu = orc.pool2(orc.conv3x3(a1, w12, b12, relu=True))
+    ctx = small_ctx(lrcn_amd.LRCN_BF16)
+    if cap:
+        L.vgg_set_wg_cap(ctx, cap)
+    got = L.from_jl(L.conv1_fused(ctx, torch.as_tensor(img).cuda(), mean, L.to_jl(w11), torch.as_tensor(b11).cuda(), L.to_jl(w12),
+                                  torch.as_tensor(b12).cuda()))
+    ctx.close()
+    assert got.shape == ref.shape and (got > 0).any()
+    assert rel_max_err(got, ref) <= 2e-2
+    # Two chained bf16 layers: where the kernel's f32 sum of conv1_1 lands on the neighbouring bf16 (one step <= 2^-7 relative, ~1e-3 of
+    # the values), the conv1_2 sums that read it move by that step times a weight -- little against the tensor, but any number of steps of
+    # a sum that cancels to near zero.  So: one output step, plus ONE flipped conv1_1 input at its worst; and nearly every value identical.
+    diff = np.abs(got - emu)
+    flip = 2.0 ** -7 * float(np.abs(a1).max()) * float(np.abs(w12).max())
+    assert (diff <= 2.0 ** -7 * np.abs(emu) + flip).all(), (gen, float(diff.max()), flip)
+    assert (diff == 0).mean() > 0.999, float((diff == 0).mean())
+
+
 # ---------------------------------------------------------------------------------------------- fp8 (BASELINE config 5)
 def _e4m3(a):
     """round-to-nearest-even OCP e4m3 with saturation at +-448, returned as float32 (torch's float8_e4m3fn cast)."""

@@ -23,6 +23,13 @@ def report(name, lib, ctx, ntiles, skip=0, fused=False):
         ok = (s[:, 5] > s[:, 0]) & (s[:, 0] > 0)
         s = s[ok]
         seg = lambda a, b: float(np.median(s[:, b] - s[:, a]))
+        if fused and os.environ.get("LRCN_FUSE11_GEN", "1") == "2":
+            # conv64f.hip: [0] patch start, [1] sub-step 36 of 72, [3] loop done, [4] epilogue + this wave's LDS writes done, [5] barrier passed
+            ticks = np.maximum((s[:, 6] - s[:, 7]).astype(np.float64), 1.0)
+            ghz = float(np.median((s[:, 5] - s[:, 0]) / ticks)) / 10.0
+            print("%-22s group %d | sub-steps 0-35 %6.0f  36-71 %6.0f  epilogue %6.0f  barrier %6.0f | patch %7.0f cycles  %.2f GHz  (%d tiles)"
+                  % (name, g, seg(0, 1), seg(1, 3), seg(3, 4), seg(4, 5), seg(0, 5), ghz, len(s)))
+            continue
         if fused:   # fine stamps of the FUSE epilogue phase: [3] stores issued, [6] raw window landed, [7] producer's LDS reads landed
             ok2 = (s[:, 7] > s[:, 6]) & (s[:, 6] > s[:, 2])
             t = s[ok2]
