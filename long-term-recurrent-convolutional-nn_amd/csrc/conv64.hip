@@ -611,8 +611,8 @@ hipError_t launch_conv64_fused11(hipStream_t stream, const void *img16, const vo
     if (!img16 || !w11 || !b11 || !w || !out || !zero_page || N < 1 || S < 16 || (S % 16)) return hipErrorInvalidValue;
     if ((int64_t)N * (S + 4) * (S + 4) * 3 >= (1ll << 31)) return hipErrorInvalidValue;
     {
-        const char *gen = getenv("LRCN_FUSE11_GEN");  // 2: conv64f.hip (second generation, in development); default: this file's alternating kernel
-        if (gen && gen[0] == '2') return launch_conv64f(stream, img16, w11, w, bias, out, N, S, zero_page, wg_cap, stamps);
+        const char *gen = getenv("LRCN_FUSE11_GEN");  // 1: this file's alternating kernel (round 3); default: conv64f.hip
+        if (!(gen && gen[0] == '1')) return launch_conv64f(stream, img16, w11, w, bias, out, N, S, zero_page, wg_cap, stamps);
     }
     Conv64Args a{};
     a.w = reinterpret_cast<const bf16_t *>(w);

@@ -100,6 +100,6 @@ hipError_t launch_conv64(hipStream_t stream, const void *in, const void *w, cons
 hipError_t launch_conv64_fused11(hipStream_t stream, const void *img16, const void *w11, const float *b11, const void *w,
                                  const float *bias, void *out, int N, int S, const void *zero_page, int wg_cap = 0, unsigned long long *stamps = nullptr);
 // the second generation of that launch (conv64f.hip: producer slices inside every wave's half-tap loop, one barrier per patch); conv1_1's
-// bias comes in w11's K padding.  launch_conv64_fused11 routes here with LRCN_FUSE11_GEN=2.
+// bias comes in w11's K padding.  launch_conv64_fused11 routes here unless LRCN_FUSE11_GEN=1.
 hipError_t launch_conv64f(hipStream_t stream, const void *img16, const void *w11, const void *w, const float *bias, void *out, int N, int S,
                           const void *zero_page, int wg_cap = 0, unsigned long long *stamps = nullptr);

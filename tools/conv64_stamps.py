@@ -23,7 +23,7 @@ def report(name, lib, ctx, ntiles, skip=0, fused=False):
         ok = (s[:, 5] > s[:, 0]) & (s[:, 0] > 0)
         s = s[ok]
         seg = lambda a, b: float(np.median(s[:, b] - s[:, a]))
-        if fused and os.environ.get("LRCN_FUSE11_GEN", "1") == "2":
+        if fused and os.environ.get("LRCN_FUSE11_GEN", "2") != "1":
             # conv64f.hip: [0] patch start, [1] sub-step 36 of 72, [3] loop done, [4] epilogue + this wave's LDS writes done, [5] barrier passed
             ticks = np.maximum((s[:, 6] - s[:, 7]).astype(np.float64), 1.0)
             ghz = float(np.median((s[:, 5] - s[:, 0]) / ticks)) / 10.0

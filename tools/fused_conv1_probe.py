@@ -42,6 +42,6 @@ def run(S, N, cap, gen):
 
 if __name__ == "__main__":
     a = [int(v) for v in sys.argv[1:]]
-    cases = [a[k:k + 4] for k in range(0, len(a), 4)] or [[48, 2, 8, 2], [48, 2, 8, 1], [48, 2, 0, 2], [64, 5, 8, 2], [224, 1, 24, 2], [224, 1, 24, 1]]
+    cases = [a[k:k + 4] for k in range(0, len(a), 4)] or [[16, 1, 0, 2], [48, 2, 8, 2], [48, 2, 8, 1], [64, 5, 8, 2], [224, 1, 24, 2], [224, 1, 24, 1]]
     for S, N, cap, gen in cases:
         run(S, N, cap, gen)
