@@ -132,6 +132,17 @@ def test_image_front_end_and_operators_through_the_abi(lib, golden_dir):
     yp = np.zeros(z["yp"].shape, np.float32, order="F")
     assert lib.lrcn_conv3x3(ctx, fptr(x), x.shape[0], x.shape[1], x.shape[2], x.shape[3], fptr(w), fptr(b), w.shape[3], 1, 1, fptr(yp)) == 0
     np.testing.assert_allclose(yp, z["yp"], rtol=1e-5, atol=1e-5)
+    # the bf16 stack's first launch as a probe (lrcn_conv1_fused): on the twin = the oracle's operators composed
+    img = rng.integers(0, 256, size=(2, 16, 16, 3), dtype=np.uint8)
+    w11 = orc.fa((rng.standard_normal((3, 3, 3, 64)) * 0.3).astype(np.float32))
+    w12 = orc.fa((rng.standard_normal((3, 3, 64, 64)) * 0.06).astype(np.float32))
+    b11, b12 = (rng.standard_normal(64).astype(np.float32) for _ in range(2))
+    mean = (C.c_float * 3)(104.0, 117.0, 123.0)
+    y1 = np.zeros((8, 8, 64, 2), np.float32, order="F")
+    assert lib.lrcn_conv1_fused(ctx, fptr(img), 2, 16, mean, fptr(w11), fptr(b11), fptr(w12), fptr(b12), fptr(y1)) == 0
+    x1 = orc.preprocess_u8(img, np.array([104.0, 117.0, 123.0], np.float32))
+    np.testing.assert_allclose(y1, orc.pool2(orc.conv3x3(orc.conv3x3(x1, w11, b11, relu=True), w12, b12, relu=True)), rtol=1e-5, atol=1e-4)
+    assert lib.lrcn_conv1_fused(ctx, fptr(img), 2, 20, mean, fptr(w11), fptr(b11), fptr(w12), fptr(b12), fptr(y1)) != 0  # S % 16
     f = orc.fa(np.abs(rng.standard_normal((3, 4096))).astype(np.float32))
     ref = f / f.sum(axis=1, keepdims=True)
     assert lib.lrcn_normalize_features(ctx, fptr(f), 3) == 0
