@@ -446,12 +446,14 @@ template <bool STAMPS> __global__ __launch_bounds__(512) void conv64f_kernel(con
             for (int mi = 0; mi < 2; ++mi) {
                 unsigned char *row = tile0 + (size_t)mi * So * 128;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
+                for (int g = 0; g < 4; g += 2) {  // two windows per conversion: v_max3 + v_max + v_add each, ONE v_cvt_pk_bf16_f32 and ONE packed ReLU for both
                     constexpr int kPos2g[4] = {0, 5, 6, 3};  // kWinPos[2 g]
-                    const float v = fmaxf(fmaxf(acc[mi][4 * g], acc[mi][4 * g + 1]), fmaxf(acc[mi][4 * g + 2], acc[mi][4 * g + 3])) + bv;
-                    const unsigned ow = relu_bf16x2(__builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{v, v}, bf16x2)));
-                    const unsigned off = out_lane ^ (unsigned)(kPos2g[g] * 128);  // (out_lane's channel part is < 128: the XOR touches the column bits only)
-                    *reinterpret_cast<unsigned short *>(row + off) = (unsigned short)ow;
+                    const float v0 = fmaxf(fmaxf(fmaxf(acc[mi][4 * g], acc[mi][4 * g + 1]), acc[mi][4 * g + 2]), acc[mi][4 * g + 3]) + bv;
+                    const float v1 = fmaxf(fmaxf(fmaxf(acc[mi][4 * g + 4], acc[mi][4 * g + 5]), acc[mi][4 * g + 6]), acc[mi][4 * g + 7]) + bv;
+                    const unsigned ow = relu_bf16x2(__builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{v0, v1}, bf16x2)));
+                    // (out_lane's channel part is < 128: the XOR touches the window-column bits only)
+                    *reinterpret_cast<unsigned short *>(row + (out_lane ^ (unsigned)(kPos2g[g] * 128))) = (unsigned short)ow;
+                    *reinterpret_cast<unsigned short *>(row + (out_lane ^ (unsigned)(kPos2g[g + 1] * 128))) = (unsigned short)(ow >> 16);
                 }
             }
         }
