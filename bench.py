@@ -476,8 +476,8 @@ def main(argv=None):
     if rank == 0:
         ms_step = 1e3 * dt_s / a.steps
         value = (B if a.emulate_world > 1 else Bg) * a.steps / dt_s
-        # dominant kernel family: the 12 convolution launches conv1_2..conv5_3 (2 x conv64_kernel + 10 x gemm8p_kernel<CONV3>)
-        # bf16: conv1_1 runs inside conv1_2's launch (conv64.hip FUSE), so its FLOPs belong to the 12 timed launches
+        # dominant kernel family: the 12 convolution launches conv1_2..conv5_3 (conv64f_kernel + conv64_kernel + 10 x gemm8p_kernel<CONV3>)
+        # bf16: conv1_1 runs inside conv1_2's launch (conv64f.hip), so its FLOPs belong to the 12 timed launches
         fused11 = a.dtype == "bf16" and os.environ.get("LRCN_FUSE11", "1")[:1] != "0" and os.environ.get("LRCN_CONV64", "1")[:1] != "0"
         flops_per_launch = (VGG_CONV_GFLOP_PER_IMAGE - (0.0 if fused11 else CONV11_GFLOP_PER_IMAGE)) * 1e9 * Bv / 12.0
         avg_launch_s = conv_ms.value * 1e-3 / max(conv_n.value, 1)
@@ -513,7 +513,7 @@ def main(argv=None):
                      "launched_by": "bench.py" if os.environ.get("LRCN_BENCH_LAUNCHED") else ("torch.distributed.run" if world > 1 else "direct")},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": traffic, "traffic_source": traffic_note,
-                         "kernel": "conv64_kernel (conv1_1+conv1_2 fused, conv2_1) + gemm8p_kernel<*,CONV3,*> (conv2_2..conv5_3): 12 launches/step"
+                         "kernel": "conv64f_kernel (conv1_1+conv1_2 fused) + conv64_kernel (conv2_1) + gemm8p_kernel<*,CONV3,*> (conv2_2..conv5_3): 12 launches/step"
                                    if a.dtype == "bf16" else "gemm_glds_kernel<float,*,CONV3,*> v_mfma_f32_32x32x2_f32 (conv1_2..conv5_3)",
                          "avg_launch_ms": 1e3 * avg_launch_s, "flops_per_launch": flops_per_launch},
         }

@@ -24,7 +24,7 @@ def main():
     nparam = int(sys.argv[4]) if len(sys.argv) > 4 else 39846640
     fe, wr = load(fetch), load(write)
     def is_conv(k):  # the 12 launches conv1_2 .. conv5_3: conv64_kernel (Cin = 64) and the CONV3 instantiations of the GEMMs
-        if "conv64_kernel" in k:
+        if "conv64_kernel" in k or "conv64f_kernel" in k:  # conv64f_kernel: the fused conv1_1 + conv1_2 launch since round 4
             return True
         if "gemm8p_kernel<" in k or "gemm_glds_kernel<" in k:
             args = k[k.index("<") + 1:k.index(">")].split(",")
@@ -35,7 +35,7 @@ def main():
     f_kib = sum(sum(fe[k]) for k in conv)
     w_kib = sum(sum(wr[k]) for k in conv)
     res = {
-        "kernel_family": "conv64_kernel + gemm8p_kernel<*,CONV3,*> (conv1_2..conv5_3)",
+        "kernel_family": "conv64f_kernel + conv64_kernel + gemm8p_kernel<*,CONV3,*> (conv1_2..conv5_3)",
         "launches_counted": n,
         "fetch_size_kib_per_launch": f_kib / n,
         "write_size_kib_per_launch": w_kib / n,
