@@ -141,6 +141,11 @@ resize_crop(ctx, src, offsets::Vector{Int64}, heights::Vector{Cint}, widths::Vec
 set_average_image(ctx, avg) = check(ctx, ccall((:lrcn_set_average_image, lib), Cint, (Ptr{Cvoid}, Ptr{Cfloat}), ctx.h, pointer(avg)))
 # input / sum(input) per row (lrcn.jl:595-597), in place
 normalize_features(ctx, feats) = check(ctx, ccall((:lrcn_normalize_features, lib), Cint, (Ptr{Cvoid}, Ptr{Cfloat}, Cint), ctx.h, pointer(feats), size(feats, 1)))
+# parity probe of the bf16 stack's first launch (mean subtraction, conv1_1 + ReLU, conv1_2 + ReLU, pool in one kernel): img = N decoded
+# crops [n][S][S][3] uint8 on the device, w11 (3,3,3,64), w12 (3,3,64,64) as in the vgg16 .mat file -> y (S/2,S/2,64,N)   lrcn.jl:770, 724-726
+conv1_fused(ctx, img, N, S, mean::Vector{Cfloat}, w11, b11, w12, b12, y) = check(ctx, ccall((:lrcn_conv1_fused, lib), Cint,
+        (Ptr{Cvoid}, Ptr{UInt8}, Cint, Cint, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}),
+        ctx.h, pointer(img), N, S, mean, pointer(w11), pointer(b11), pointer(w12), pointer(b12), pointer(y)))
 
 # ---- data parallelism over the GPUs of a node: one Julia process (or task) + one Context per GPU ----
 # rank 0: id = comm_unique_id(); ship the 128 bytes to the other ranks (Distributed.jl, a file, MPI ...); every rank: comm_init
