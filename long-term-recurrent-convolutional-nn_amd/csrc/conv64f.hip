@@ -13,19 +13,22 @@
 //     conv1_2 runs on v_mfma_f32_32x32x16_bf16 (half the MFMA instructions of 16x16x32 for the same pipe cycles: a wave's 64 pixels x
 //     32 channels = 2 m-tiles of 32 pixels (2 image rows x 16 columns) x 1 n-tile, K = 16 per instruction), and whatever else a wave
 //     has to issue is cut into pieces of <= 3..4 instructions and PINNED (sched_barrier) behind the MFMAs: a patch is 72 sub-steps
-//     per wave (36 K-steps x 2 m-tiles) of [wait for the m-tile's A fragment | MFMA | one micro-slice of the conv1_1 producer of the
-//     NEXT patch | LDS read of the same m-tile's fragment two K-steps ahead];
-//   * the fragment is single-buffered (16 registers; the read goes into the registers the two MFMAs just consumed) -- the registers
+//     per wave (36 K-steps x 2 m-tiles) of [wait for the m-tile's A fragment | MFMA | LDS read of the same m-tile's fragment two K-steps
+//     ahead | one micro-slice of the conv1_1 producer of the NEXT patch];
+//   * the fragment is single-buffered (16 registers; the read goes into the registers the MFMA has just consumed) -- the registers
 //     that frees are what the producer's rolling state lives in (the conv1_2 weights of all nine taps stay resident: 144);
-//   * the producer of an m-tile (16 patch pixels x 64 channels, K = 27 -> 32) is 20 micro-slices: table read | raw-window reads |
-//     conv1_1 weight reads | store address | border mask | im2col fragment (2) | MFMA | MFMA + weight reads | 2 x (convert + ReLU |
-//     address + store) | MFMA | MFMA | 2 x (...).  Everything that depends only on the lane (which patch pixel, where its raw run
-//     starts, where its 8 bytes go in the swizzled patch, which tile borders would zero it) comes from a per-lane TABLE in LDS, filled
-//     once per launch: an LDS read instead of ~30 vector-ALU instructions per m-tile -- the vector issue port, not the matrix pipe, is
-//     what a patch is short of.  A wave owns 3 of a patch's 21 m-tiles (waves 5..7: two, and repeat one -- the LDS-operation count per
-//     sub-step is what the counted s_waitcnt lgkmcnt(N) of every sub-step is computed from, so it must not depend on the wave);
-//   * LDS operations return in order: an operation issued in sub-step k has landed once sub-step k + 4 has waited for ITS fragment
-//     (issued at the end of k), so micro-slices are simply placed >= 5 sub-steps after the reads they consume: no extra waits;
+//   * the producer of an m-tile (16 patch pixels x 64 channels, K = 27 -> 32) is 17 micro-slices over 24 sub-steps: raw-window reads (2) |
+//     conv1_1 weight reads | store address + border mask | im2col fragment (2) | MFMA | MFMA + weight reads | convert + ReLU (2) |
+//     16-byte store | MFMA | MFMA | the next slot's table read | convert + ReLU (2) | 16-byte store.  Everything that depends only on the
+//     lane (which patch pixel, where its raw run starts, where its 16 bytes go in the swizzled patch, which tile borders would zero it)
+//     comes from a per-lane TABLE in LDS, filled once per launch: an LDS read instead of ~30 vector-ALU instructions per m-tile.  No inline
+//     asm in a slice but the LDS operations themselves, no compare into an SGPR pair, conversions >= 4 sub-steps behind their MFMA: each
+//     of those drew an s_nop, and a pad inside an MFMA-paced stream costs 17..43 cycles, not 4.  A wave owns 3 of a patch's 21 m-tiles
+//     (waves 5..7: two, and repeat one -- the LDS-operation count per sub-step is what the counted s_waitcnt lgkmcnt(N) of every
+//     sub-step is computed from, so it must not depend on the wave);
+//   * LDS operations return in order: an operation issued in sub-step k has landed once sub-step k + 5 has waited for ITS fragment
+//     (issued in k + 1, behind it), so micro-slices are simply placed >= 5 sub-steps after the reads they consume: no extra waits.
+//     Every asm read must be CONSUMED: a result hipcc sees as dead leaves its registers free for other values, and the data lands in them;
 //   * conv1_1's bias rides in the K padding: k' = 27, 28, 29 of the im2col fragment hold 1.0 and the weight rows hold the f32 bias cut
 //     into three bf16 pieces (hi + mid + lo = the f32 value exactly), so the accumulator input is the constant 0, no bias registers
 //     or LDS reads, and a patch pixel outside the image (conv1_2's zero padding) is ONE mask on the fragment: 0 x w + 0 x b = 0;
@@ -95,12 +98,11 @@ template <int OFF> __device__ __forceinline__ u32x4 lds_read16(unsigned addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
     return r;
 }
-__device__ __forceinline__ void lds_write8(unsigned addr, u32x2 v) { asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
 #define PIN() __builtin_amdgcn_sched_barrier(0)
 
-// ---- the static schedule of a patch: 72 sub-steps s = 4 h + i (half-tap h, m-tile i of the wave) ----
+// ---- the static schedule of a patch: 72 sub-steps s = 2 ksn + mi (K-step ksn = 4 tap + kk of 36, m-tile mi of the wave's two) ----
 constexpr int NSUB = 72;
 // producer micro-slice of sub-step s: m-tile slot s / 24, event r = s % 24
 constexpr int R_RAW2 = 0, R_RAW16 = 1, R_W01 = 2, R_WBASE = 3, R_AV0 = 6, R_AV1 = 7, R_MM0 = 8, R_MM1 = 9, R_CV0 = 13, R_CV1 = 14, R_ST01 = 15, R_MM2 = 16,
@@ -131,7 +133,7 @@ template <bool STAMPS> __global__ __launch_bounds__(512) void conv64f_kernel(con
     extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wp = wave & 3;   // pixel group: m-tiles 4 wp .. 4 wp + 3 of the 16 (window rows 2 wp, 2 wp + 1)
+    const int wp = wave & 3;   // pixel group: image rows 4 wp .. 4 wp + 3 of the 16 x 16 tile (window rows 2 wp, 2 wp + 1)
     const int wq = wave >> 2;  // channel group (32 channels)
     const int S = a.S, So = S >> 1;
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
@@ -159,7 +161,7 @@ template <bool STAMPS> __global__ __launch_bounds__(512) void conv64f_kernel(con
         // registers r of a group g are rows 8 g + 4 lh + r = ONE window (pool = max of 4 registers).  Window win sits at window column
         // kWinPos[win]: the LDS serves a ds_read_b128 in the lane groups {0-3, 12-15, 20-27} and {4-11, 16-19, 28-31} (+ 32), i.e. windows
         // {0, 3, 5, 6} and {1, 2, 4, 7}; each group gets 8 adjacent columns x 2 rows, which the patch swizzle spreads over all 16 bank slots
-        // at every tap shift.  (kWinPos[2 g + 1] = kWinPos[2 g] ^ 4: the epilogue's store offset is one v_xad.)
+        // at every tap shift.  (kWinPos[2 g + 1] = kWinPos[2 g] ^ 4: the epilogue's store offset of lane half lh is one XOR.)
         const int win = l31 >> 2, dy = (l31 >> 1) & 1, dx = l31 & 1;
         const int wpos = (0x73261540 >> (4 * win)) & 7;  // kWinPos[win] = {0, 4, 5, 1, 6, 2, 3, 7}
         const int x = 2 * wpos + dx;
@@ -238,7 +240,7 @@ template <bool STAMPS> __global__ __launch_bounds__(512) void conv64f_kernel(con
     };
 
     // ---- the conv1_1 producer, in micro-slices.  No inline asm but the LDS operations themselves, no compare into an SGPR pair, every
-    // conversion >= 3 sub-steps behind its MFMA: each of those made hipcc pad with an s_nop, and a pad inside an MFMA-paced stream costs
+    // conversion >= 4 sub-steps behind its MFMA: each of those made hipcc pad with an s_nop, and a pad inside an MFMA-paced stream costs
     // 17..43 cycles of the wave's time (MI355X_MICROARCH.md), not 4 ----
     u32x4 p_tab;                    // this slot's table entry
     u32x2 p_runl, p_runh;           // the first 8 values of the lane's 9-value run
