@@ -23,6 +23,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+SCRIPT = os.path.abspath(__file__)   # what launch() / supervise() start as ranks (tests/bench_dryrun.py wraps this file and puts itself here)
 
 # algorithmic work, SURVEY.md 8(d)
 VGG_CONV_GFLOP_PER_IMAGE = 30.693        # 13 conv layers
@@ -235,84 +236,48 @@ def launch(a, argv):
     """`python bench.py --gpus N` with no WORLD_SIZE in the environment: this process NEVER touches the GPU (no torch import, no HIP call --
     a parent that had initialised the device could not be replaced or forked safely); it starts the N ranks as a CHILD job
     (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same flags>`),
-    waits for it under a watchdog, relays rank 0's JSON line and exits with the job's code.  --dp-backend auto: first attempt with the
-    C-ABI communicator, second with torch.distributed's if the first fails or hangs (only the parent can do that safely)."""
+    waits for it under a watchdog, relays rank 0's JSON line and exits with the job's code.  Every rank of that job is itself a GPU-free
+    supervisor that walks the ladder of supervise() below -- the same thing happens when the driver starts the torchrun job itself."""
     from lrcn_amd import launch as lch   # imports neither torch nor the HIP library
-    backends = ["abi", "torch"] if a.dp_backend == "auto" else [a.dp_backend]
-    child_argv = [x for x in argv]
-    last_rc = 1
-    for attempt, backend in enumerate(backends):
-        rc, out = lch.run_ranks(__file__, child_argv, a.gpus, {"LRCN_DP_BACKEND": backend, "LRCN_BENCH_LAUNCHED": "1"}, a.watchdog_s)
-        if rc == 124:
-            print("bench.py: the %d-rank job (dp backend %s) did not finish within %.0f s and was stopped" % (a.gpus, backend, a.watchdog_s),
-                  file=sys.stderr)
-        lines = [ln for ln in (out or "").splitlines() if ln.startswith("{") and '"metric"' in ln]
-        if rc == 0 and lines:
-            line = json.loads(lines[-1])
-            line.setdefault("rccl", {})["launcher"] = "self (bench.py spawned torch.distributed.run; attempt %d of %d)" % (attempt + 1, len(backends))
-            print(json.dumps(line), flush=True)
-            return 0
-        last_rc = rc or 1
-        print("bench.py: %d-rank job with dp backend %s failed (rc %s)%s" % (a.gpus, backend, rc, "; retrying with the next backend"
-                                                                           if attempt + 1 < len(backends) else ""), file=sys.stderr)
-    return last_rc
+    rc, out = lch.run_ranks(SCRIPT, list(argv), a.gpus, {"LRCN_BENCH_LAUNCHED": "1"}, a.watchdog_s)
+    if rc == 124:
+        print("bench.py: the %d-rank job did not finish within %.0f s and was stopped" % (a.gpus, a.watchdog_s), file=sys.stderr)
+    lines = [ln for ln in (out or "").splitlines() if is_json_line(ln)]
+    if rc == 0 and lines:
+        line = json.loads(lines[-1])
+        line.setdefault("rccl", {})["launcher"] = "self (bench.py spawned torch.distributed.run)"
+        print(json.dumps(line), flush=True)
+        return 0
+    print("bench.py: the %d-rank job failed (rc %s)" % (a.gpus, rc), file=sys.stderr)
+    return rc or 1
 
 
-def dryrun_main(a, world, rank):
-    """LRCN_BENCH_DRYRUN=1 (tests/test_bench_launcher.py): the SAME launcher, rank set-up, sharding, trainer (dp.DataParallelTrainer), barrier +
-    max-over-ranks timing and JSON assembly over gloo on the CPU, with tests/dp_oracle_ops.py's stand-ins for the device operations and tiny
-    dimensions.  It proves `--gpus N` produces one well-formed line with n_gpus = N before an N-GPU node exists; it measures nothing."""
-    import numpy as np
-    import torch
-    import torch.distributed as dist
-    from lrcn_amd import dp
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import dp_oracle_ops as doo
-    if os.environ.get("LRCN_BENCH_DRYRUN_FAIL_ABI") and os.environ.get("LRCN_DP_BACKEND") == "abi":
-        raise SystemExit("dry run: simulated failure of the C-ABI communicator")
-    if os.environ.get("LRCN_BENCH_DRYRUN_HANG"):   # a rank stuck in a collective: the file named here receives its pid, then it sleeps
-        with open(os.environ["LRCN_BENCH_DRYRUN_HANG"] + ".%d" % rank, "w") as f:
-            f.write(str(os.getpid()))
-        time.sleep(3600)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-    E = H = 16
-    V, T, Bg = 37, 3, 8
-    rows = dp.shard_rows(Bg, world * a.emulate_world, rank)
-    param, optim, ops = doo.make(E, H, V, seed=42)
-    trainer = dp.DataParallelTrainer(None, param, optim, Bg, world, rank, pdrop=0.0, seed=7, ops=ops, backend="torch")
-    rng = np.random.default_rng(7)
-    feats = torch.as_tensor((rng.standard_normal((Bg, 4096)) * 0.01).astype(np.float32)[rows])
-    toks = rng.integers(3, V, size=(T, Bg)).astype(np.int32)[:, rows]
+def is_json_line(ln):
+    return ln.startswith("{") and '"metric"' in ln
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
 
-    for _ in range(a.warmup):
-        trainer.step(None, toks, feats=feats)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        trainer.step(None, toks, feats=feats)
-    barrier()
-    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt_s = float(tt.item())
-    loss = trainer.loss_value()
-    if rank == 0:
-        print(json.dumps({"metric": "DRYRUN (CPU stand-ins, gloo) -- " + metric_name(a), "value": Bg * a.steps / dt_s, "unit": "images/sec",
-                          "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt_s / a.steps, "higher_is_better": True,
-                          "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "dryrun",
-                          "config": {"workload": "dry run of the launcher and the N-rank plumbing", "global_batch": Bg,
-                                     "per_gpu_batch": rows.stop - rows.start, "parallelism": "dp%d" % world, "last_loss": loss},
-                          "rccl": {"world": world, "backend": "gloo-dryrun", "launched_by": os.environ.get("LRCN_BENCH_LAUNCHED", "0")}}), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
-    return 0
+def supervise(a, argv):
+    """WORLD_SIZE > 1 and this is the process torchrun (or the driver) started for one rank: it stays GPU-free and runs the real rank as
+    a fresh child per RUNG of the ladder (lrcn_amd/launch.py): "default" = the full N-rank pipeline (per-group [event -> all-reduce ->
+    fused Adam] on a probed update stream, sparse exchange of the embedding gradient, several batches per VGG forward) -> "plain" = one
+    all-reduce of the flat gradient buffer + one replicated Adam, no probes, one forward per step -> give up (rc != 0).  A rung is left
+    when any rank's child exits non-zero, stops beating for LRCN_BENCH_STALL_S seconds (a hung collective), or fails its own step-1
+    self-check (rank_main: sparse = dense embedding gradient, sum of the ranks' losses = rank 0's recomputation on all rows, parameter
+    checksums equal on every rank).  The line names the rung that produced it: rccl.mode, rccl.rung, rccl.fallback_reason."""
+    from lrcn_amd import launch as lch
+    rungs = lch.default_rungs(a.dp_backend)
+    only = os.environ.get("LRCN_BENCH_RUNGS_ONLY")   # e.g. "plain": development
+    if only:
+        rungs = [r for r in rungs if r[0] in only.split(",")] or rungs
+
+    def annotate(line, name, k, n, reasons):
+        d = json.loads(line)
+        r = d.setdefault("rccl", {})
+        r["mode"], r["rung"], r["fallback_reason"] = name, "%d of %d" % (k + 1, n), ("; ".join(reasons) or None)
+        return json.dumps(d)
+
+    return lch.supervise_rank(SCRIPT, list(argv), rungs, stall_s=float(os.environ.get("LRCN_BENCH_STALL_S", "300")),
+                              rung_s=float(os.environ.get("LRCN_BENCH_RUNG_S", "900")), is_line=is_json_line, annotate=annotate)
 
 
 def csrc_digest():
@@ -342,8 +307,15 @@ def main(argv=None):
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     if a.emulate_world > 1 and world > 1:
         raise SystemExit("--emulate-world is a one-process measurement")
-    if os.environ.get("LRCN_BENCH_DRYRUN"):
-        return dryrun_main(a, world, rank)
+    if world > 1 and not os.environ.get("LRCN_BENCH_CHILD") and os.environ.get("LRCN_BENCH_LADDER", "1")[:1] != "0":
+        return supervise(a, argv)       # this process stays GPU-free; the rank runs as its child, rung by rung
+    return rank_main(a, world, rank, local_rank)
+
+
+def rank_main(a, world, rank, local_rank):
+    """One rank of the job: everything that touches the GPU."""
+    from lrcn_amd.launch import beat
+    beat("started")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     import numpy as np
@@ -368,6 +340,7 @@ def main(argv=None):
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    beat("process group up")
 
     if os.environ.get("LRCN_BENCH_MAIN_STREAM", "0")[:1] == "1":
         # development: run the whole job on a stream of its own instead of the device's null stream (whose work orders itself against the
@@ -390,7 +363,7 @@ def main(argv=None):
     L.vgg_load(ctx, *vgg_w)
     param = L.initweights(ctx, seed=42)          # identical on every rank (same seed)
     optim = L.initparams(param)
-    backend = a.dp_backend if a.dp_backend != "auto" else "torch"   # 'auto' is resolved by launch(); a torchrun-launched job cannot retry
+    backend = a.dp_backend if a.dp_backend != "auto" else "torch"   # 'auto' is resolved by the ladder (supervise): the rung sets LRCN_DP_BACKEND
     emu_shard = bool(a.shard_adam) and a.emulate_world > 1   # one process: rank 0's side of the sharded update, collectives stubbed by copies
     trainer = dp.DataParallelTrainer(ctx, param, optim, Bg, world, rank, pdrop=a.pdrop, seed=7, backend=backend,
                                      shard_adam=bool(a.shard_adam) and (world > 1 or emu_shard), vgg_chunk=m_chunk, rows=B,
@@ -408,8 +381,30 @@ def main(argv=None):
     rng = np.random.default_rng(7)
     pz = 1.0 / np.arange(1, V - 3 + 1)
     pz /= pz.sum()
-    toks_all = [torch.as_tensor((rng.choice(V - 3, size=(T, Bg), p=pz) + 3).astype(np.int32)[:, rows.start:rows.stop]
-                                .copy()).cuda() for _ in range(n_sets)]
+    toks_glob = [(rng.choice(V - 3, size=(T, Bg), p=pz) + 3).astype(np.int32) for _ in range(n_sets)]   # every rank draws the GLOBAL batch
+    toks_all = [torch.as_tensor(t[:, rows.start:rows.stop].copy()).cuda() for t in toks_glob]
+    beat("trainer and inputs ready")
+
+    # First contact (world > 1; LRCN_BENCH_SELFCHECK=1 forces it on one rank): the step-1 self-check, before anything is timed.  On a rung
+    # that has a successor a violation ends this rank with an error -- the supervisors then move every rank to the next rung; on the
+    # last rung it is reported in the line and the number stands with that caveat.
+    selfcheck, strict = None, int(os.environ.get("LRCN_BENCH_RUNG_INDEX", "0")) + 1 < int(os.environ.get("LRCN_BENCH_RUNGS", "1"))
+
+    def verdict(name, ok, detail):
+        selfcheck.setdefault("violations", [])
+        if not ok:
+            selfcheck["violations"].append("%s: %s" % (name, detail))
+            if strict:
+                raise SystemExit("bench.py self-check failed on rung %r: %s: %s" % (os.environ.get("LRCN_BENCH_RUNG", "-"), name, detail))
+
+    if (world > 1 or os.environ.get("LRCN_BENCH_SELFCHECK", "0")[:1] == "1") and a.emulate_world == 1:
+        selfcheck = trainer.self_check(L.convnet_u8(ctx, imgs_dev[0][:B]), toks_glob[0])
+        verdict("world", selfcheck["world_from_communicator"] == world == selfcheck["world_measured_by_allreduce"], selfcheck)
+        verdict("loss over ranks vs rank 0 on all rows", selfcheck["loss_rel_diff"] <= 1e-5, selfcheck["loss_rel_diff"])
+        sp = selfcheck["sparse_vs_dense_embed_grad_rel"]
+        verdict("sparse vs dense embedding gradient", sp is None or sp <= 1e-4, sp)
+        verdict("parameters identical before step 1", selfcheck["params_identical_before_step_1"], "checksums differ")
+        beat("self-check passed")
 
     step_ev = []
     chunk_i = [0]   # index of the chunk whose features are being consumed
@@ -451,6 +446,12 @@ def main(argv=None):
             spun += 1
     run(a.warmup)
     barrier()
+    beat("warm-up done")
+    if selfcheck is not None and a.warmup > 0:
+        same, _ = trainer.check_replicas()
+        selfcheck["params_identical_after_warmup"] = bool(same)
+        verdict("parameters identical after %d warm-up step(s)" % a.warmup, same, "checksums differ")
+        barrier()
     _lib = lrcn_amd._lib
     _lib.check(ctx._h, _lib.lib().lrcn_profile(ctx._h, 1))
     e0 = torch.cuda.Event(enable_timing=True)
@@ -460,6 +461,11 @@ def main(argv=None):
     run(a.steps, events=True)
     barrier()
     dt_s = time.perf_counter() - t0
+    beat("timed region done")
+    if selfcheck is not None:
+        same, _ = trainer.check_replicas()
+        selfcheck["params_identical_after_last_step"] = bool(same)
+        verdict("parameters identical after the last step", same, "checksums differ")
     step_ms_seq = [step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(len(step_ev) - 1)]
     step_ms = sorted(step_ms_seq)
     median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
@@ -505,12 +511,14 @@ def main(argv=None):
                        "inputs": ("pinned host, H2D per step on a copy stream (%.1f MB per step, uploaded one step ahead of the forward that reads it)"
                                   % (B * 224 * 224 * 3 / 1e6)) if a.inputs == "host" else "resident in HBM",
                        "setup_spinup": "%d untimed VGG forwards (%.0f ms) before the warm-up steps; not training steps" % (spun, a.spinup_ms)},
-            "rccl": {"world": world, "backend": ("none (one rank: no collective)" if world == 1 else
+            "rccl": {"world": (dist.get_world_size() if world > 1 else 1), "world_argv": a.gpus, "backend": ("none (one rank: no collective)" if world == 1 else
                                                  ("gloo on ONE shared GPU (LRCN_BENCH_FAKE_MULTI: validation, not a measurement)" if fake_multi else trainer.backend)),
                      "update": ("EMULATED sharded update (Adam on 1/%d of every gradient group; reduce-scatter / all-gather stubbed by device copies of the "
                                 "bytes a rank receives; the other shards' parameters are not updated)" % a.emulate_world) if emu_shard else
                                ("sharded (reduce-scatter -> Adam on 1/N -> all-gather)" if trainer.shard else "replicated (all-reduce -> Adam)"),
-                     "launched_by": "bench.py" if os.environ.get("LRCN_BENCH_LAUNCHED") else ("torch.distributed.run" if world > 1 else "direct")},
+                     "launched_by": "bench.py" if os.environ.get("LRCN_BENCH_LAUNCHED") else ("torch.distributed.run" if world > 1 else "direct"),
+                     "selfcheck": selfcheck,
+                     "pipeline": trainer.describe() if hasattr(trainer, "describe") else None},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": traffic, "traffic_source": traffic_note,
                          "kernel": "conv64f_kernel (conv1_1+conv1_2 fused) + conv64_kernel (conv2_1) + gemm8p_kernel<*,CONV3,*> (conv2_2..conv5_3): 12 launches/step"

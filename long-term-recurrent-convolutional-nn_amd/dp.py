@@ -762,6 +762,122 @@ class DataParallelTrainer:
                             self.flat_param[a + i * n:a + (i + 1) * n].copy_(t)
         self.ops.join(self._bucket_streams)
 
+    def describe(self):
+        """What this trainer's step is made of (reported in bench.py's line: rccl.pipeline)."""
+        buckets = os.environ.get("LRCN_DP_BUCKETS", "1")[:1] != "0"
+        return {"backend": self.backend, "update": "sharded" if self.shard else "replicated", "fused_update": bool(self._fused),
+                "per_group_pipeline": bool(self.shard or (self.backend == "abi" and self._multi) or self._group_pipeline()),
+                "one_allreduce_of_the_flat_buffer": bool(self.world > 1 and not buckets and not self.shard),
+                "sparse_embedding_exchange": bool(getattr(self, "_sparse_embed", False)), "vgg_side_stream": self._side is not None,
+                "queue_probe": getattr(self, "queue_probe", None), "backend_note": self.backend_note or None}
+
+    # ---- first-contact self-check of an N-rank job (bench.py and tools/lrcn.py run it once, before anything is timed) ----
+    def _dist_on(self):
+        return dist.is_available() and dist.is_initialized()
+
+    def _gather_cat(self, t):
+        """All-gather of equal-sized contiguous tensors -> one tensor, rank blocks in rank order (RCCL: on the device; gloo: through host)."""
+        if not self._dist_on():
+            return t.clone()
+        W = dist.get_world_size(self.group)
+        if dist.get_backend(self.group) == "nccl":
+            out = torch.empty((W,) + tuple(t.shape), device=t.device, dtype=t.dtype)
+            dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
+            return out.view((W * t.shape[0],) + tuple(t.shape[1:]))
+        h = t.detach().cpu().contiguous()
+        parts = [torch.empty_like(h) for _ in range(W)]
+        dist.all_gather(parts, h, group=self.group)
+        return torch.cat(parts).to(t.device)
+
+    def param_checksum(self):
+        """An exact, order-independent fingerprint of the nine parameter tensors: the int64 sum of their float32 bit patterns."""
+        tot = 0
+        for t in self.param:
+            if t.numel():
+                tot += int(t.contiguous().view(-1).view(torch.int32).sum(dtype=torch.int64).item()) if t.is_contiguous() else \
+                    int(t.permute(*reversed(range(t.dim()))).contiguous().view(-1).view(torch.int32).sum(dtype=torch.int64).item())
+        return tot
+
+    def check_replicas(self):
+        """-> (identical on every rank?, the checksums in rank order).  Synchronous SGD with a summed gradient keeps replicas bit-identical:
+        every rank receives the same reduced bytes and runs the same Adam arithmetic."""
+        dev = self.param[0].device
+        mine = torch.tensor([self.param_checksum()], dtype=torch.int64, device=dev)
+        allc = [int(x) for x in self._gather_cat(mine).cpu().tolist()]
+        return all(c == allc[0] for c in allc), allc
+
+    def check_sparse_embed(self, feats, tokens):
+        """The sparse exchange of the embedding gradient against the dense one ON THE SAME STEP (same features, tokens and dropout seed):
+        lossgradient with the rows buffer registered -> all-gather -> ordered per-token sum, versus lossgradient scattering into the dense
+        gradient -> all-reduce(SUM).  -> max |sparse - dense| / max |dense|, or None when the sparse path is not in use."""
+        if not getattr(self, "_sparse_embed", False):
+            return None
+        seed = (self.seed + 1) * 65536 + self.rank
+        M = (int(tokens.shape[0]) + 1) * int(tokens.shape[1])
+        dev = self.param[0].device
+        self.ops.set_embed_rows_buffer(None, None)
+        try:
+            self.ops.lossgradient(self.param, feats, tokens, self.B_global, self.pdrop, seed, self.grads)
+            torch.cuda.synchronize(dev)
+            dense = self.grads[6].clone()
+        finally:
+            self.ops.set_embed_rows_buffer(self._emb_rows, self._emb_tok)
+        if self._dist_on():
+            flat = dense.permute(1, 0).contiguous() if not dense.is_contiguous() else dense
+            if dist.get_backend(self.group) == "nccl":
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            else:
+                h = flat.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+                flat.copy_(h)
+            dense_sum = flat.permute(1, 0) if flat is not dense else flat
+        else:
+            dense_sum = dense
+        self.ops.lossgradient(self.param, feats, tokens, self.B_global, self.pdrop, seed, self.grads)
+        torch.cuda.synchronize(dev)
+        rows_all, tok_all, n = self._gather_embed_rows(M)
+        s = torch.cuda.current_stream(dev)
+        self.ops.embed_grad_from_rows(rows_all, tok_all, n, self.grads[6], s)
+        torch.cuda.synchronize(dev)
+        return float((self.grads[6] - dense_sum).abs().max() / (dense_sum.abs().max() + 1e-30))
+
+    def self_check(self, feats, tokens_global):
+        """Before timing, on real inputs of step 1 (feats: this rank's rows of the first batch, tokens_global: [T][B_global] on the host):
+        * the world the communicator reports, and the world an all-reduce of ones measures;
+        * sharding and the loss reduction: the mean over ranks of the shard losses equals rank 0's recomputation, shard by shard, on the
+          features of ALL rows (all-gathered) and its own copy of the global tokens -- a rank that took the wrong rows, or a reduction
+          that lost a rank, shows here;
+        * sparse = dense embedding gradient on the same step (check_sparse_embed);
+        * the parameters are bit-identical on every rank before the first step.
+        -> dict (every rank computes the same values).  The caller decides what a violation means (bench.py: leave the rung)."""
+        dev = self.param[0].device
+        W = dist.get_world_size(self.group) if self._dist_on() else 1
+        ones = torch.ones(1, device=dev)
+        if self._dist_on():
+            dist.all_reduce(ones, op=dist.ReduceOp.SUM, group=self.group)
+        B = int(feats.shape[0])
+        rows = shard_rows(self.B_global, W, self.rank) if W * B == self.B_global else slice(0, B)
+        toks = np.ascontiguousarray(np.asarray(tokens_global)[:, rows])
+        mine = torch.tensor([float(self.ops.loss(self.param, feats, toks))], dtype=torch.float64, device=dev)
+        if self._dist_on():
+            dist.all_reduce(mine, op=dist.ReduceOp.SUM, group=self.group)
+        mean_of_ranks = float(mine.item()) / W
+        # feats is column-major (B x 4096 with the row index fastest): its transpose is the contiguous tensor that travels
+        ft = feats.permute(1, 0) if not feats.is_contiguous() else feats
+        all_ft = self._gather_cat(ft.contiguous())
+        recomputed = 0.0
+        for r in range(W):
+            blk = all_ft[r * ft.shape[0]:(r + 1) * ft.shape[0]]
+            fr = blk.permute(1, 0) if not feats.is_contiguous() else blk
+            rr = shard_rows(self.B_global, W, r) if W * B == self.B_global else slice(0, B)
+            recomputed += float(self.ops.loss(self.param, fr, np.ascontiguousarray(np.asarray(tokens_global)[:, rr]))) / W
+        same, sums = self.check_replicas()
+        return {"world_from_communicator": W, "world_measured_by_allreduce": int(round(float(ones.item()))),
+                "loss_mean_over_ranks": mean_of_ranks, "loss_rank0_recomputed_on_all_rows": recomputed,
+                "loss_rel_diff": abs(mean_of_ranks - recomputed) / (abs(recomputed) + 1e-300),
+                "sparse_vs_dense_embed_grad_rel": self.check_sparse_embed(feats, toks),
+                "params_identical_before_step_1": bool(same)}
+
     def loss_value(self):
         """Global loss of the last step: sum over ranks of the locally normalised partial losses."""
         v = torch.tensor([self.ops.last_loss()], device=self.param[0].device, dtype=torch.float64)

@@ -1,6 +1,8 @@
-"""bench.py's launcher and N-rank plumbing, without a GPU: `python bench.py --gpus 2` with no WORLD_SIZE must start its
-ranks itself -- from a parent that never touches the device -- and relay ONE well-formed JSON line with n_gpus = 2; the torchrun form the
-driver uses for N > 1 must keep working.  LRCN_BENCH_DRYRUN=1 swaps the device operations for tests/dp_oracle_ops.py over gloo."""
+"""bench.py's launcher, per-rank supervisors (the first-contact LADDER, round 5) and N-rank plumbing, without a GPU: `python bench.py --gpus 2`
+with no WORLD_SIZE must start its ranks itself -- from a parent that never touches the device -- and relay ONE well-formed JSON line
+with n_gpus = 2; the torchrun form the driver uses for N > 1 must keep working; a rung that fails, hangs or fails its self-check on ANY
+rank must be left by ALL ranks for the next one, and the line must say which rung produced it and why the earlier ones were left.
+tests/bench_dryrun.py is bench.py with the device operations swapped for tests/dp_oracle_ops.py over gloo."""
 import json
 import os
 import subprocess
@@ -9,12 +11,11 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BENCH = os.path.join(ROOT, "bench.py")
+BENCH = os.path.join(ROOT, "tests", "bench_dryrun.py")   # the main() of bench.py with CPU stand-ins for rank_main
 
 
 def _env():
     env = dict(os.environ)
-    env["LRCN_BENCH_DRYRUN"] = "1"
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
     env.pop("LOCAL_RANK", None)
@@ -41,6 +42,11 @@ def test_self_launch_two_ranks_prints_one_line():
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["value"] > 0
     assert d["rccl"]["world"] == 2 and d["rccl"]["launched_by"] == "1" and "self" in d["rccl"]["launcher"]
     assert d["config"]["per_gpu_batch"] * 2 == d["config"]["global_batch"] and d["config"]["parallelism"] == "dp2"
+    # the ladder's first rung produced the line, and the step-1 self-check ran and passed on it
+    assert d["rccl"]["mode"] == "default" and d["rccl"]["rung"] == "1 of 2" and d["rccl"]["fallback_reason"] is None
+    sc = d["rccl"]["selfcheck"]
+    assert sc["world_from_communicator"] == 2 == sc["world_measured_by_allreduce"] and sc["loss_rel_diff"] <= 1e-6
+    assert sc["params_identical_before_step_1"] and sc["params_identical_after_last_step"] and sc["violations"] == []
 
 
 def test_torchrun_form_still_works():
@@ -54,6 +60,7 @@ def test_torchrun_form_still_works():
     assert r.returncode == 0, r.stderr[-2000:]
     d = _one_line(r.stdout)
     assert d["n_gpus"] == 2 and d["rccl"]["world"] == 2 and d["rccl"]["launched_by"] == "0" and "launcher" not in d["rccl"]
+    assert d["rccl"]["mode"] == "default"   # the driver's own torchrun job walks the same ladder: every rank it starts is a supervisor
 
 
 def test_single_rank_and_emulated_world():
@@ -75,19 +82,64 @@ def test_world_size_mismatch_is_an_error():
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
 
 
-def test_failed_job_is_reported_and_auto_backend_retries(tmp_path):
-    """The launcher returns the job's failure (no line), and --dp-backend auto reruns with torch after a failed abi attempt: the dry run
-    fails on purpose when LRCN_DP_BACKEND=abi and LRCN_BENCH_DRYRUN_FAIL_ABI=1."""
+def _run(args, env, timeout=300):
+    return subprocess.run([sys.executable, BENCH] + args, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_failed_abi_rung_falls_to_the_next_one():
+    """--dp-backend auto puts the C-ABI communicator on the first rung; when it fails on every rank the job reruns as fresh children on the
+    torch.distributed rung.  --dp-backend abi: its only other rung is "plain" (torch.distributed, one all-reduce)."""
     env = _env()
     env["LRCN_BENCH_DRYRUN_FAIL_ABI"] = "1"
-    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "0", "--dp-backend", "abi"], env=env,
-                       capture_output=True, text=True, timeout=300)
-    assert r.returncode != 0 and not r.stdout.strip()
-    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "0", "--dp-backend", "auto"], env=env,
-                       capture_output=True, text=True, timeout=300)
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "0", "--dp-backend", "auto"], env)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _one_line(r.stdout)
-    assert d["n_gpus"] == 2 and "attempt 2 of 2" in d["rccl"]["launcher"]
+    assert d["n_gpus"] == 2 and d["rccl"]["mode"] == "default" and d["rccl"]["rung"] == "2 of 3" and "abi" in d["rccl"]["fallback_reason"]
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "0", "--dp-backend", "abi"], env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _one_line(r.stdout)
+    assert d["rccl"]["mode"] == "plain" and d["rccl"]["env_of_rung"]["LRCN_DP_BACKEND"] == "torch"
+
+
+@pytest.mark.parametrize("how", ["crash", "hang", "selfcheck"])
+def test_one_rank_failing_on_the_default_rung_moves_every_rank_to_plain(how):
+    """Rank 1 alone crashes / stops making progress (a hung collective) / breaks the replicas before the self-check on the "default" rung:
+    rank 0's supervisor stops its own child as soon as rank 1's verdict is in (or its heartbeat is stale), and both rerun as fresh children
+    on "plain" -- one all-reduce of the flat buffer, no sparse exchange -- whose line names the rung and the reason."""
+    env = _env()
+    env["LRCN_BENCH_STALL_S"] = "6"
+    key = {"crash": "LRCN_BENCH_DRYRUN_FAIL_RUNG", "hang": "LRCN_BENCH_DRYRUN_HANG_RUNG", "selfcheck": "LRCN_BENCH_DRYRUN_BAD_SELFCHECK"}[how]
+    env[key] = "default" if how == "selfcheck" else "default:1"
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1"], env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _one_line(r.stdout)
+    rc = d["rccl"]
+    assert rc["mode"] == "plain" and rc["rung"] == "2 of 2" and rc["world"] == 2
+    assert rc["env_of_rung"] == {"LRCN_DP_BUCKETS": "0", "LRCN_DP_SPARSE_EMBED": "0", "LRCN_DP_BACKEND": "torch"}
+    assert "default: rank" in rc["fallback_reason"], rc["fallback_reason"]
+    assert {"crash": "exit code", "hang": "no progress", "selfcheck": "exit code"}[how] in rc["fallback_reason"], rc["fallback_reason"]
+    assert rc["selfcheck"]["violations"] == [] and rc["selfcheck"]["params_identical_after_last_step"]
+    assert "rung 'default' failed" in r.stderr
+
+
+def test_every_rung_failing_is_an_error_without_a_line():
+    env = _env()
+    env["LRCN_BENCH_DRYRUN_FAIL_ABI"] = "1"
+    env["LRCN_BENCH_DRYRUN_FAIL_RUNG"] = "plain:0"
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--dp-backend", "abi"], env)
+    assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "giving up" in r.stderr
+
+
+def test_selfcheck_violation_on_the_last_rung_is_reported_not_fatal():
+    env = _env()
+    env["LRCN_BENCH_RUNGS_ONLY"] = "plain"
+    env["LRCN_BENCH_DRYRUN_BAD_SELFCHECK"] = "plain"
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"], env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _one_line(r.stdout)
+    assert d["rccl"]["mode"] == "plain" and "params" in d["rccl"]["selfcheck"]["violations"]
+    assert d["rccl"]["selfcheck"]["params_identical_after_last_step"] is False
 
 
 def test_parent_never_imports_torch():

@@ -82,7 +82,7 @@ BENCH_ROUTES = "conv64-fused11,conv64,8p:2," + ",".join(["8p:0"] * 9)
 @pytest.mark.parametrize("N,cap", [(256, 224), (256, 0), (32, 224), (34, 64)])  # 34 images, cap 64: persistent walks that end on a partial row tile
 def test_full_vgg_bf16_bench_batch_nonzero_biases_vs_oracle(biased_vgg, N, cap):
     # the bench's VGG forward: N = 256 crops, capped persistent grids (dp.py sets 224), conv1_1 bias as the fused kernel's accumulator
-    # input, fc6 / fc7 biases through the split-K reduce; rows {0, N-1} against the oracle's fp32 stack
+    # input, fc6 / fc7 biases through the split-K reduce; sampled images against the oracle's fp32 stack
     w, host = biased_vgg
     g = torch.Generator(device="cuda")
     g.manual_seed(1234)
@@ -94,14 +94,23 @@ def test_full_vgg_bf16_bench_batch_nonzero_biases_vs_oracle(biased_vgg, N, cap):
     routes = L.debug_route(ctx, 1)
     if N == 256:
         assert routes.startswith(BENCH_ROUTES + ",8p-splitk:"), routes
-    pick = [0, N - 1]
+    # N = 256 (round 5): EIGHT oracle-checked images, chosen where the persistent walks of the capped grids change hands.
+    # At 256 images a layer with P output pixels per image has exactly P row tiles of 256 rows (x Cout / 256 column tiles), and workgroup w
+    # of a grid of G walks tiles w, w + G, ...: conv3_x (P = 3136, G = 224) starts its second round in image 18, conv4_x (P = 784, two
+    # column tiles) in image 36, conv5_x (P = 196, 392 tiles on 196 workgroups) ends its first round with image 127 and starts the second
+    # with image 128; images 0 / 255 hold the first tile of the first walk and the last tile of the last one; 1 and 254 their neighbours.
+    # fc6's split-K seams lie in K (the 25088 features), so every one of these rows crosses all of them.
+    pick = [0, 1, 18, 36, 127, 128, 254, 255] if N == 256 else [0, N - 1]
     x = orc.preprocess_u8(imgs[pick].cpu().numpy(), np.array(L.VGG_MEAN, np.float32))
     ref = orc.vgg_forward(host[0], host[1], host[2], host[3], x)
     assert np.isfinite(got).all()
-    err = rel_max_err(got[pick], ref)
-    cos = float((got[pick] * ref).sum() / (np.linalg.norm(got[pick]) * np.linalg.norm(ref)))
-    print("N=%d cap=%d routes=%s rel_max_err=%.4g cos=%.6f" % (N, cap, routes, err, cos))
-    assert err <= 3e-2 and cos > 0.999
+    worst, worst_cos = 0.0, 1.0
+    for i, n in enumerate(pick):   # per image: a wrong image cannot hide behind seven right ones
+        err = rel_max_err(got[n], ref[i])
+        cos = float((got[n] * ref[i]).sum() / (np.linalg.norm(got[n]) * np.linalg.norm(ref[i])))
+        worst, worst_cos = max(worst, err), min(worst_cos, cos)
+        assert err <= 3e-2 and cos > 0.999, (n, err, cos)
+    print("N=%d cap=%d routes=%s images %s: worst rel_max_err=%.4g min cos=%.6f" % (N, cap, routes, pick, worst, worst_cos))
     ctx.close()
 
 
