@@ -108,6 +108,29 @@ def cpu_baseline(vgg_w, E, H, V, T, rng, n_layers=2):
                   "ref_grads": g}
 
 
+PEAK_HBM_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+PEAK_PCIE_GBS = 64.0      # PCIe Gen5 x16, one direction
+
+
+def sub_reports(segs, n_steps):
+    """lrcn_profile_segment's accumulators -> roofline.sub: per HBM-bound segment of SURVEY 8(d) the achieved GB/s on its ALGORITHMIC bytes
+    (28 B/param for update!, one read of the recurrent weight block per timestep, (T+1) B E elements for the embedding gather, its dual's
+    rows in + dense gradient out, 1 B + one element per pixel value for the preprocessing pass, the crops' bytes for the upload), the
+    bytes and milliseconds per training step, and the fraction of the peak that bounds it (HBM 8 TB/s; the upload: PCIe Gen5 x16)."""
+    names = {"update": "adam", "rec_fwd": "recurrence_weight_stream_fwd", "rec_bwd": "recurrence_weight_stream_bwd", "embed_gather": "embed_gather",
+             "embed_grad": "embed_scatter", "preprocess": "preprocess", "upload": "upload"}
+    out = {"measured_on": "%d extra steps after the timed region with lrcn_profile(ctx, 2): HIP-event pairs on the launching stream around "
+                          "each segment; bytes are algorithmic (SURVEY 8d), not PMC traffic" % n_steps}
+    for k, (ms, n, by) in segs.items():
+        if n == 0 or ms <= 0:
+            continue
+        peak = PEAK_PCIE_GBS if k == "upload" else PEAK_HBM_GBS
+        gbs = by / ms / 1e6
+        out[names[k]] = {"GB/s": round(gbs, 1), "frac_of_peak": round(gbs / peak, 4), "peak_GB/s": peak, "ms_per_step": round(ms / n_steps, 4),
+                         "algorithmic_MB_per_step": round(by / n_steps / 1e6, 3), "brackets": int(n)}
+    return out
+
+
 def parity_spot_check(ctx, L, sample, batch_imgs, dtype="bf16"):
     """The cpu_baseline sample through the HIP path of THIS context: the 4 crops replace the first rows of one of the
     benchmark's own image batches, so the VGG forward runs at the benchmark's batch size with the benchmark's kernels and
@@ -474,6 +497,17 @@ def rank_main(a, world, rank, local_rank):
     _lib.check(ctx._h, _lib.lib().lrcn_profile_get(ctx._h, C.byref(conv_ms), C.byref(conv_n)))
     _lib.check(ctx._h, _lib.lib().lrcn_profile(ctx._h, 0))
     loss = trainer.loss_value()
+    # SURVEY 8(d)'s HBM-bound sub-reports, from a SEPARATE untimed pass of the same pipeline (the event pairs of lrcn_profile level 2 sit
+    # between dependent launches and would cost the timed step a few microseconds each): rank 0 of a one-rank job only
+    sub = None
+    if world == 1 and os.environ.get("LRCN_BENCH_SUBREPORTS", "1")[:1] != "0":
+        n_sub = 2 * max(m_chunk, 4)
+        L.profile(ctx, 2)
+        run(n_sub)
+        torch.cuda.synchronize()
+        sub = sub_reports(L.profile_segments(ctx), n_sub)
+        L.profile(ctx, 0)
+        torch.cuda.synchronize()
     tt = torch.tensor([dt_s], device="cuda", dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -523,7 +557,7 @@ def rank_main(a, world, rank, local_rank):
                          "traffic": traffic, "traffic_source": traffic_note,
                          "kernel": "conv64f_kernel (conv1_1+conv1_2 fused) + conv64_kernel (conv2_1) + gemm8p_kernel<*,CONV3,*> (conv2_2..conv5_3): 12 launches/step"
                                    if a.dtype == "bf16" else "gemm_glds_kernel<float,*,CONV3,*> v_mfma_f32_32x32x2_f32 (conv1_2..conv5_3)",
-                         "avg_launch_ms": 1e3 * avg_launch_s, "flops_per_launch": flops_per_launch},
+                         "avg_launch_ms": 1e3 * avg_launch_s, "flops_per_launch": flops_per_launch, "sub": sub},
         }
         if a.emulate_world > 1:
             out["config"]["emulate_world"] = a.emulate_world

@@ -83,9 +83,10 @@ int lrcn_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
 int lrcn_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
 const char *lrcn_version(void);
 /* ABI revision of this header.  It changes whenever a struct layout or an existing signature changes (lrcn_config gained its trailing
- * n_layers field at revision 2; revision 3 added the entry points marked "rev 3", revision 4 those marked "rev 4").  A binding compiled
+ * n_layers field at revision 2; revision 3 added the entry points marked "rev 3", revision 4 those marked "rev 4", revision 5 those marked
+ * "rev 5": lrcn_avg_loss_batch, lrcn_profile_segment).  A binding compiled
  * against another revision must refuse to run: lrcn_create reads sizeof(lrcn_config) bytes of the caller's struct. */
-#define LRCN_ABI_VERSION 4
+#define LRCN_ABI_VERSION 5
 int lrcn_abi_version(void);
 /* Options (rev 3).  Returns LRCN_EINVAL for an unknown option or a value outside its range.
  *   LRCN_OPT_FUSED_UPDATE (0 | 1, default 0): lrcn_train_step / lrcn_train_step_dp write the NEXT step's K-contiguous shadow weights
@@ -139,6 +140,13 @@ int lrcn_loss(lrcn_ctx *ctx, const float *const params[9], const float *feats, c
 /* lossgradient = grad(loss) (lrcn.jl:583): as lrcn_loss, plus d loss / d params into grads[9] (overwritten). */
 int lrcn_loss_grad(lrcn_ctx *ctx, const float *const params[9], const float *feats, const int32_t *tokens, int T,
                    int B, int norm_B, const lrcn_dropout *drop, float *const grads[9], double *loss_host);
+
+/* The body of average_loss's batch loop (lrcn.jl:452-475; rev 5 -- the entry point SURVEY 8(b) lists by this name): the forward pass of
+ * one batch with pdrop = 0, its loss divided by the batch's OWN size (average_loss takes the batch size from the data, lrcn.jl:412, not
+ * from the global `batchsize`): -sum logp / (B*(T+1)) into *loss_host.  Identical to lrcn_loss(..., norm_B = B, drop = NULL, ...); the
+ * host averages the per-batch values over the split (train.py, lrcn.jl:477-485). */
+int lrcn_avg_loss_batch(lrcn_ctx *ctx, const float *const params[9], const float *feats, const int32_t *tokens, int T, int B,
+                        double *loss_host);
 
 /* Gradient-ready events (new: lets a data-parallel host start the all-reduce of a gradient group while lossgradient's
  * backward is still running).  lrcn_loss_grad finalises the nine gradients in this order of GROUPS:
@@ -318,6 +326,21 @@ int lrcn_conv3x3_fp8(lrcn_ctx *ctx, const float *x, int W, int H, int Cin, int N
  * lrcn_profile_get synchronises and returns the accumulated milliseconds and launch count since lrcn_profile(ctx,1). */
 int lrcn_profile(lrcn_ctx *ctx, int enable);
 int lrcn_profile_get(lrcn_ctx *ctx, double *conv_ms, int64_t *conv_launches);
+/* Segment timing for the HBM-bound sub-reports of SURVEY 8(d) (rev 5).  lrcn_profile(ctx, 2) = as 1, and additionally a pair of HIP
+ * events -- on the stream the work is launched on -- around each of these segments of every call, with the segment's ALGORITHMIC bytes
+ * (SURVEY 8d's per-unit figures x the units processed) summed beside the time:
+ *   LRCN_SEG_UPDATE        update! (lrcn.jl:394): 28 B per parameter (w, m, v read + written, g read)
+ *   LRCN_SEG_REC_FWD / _BWD  the per-timestep recurrence launches of one layer pass (lrcn.jl:529 and its dual): one read of the
+ *                          recurrent weight block (4H x H elements) per timestep
+ *   LRCN_SEG_EMBED_GATHER  param[end-2][idx,:] (lrcn.jl:556, 569): (T+1) B rows of E elements read and written
+ *   LRCN_SEG_EMBED_GRAD    its dual: (T+1) B rows of E f32 in, the dense V x E f32 gradient out
+ *   LRCN_SEG_PREPROCESS    read_image_data's arithmetic (lrcn.jl:768-772): 1 B in + 1 activation element out per pixel value
+ *   LRCN_SEG_UPLOAD        the per-batch H2D copy of train1 (lrcn.jl:369-376): N x 150528 bytes (PCIe, not HBM)
+ * The event records sit between dependent launches and cost a few microseconds each: level 2 is for a separate, untimed pass.
+ * lrcn_profile_segment synchronises the device and returns what accumulated since lrcn_profile(ctx, 2). */
+enum { LRCN_SEG_UPDATE = 0, LRCN_SEG_REC_FWD = 1, LRCN_SEG_REC_BWD = 2, LRCN_SEG_EMBED_GATHER = 3, LRCN_SEG_EMBED_GRAD = 4,
+       LRCN_SEG_PREPROCESS = 5, LRCN_SEG_UPLOAD = 6, LRCN_SEG_COUNT = 7 };
+int lrcn_profile_segment(lrcn_ctx *ctx, int segment, double *ms, int64_t *brackets, double *algorithmic_bytes);
 /* Diagnostic: average milliseconds of one bf16 3x3 convolution layer (N images of S x S x Cin -> Cout, optional fused
  * pool) on random data, `iters` back-to-back launches timed with HIP events.  Kernel-development aid, not the product path. */
 int lrcn_bench_conv(lrcn_ctx *ctx, int N, int S, int Cin, int Cout, int pool, int iters, double *ms_out);

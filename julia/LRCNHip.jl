@@ -76,6 +76,15 @@ function loss(ctx, param, input, tokens, T, B; batchsize=B, pdrop=0.0, seed=0)  
     out[]
 end
 
+# the body of average_loss's batch loop: pdrop 0, divided by the batch's own size                lrcn.jl:452-475 (batch size from the data, :412)
+function avg_loss_batch(ctx, param, input, tokens, T, B)
+    out = Ref{Cdouble}(0)
+    check(ctx, ccall((:lrcn_avg_loss_batch, lib), Cint,
+        (Ptr{Cvoid}, Ptr{Ptr{Cfloat}}, Ptr{Cfloat}, Ptr{Int32}, Cint, Cint, Ref{Cdouble}),
+        ctx.h, ptrs(param), pointer(input), pointer(tokens), T, B, out))
+    out[]
+end
+
 function lossgradient(ctx, param, input, tokens, T, B, grads; batchsize=B, pdrop=0.0, seed=0)  # lrcn.jl:583
     d = Ref(Dropout(pdrop, seed, C_NULL, C_NULL))
     check(ctx, ccall((:lrcn_loss_grad, lib), Cint,

@@ -13,8 +13,9 @@ LIB_PATH = os.environ.get("LRCN_HIP_LIB") or os.path.join(CSRC, "liblrcn_hip.so"
 HEADER = os.path.normpath(os.path.join(HERE, "..", "include", "lrcn.h"))
 
 LRCN_F32, LRCN_BF16, LRCN_FP8 = 0, 1, 2
-LRCN_ABI_VERSION = 4   # include/lrcn.h: the revision this binding's struct layouts and signatures were written against
+LRCN_ABI_VERSION = 5   # include/lrcn.h: the revision this binding's struct layouts and signatures were written against
 LRCN_OPT_FUSED_UPDATE, LRCN_OPT_DETERMINISTIC, LRCN_OPT_CONV_CHUNK_BYTES = 1, 2, 3
+SEGMENTS = ("update", "rec_fwd", "rec_bwd", "embed_gather", "embed_grad", "preprocess", "upload")   # LRCN_SEG_* of include/lrcn.h, in order
 EOS, BOS, UNK = 0, 1, 2
 CNNOUT = 4096
 MAX_T = 28
@@ -65,6 +66,7 @@ SIGNATURES = {
                             C.POINTER(C.c_double)]),
     "lrcn_loss_grad": (C.c_int, [C.c_void_p, P9, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(Dropout),
                                  P9, C.POINTER(C.c_double)]),
+    "lrcn_avg_loss_batch": (C.c_int, [C.c_void_p, P9, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "lrcn_grad_group_wait": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "lrcn_last_loss": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "lrcn_forward_logits": (C.c_int, [C.c_void_p, P9, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
@@ -106,6 +108,7 @@ SIGNATURES = {
     "lrcn_upload_wait": (C.c_int, [C.c_void_p]),
     "lrcn_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "lrcn_profile_get": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "lrcn_profile_segment": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "lrcn_debug_stamps": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int64]),
     "lrcn_bench_conv": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "lrcn_bench_gemm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),

@@ -123,6 +123,14 @@ struct lrcn_ctx {
     size_t prof_used = 0;
     double prof_ms = 0.0;
     int64_t prof_launches = 0;
+    // level 2 (lrcn_profile(ctx, 2)): event pairs around the HBM-bound segments of SURVEY 8(d), see lrcn_profile_segment
+    int prof_level = 0;
+    struct SegProf {
+        std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+        size_t used = 0;
+        double ms = 0.0, bytes = 0.0;
+        int64_t n = 0;
+    } seg[LRCN_SEG_COUNT];
     std::string vgg_routes;  // kernel family per layer of the most recent VGG forward (lrcn_debug_route)
     // image front end: the full averageImage (lrcn_set_average_image), per-batch image descriptors, float scratch of the unfused path
     float *avg_img = nullptr;
@@ -450,6 +458,29 @@ void fused_update_done(lrcn_ctx *c, float *const p[9]) {  // every tensor's Adam
 // pre-activations on exit; acts/Call/Hall receive the per-step results.  (lrcn.jl:528-538, time-batched)
 // nothing runs beside the LSTM step: no VGG forward with capped grids on another stream (what the two-stream trainer sets up)
 bool lstm_alone(const lrcn_ctx *c) { return !(c->vgg_wg_cap >= 8 && c->vgg_loaded); }
+
+// A pair of HIP events around one segment of a call, on the stream its work is launched on (lrcn_profile level 2; a no-op otherwise).
+struct SegScope {
+    lrcn_ctx *c;
+    hipStream_t st;
+    std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
+    SegScope(lrcn_ctx *c_, int seg, hipStream_t st_, double bytes) : c(c_), st(st_) {
+        if (c->prof_level < 2) return;
+        auto &sp = c->seg[seg];
+        if (sp.used == sp.ev.size()) {
+            std::pair<hipEvent_t, hipEvent_t> e;
+            if (hipEventCreate(&e.first) != hipSuccess || hipEventCreate(&e.second) != hipSuccess) return;
+            sp.ev.push_back(e);
+        }
+        ev = &sp.ev[sp.used++];
+        sp.bytes += bytes;
+        sp.n += 1;
+        (void)hipEventRecord(ev->first, st);
+    }
+    ~SegScope() {
+        if (ev) (void)hipEventRecord(ev->second, st);
+    }
+};
 bool lstm_fused_on(lrcn_ctx *c, int B, int H, int64_t ldH, int64_t ld4H) {
     const char *k = getenv("LRCN_LSTM_FUSED");  // LRCN_LSTM_FUSED=0: GEMM + cell as separate launches at every batch size
     const char *mb = getenv("LRCN_LSTM_FUSED_MAXB");  // kernel-development knob: largest batch routed to the fused step kernels
@@ -470,6 +501,7 @@ int lstm_layer_fwd(lrcn_ctx *c, int S, int B, int H, int64_t ldH, int64_t ld4H, 
     const int dt = c->dt;
     const bool fused = lstm_fused_on(c, B, H, ldH, ld4H);
     const bool epi = !fused && Wh_gi && lstm_epi_on(c, B);
+    SegScope seg(c, LRCN_SEG_REC_FWD, c->stream, (double)(S - 1) * 4.0 * H * H * c->esz);  // one read of Wh (4H x H) per recurrent step
     for (int s = 0; s < S; ++s) {
         float *G = Gx + (int64_t)s * B * 4 * H;
         if (s > 0 && epi) {
@@ -513,6 +545,7 @@ int lstm_layer_fwd(lrcn_ctx *c, int S, int B, int H, int64_t ldH, int64_t ld4H, 
 int lstm_layer_bwd(lrcn_ctx *c, int S, int B, int H, int64_t ld4H, const void *acts, const float *Call, const float *dHall,
                    const void *WhT, void *dZ) {
     const int dt = c->dt;
+    SegScope seg(c, LRCN_SEG_REC_BWD, c->stream, (double)(S - 1) * 4.0 * H * H * c->esz);
     if (!lstm_fused_on(c, B, H, round_up64(H, 64), ld4H) && lstm_epi_on(c, B)) {
         // cell backward of the last step, then one launch per step: dh_rec = dZ[s] Wh with the cell backward of s-1 in its epilogue
         k_lstm_bwd(c->stream, dt, boff(acts, (int64_t)(S - 1) * B * ld4H, c->esz), ld4H, S > 1 ? Call + (int64_t)(S - 2) * B * H : nullptr,
@@ -601,7 +634,10 @@ int loss_impl(lrcn_ctx *c, const float *const p[9], const float *feats, const in
     GEMM(c, dt, c->F, LRCN_CNNOUT, c->Wcd, LRCN_CNNOUT, c->xcnn, c->ldh, B, h, LRCN_CNNOUT, nullptr, true);
     // embeddings of [bos, tokens...] with the :542 dropout.  LRCN-1f: the LSTM input is dropout(hcat(embedding, x_cnn)) -- the
     // gather fills columns [0, E), the concat kernel appends x_cnn and applies the one mask over all E + h columns
-    k_embed_gather(st, dt, c->WeT, c->ldE, c->tok_in, S, B, E, two ? d1 : none, c->Xemb, c->ldX1);
+    {
+        SegScope seg(c, LRCN_SEG_EMBED_GATHER, st, 2.0 * M * E * es);  // (T+1) B rows of E elements read and written
+        k_embed_gather(st, dt, c->WeT, c->ldE, c->tok_in, S, B, E, two ? d1 : none, c->Xemb, c->ldX1);
+    }
     if (!two) k_concat_x2(st, dt, c->Xemb, c->ldX1, c->xcnn, c->ldh, S, B, E, h, d1);
     // LSTM 1
     GEMM(c, dt, c->Xemb, c->ldX1, c->W1x, c->ldX1, c->G1, 4 * H1, M, 4 * H1, X1, p[1], true);
@@ -741,6 +777,7 @@ int loss_impl(lrcn_ctx *c, const float *const p[9], const float *feats, const in
             GEMM(c, dt, c->dxcT, ldB, c->FT, ldB, grads[5], LRCN_CNNOUT, h, LRCN_CNNOUT, B, nullptr, true, false, false, false, par);
             HIPCHK(c, hipEventRecord(c->grad_ev[2], sw));  // group 2: Wcnn
         }
+        SegScope seg_eg(c, LRCN_SEG_EMBED_GRAD, st, 4.0 * M * E + 4.0 * (double)V * E);  // (T+1) B rows of E f32 in, dense V x E f32 out
         if (c->emb_rows_out) {
             // data-parallel host with the sparse exchange on: hand out this rank's rows and ids; grads[6] is NOT written by this call
             if (M > c->emb_rows_cap) FAIL(c, LRCN_EINVAL, "embedding-row buffer holds %d rows, this call has %d", c->emb_rows_cap, M);
@@ -948,6 +985,11 @@ void lrcn_destroy(lrcn_ctx *c) {
     for (auto &e : c->ar_done)
         if (e) (void)hipEventDestroy(e);
     if (c->comm_stream && c->comm_stream_owned) (void)hipStreamDestroy(c->comm_stream);
+    for (auto &sp : c->seg)
+        for (auto &e : sp.ev) {
+            (void)hipEventDestroy(e.first);
+            (void)hipEventDestroy(e.second);
+        }
     for (auto &e : c->prof_ev) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
@@ -1188,6 +1230,13 @@ int lrcn_adam_update(lrcn_ctx *c, float *const p[9], const float *const g[9], fl
     DeviceGuard dg(c);
     if (!c || !p || !g || !m || !v || step < 1) return LRCN_EINVAL;
     c->fused_groups = 0;  // the whole-model update supersedes any per-group sequence left unfinished (an error between two groups)
+    int64_t nparam = 0;
+    {
+        int64_t szp[9];
+        ctx_sizes(c, szp);
+        for (int k = 0; k < 9; ++k) nparam += szp[k];
+    }
+    SegScope seg(c, LRCN_SEG_UPDATE, c->stream, 28.0 * (double)nparam);  // w, m, v read + written, g read: 28 B per parameter
     if (c->opt_fused) {  // LRCN_OPT_FUSED_UPDATE: the same update, and the next step's shadow weights in the same pass
         c->shadow_valid = false;
         int r = adam_fused(c, p, g, m, v, -1, step, lr, b1, b2, eps, c->stream);
@@ -1217,6 +1266,10 @@ int lrcn_adam_update_group(lrcn_ctx *c, float *const p[9], const float *const g[
     if (!c || !p || !g || !m || !v || step < 1) return LRCN_EINVAL;
     if (group < 0 || group >= LRCN_GRAD_GROUPS) FAIL(c, LRCN_EINVAL, "group=%d outside [0,%d)", group, LRCN_GRAD_GROUPS);
     static const int kGroup[LRCN_GRAD_GROUPS][2] = {{7, 8}, {2, 3}, {4, 5}, {0, 1}, {6, 6}};  // order of the grad_ev records
+    int64_t szg[9];
+    ctx_sizes(c, szg);
+    SegScope seg(c, LRCN_SEG_UPDATE, stream ? reinterpret_cast<hipStream_t>(stream) : c->stream,
+                 28.0 * (double)(szg[kGroup[group][0]] + (kGroup[group][1] != kGroup[group][0] ? szg[kGroup[group][1]] : 0)));
     if (c->opt_fused) {
         // fused with the shadow pass; the written set becomes current once all five groups of this step have been issued (they are
         // issued in any order, each exactly once per step, with the same `step`)
@@ -1261,6 +1314,7 @@ int lrcn_adam_update_flat(lrcn_ctx *c, float *w, const float *g, float *m, float
     if (n == 0) return LRCN_OK;
     if (!w || !g || !m || !v) return LRCN_EINVAL;
     c->shadow_valid = false;  // some parameter changed: the next call makes its shadow weights afresh
+    SegScope seg(c, LRCN_SEG_UPDATE, stream ? reinterpret_cast<hipStream_t>(stream) : c->stream, 28.0 * (double)n);
     AdamTensors t{};
     t.w[0] = w; t.g[0] = g; t.m[0] = m; t.v[0] = v; t.n[0] = n;
     k_adam(stream ? reinterpret_cast<hipStream_t>(stream) : c->stream, t, step, lr, b1, b2, eps);
@@ -1887,6 +1941,7 @@ int vgg_body(lrcn_ctx *c, int N, const void *src, bool src_u8, const float *mean
     };
     if (fuse11) {
         // read_image_data's arithmetic as an elementwise pass (38 MB -> 77 MB at N = 256); conv1_1 itself runs inside conv1_2's launch
+        SegScope seg_pp(c, LRCN_SEG_PREPROCESS, c->stream, 3.0 * N * 224 * 224 * 3);  // 1 B in, one bf16 out per pixel value
         k_img_u8_to_bf16(c->stream, reinterpret_cast<const uint8_t *>(src), (int64_t)N * 224 * 224 * 3, m0, m1, m2, avg, 224, c->img16);
     } else if (vdt == GEMM_T_BF16) {
         // conv1_1 fused with the preprocessing arithmetic (conv11.hip): HBM-bound, no im2col in memory
@@ -2089,10 +2144,38 @@ int lrcn_profile(lrcn_ctx *c, int enable) {
     DeviceGuard dg(c);
     if (!c) return LRCN_EINVAL;
     c->prof = enable != 0;
+    c->prof_level = enable;
     c->prof_used = 0;
     c->prof_ms = 0.0;
     c->prof_launches = 0;
+    for (auto &sp : c->seg) {
+        sp.used = 0;
+        sp.ms = sp.bytes = 0.0;
+        sp.n = 0;
+    }
     return LRCN_OK;
+}
+
+int lrcn_profile_segment(lrcn_ctx *c, int segment, double *ms, int64_t *brackets, double *bytes) {
+    DeviceGuard dg(c);
+    if (!c || !ms || !brackets || !bytes || segment < 0 || segment >= LRCN_SEG_COUNT) return LRCN_EINVAL;
+    HIPCHK(c, hipDeviceSynchronize());  // the segments live on several streams (context, copy, caller-given update streams)
+    auto &sp = c->seg[segment];
+    for (size_t i = 0; i < sp.used; ++i) {
+        float t = 0.0f;
+        HIPCHK(c, hipEventElapsedTime(&t, sp.ev[i].first, sp.ev[i].second));
+        sp.ms += t;
+    }
+    sp.used = 0;
+    *ms = sp.ms;
+    *brackets = sp.n;
+    *bytes = sp.bytes;
+    return LRCN_OK;
+}
+
+int lrcn_avg_loss_batch(lrcn_ctx *c, const float *const p[9], const float *feats, const int32_t *tokens, int T, int B, double *loss_host) {
+    // average_loss's loop body (lrcn.jl:452-475): pdrop 0, normalised by the batch's own size (lrcn.jl:412)
+    return lrcn_loss(c, p, feats, tokens, T, B, B, nullptr, loss_host);
 }
 
 int lrcn_profile_get(lrcn_ctx *c, double *conv_ms, int64_t *conv_launches) {
@@ -2224,7 +2307,10 @@ int lrcn_upload_crops(lrcn_ctx *c, const uint8_t *host_u8, int N, const uint8_t 
              lrcn_ctx::kStage, lrcn_ctx::kStage);
     // the forward that last read this buffer: normally long finished; otherwise wait for it HERE, on the host (see lrcn_ctx::kStage)
     if (c->stage_read[j] && hipEventQuery(c->rd_done[j]) != hipSuccess) HIPCHK(c, hipEventSynchronize(c->rd_done[j]));
-    HIPCHK(c, hipMemcpyAsync(c->stage[j], host_u8, per * (size_t)N, hipMemcpyHostToDevice, c->copy_stream));
+    {
+        SegScope seg_up(c, LRCN_SEG_UPLOAD, c->copy_stream, (double)per * N);
+        HIPCHK(c, hipMemcpyAsync(c->stage[j], host_u8, per * (size_t)N, hipMemcpyHostToDevice, c->copy_stream));
+    }
     HIPCHK(c, hipEventRecord(c->up_done[j], c->copy_stream));
     c->stage_full[j] = true;
     c->stage_next = (j + 1) % lrcn_ctx::kStage;

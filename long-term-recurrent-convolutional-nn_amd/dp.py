@@ -121,7 +121,7 @@ class HipOps:
 
     def loss(self, param, feats, tokens):
         """Forward-only loss of one batch (average_loss's body, lrcn.jl:452-475): pdrop 0, normalised by the batch's own size."""
-        return L.loss(self.ctx, param, feats, tokens)
+        return L.avg_loss_batch(self.ctx, param, feats, tokens)
 
     def vgg_blocks(self, img_u8, rows, feats=None, normalize=False):
         """One forward for the crops of several batches -> list of rows x 4096 feature blocks (lrcn_vgg_forward_u8_blocks)."""

@@ -387,9 +387,33 @@ def average_loss(ctx, param, batches):
         if T > 28:
             continue
         n = B * (T + 1)
-        total += loss(ctx, param, feats, tokens) * n
+        total += avg_loss_batch(ctx, param, feats, tokens) * n
         count += n
     return total / max(count, 1)
+
+
+def avg_loss_batch(ctx, param, feats, tokens):
+    """The body of average_loss's batch loop (lrcn.jl:452-475): pdrop 0, the loss divided by the batch's own size (lrcn_avg_loss_batch)."""
+    tok = _tokens(tokens, feats.device)
+    T, B = tok.shape
+    out = C.c_double()
+    ctx._call("lrcn_avg_loss_batch", _p9(param), _ptr(feats), C.c_void_p(tok.data_ptr()), T, B, C.byref(out))
+    return out.value
+
+
+def profile(ctx, level):
+    """lrcn_profile: 0 off, 1 the convolution launches of every VGG forward, 2 also the HBM-bound segments (lrcn_profile_segment)."""
+    ctx._call("lrcn_profile", int(level))
+
+
+def profile_segments(ctx):
+    """-> {segment: (milliseconds, brackets, algorithmic bytes)} accumulated since profile(ctx, 2) (synchronises the device)."""
+    out = {}
+    for i, name in enumerate(_lib.SEGMENTS):
+        ms, n, by = C.c_double(), C.c_int64(), C.c_double()
+        ctx._call("lrcn_profile_segment", i, C.byref(ms), C.byref(n), C.byref(by))
+        out[name] = (ms.value, n.value, by.value)
+    return out
 
 
 def beam_search(ctx, param, feat, beam_width, nword):

@@ -177,6 +177,10 @@ int lrcn_loss_grad(lrcn_ctx *c, const float *const p[9], const float *feats, con
     if (!c || !p || !feats || (!tokens && T > 0) || !grads) return LRCN_EINVAL;
     return loss_common(c, p, feats, tokens, T, B, norm_B, drop, grads, loss_host);
 }
+int lrcn_avg_loss_batch(lrcn_ctx *c, const float *const p[9], const float *feats, const int32_t *tokens, int T, int B, double *loss_host) {
+    if (!c || !p || !feats || (!tokens && T > 0)) return LRCN_EINVAL;
+    return loss_common(c, p, feats, tokens, T, B, B, NULL, NULL, loss_host); /* average_loss's body: pdrop 0, the batch's own size (lrcn.jl:412, 452-475) */
+}
 int lrcn_grad_group_wait(lrcn_ctx *c, int group, void *stream) {
     (void)stream;
     return (c && group >= 0 && group < LRCN_GRAD_GROUPS) ? LRCN_OK : LRCN_EINVAL; /* synchronous on the host: always ready */
@@ -470,6 +474,11 @@ int lrcn_conv3x3_fp8(lrcn_ctx *c, const float *x, int W, int H, int Cin, int N, 
     FAIL(c, LRCN_ESTATE, "the e4m3 convolution stack exists on the GPU only");
 }
 int lrcn_profile(lrcn_ctx *c, int enable) { (void)enable; return c ? LRCN_OK : LRCN_EINVAL; }
+int lrcn_profile_segment(lrcn_ctx *c, int segment, double *ms, int64_t *n, double *bytes) {
+    if (!c || !ms || !n || !bytes || segment < 0 || segment >= LRCN_SEG_COUNT) return LRCN_EINVAL;
+    *ms = 0.0; *n = 0; *bytes = 0.0; /* the host twin is synchronous and unprofiled */
+    return LRCN_OK;
+}
 int lrcn_profile_get(lrcn_ctx *c, double *ms, int64_t *n) {
     if (!c || !ms || !n) return LRCN_EINVAL;
     *ms = 0.0; *n = 0;

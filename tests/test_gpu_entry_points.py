@@ -107,3 +107,33 @@ def test_out_of_range_token_ids_are_reported():
         ctx.sync()
     ctx.sync()
     ctx.close()
+
+
+def test_profile_segments_bracket_the_hbm_bound_parts_of_a_step():
+    # lrcn_profile(ctx, 2) + lrcn_profile_segment (rev 5): after three train steps every LSTM-side segment has three brackets (the
+    # recurrence: one per layer pass), a positive time, and exactly the algorithmic bytes include/lrcn.h states for it
+    E = H = 64
+    V, B, T = 301, 8, 5
+    rng = np.random.default_rng(2)
+    ctx = L.Context(E, H, H, V, max_B=B, max_T=T, lstm_dtype=lrcn_amd.LRCN_BF16)
+    param = L.initweights(ctx, seed=3)
+    optim = L.initparams(param)
+    grads = [L.jl_empty(*t.shape) for t in param]
+    feats = L.to_jl((rng.standard_normal((B, 4096)) * 0.05).astype(np.float32))
+    tokens = rng.integers(0, V, size=(T, B)).astype(np.int32)
+    L.profile(ctx, 2)
+    for k in range(3):
+        L.train_step(ctx, param, optim, grads, feats, tokens, pdrop=0.4, seed=k)
+    seg = L.profile_segments(ctx)
+    nparam = sum(int(t.numel()) for t in param)
+    M = (T + 1) * B
+    want = {"update": (3, 3 * 28.0 * nparam), "rec_fwd": (6, 6 * T * 4.0 * H * H * 2), "rec_bwd": (6, 6 * T * 4.0 * H * H * 2),
+            "embed_gather": (3, 3 * 2.0 * M * E * 2), "embed_grad": (3, 3 * (4.0 * M * E + 4.0 * V * E))}
+    for name, (n, by) in want.items():
+        ms, got_n, got_by = seg[name]
+        assert got_n == n and ms > 0 and got_by == by, (name, seg[name], n, by)
+    assert seg["preprocess"][1] == 0 and seg["upload"][1] == 0   # no VGG forward, no upload in these steps
+    L.profile(ctx, 0)
+    L.train_step(ctx, param, optim, grads, feats, tokens, pdrop=0.4, seed=9)
+    assert all(v[1] == 0 for v in L.profile_segments(ctx).values())   # switching the level resets, level 0 records nothing
+    ctx.close()
