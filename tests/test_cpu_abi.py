@@ -76,6 +76,12 @@ def test_golden_loss_grads_and_adam_through_the_abi(lib, golden_dir, name):
             np.testing.assert_allclose(g, z["g_" + n], rtol=1e-4, atol=1e-7, err_msg=n)
     last = C.c_double()
     assert lib.lrcn_last_loss(ctx, C.byref(last)) == 0 and last.value == out.value
+    if d is None:
+        # the body of average_loss's batch loop under its own name (rev 5): pdrop 0, divided by the batch's OWN size (lrcn.jl:412, 452-475)
+        avg, own = C.c_double(), C.c_double()
+        assert lib.lrcn_avg_loss_batch(ctx, p9(param), fptr(feats), fptr(tokens), T, B, C.byref(avg)) == 0
+        assert lib.lrcn_loss(ctx, p9(param), fptr(feats), fptr(tokens), T, B, B, None, C.byref(own)) == 0
+        assert avg.value == own.value and abs(avg.value * B - float(z["loss"]) * int(z["norm_B"])) <= 1e-6 * abs(avg.value * B)
     # train1's loop body as one call, twice (the golden Adam trajectory)
     mom, var = [np.zeros_like(a) for a in param], [np.zeros_like(a) for a in param]
     for step, ref_loss in enumerate(z["adam_losses"], start=1):

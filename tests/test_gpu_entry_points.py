@@ -76,6 +76,7 @@ def test_average_loss_aggregation_vs_oracle():
         tokens = rng.integers(0, V, size=(T, B)).astype(np.int32)
         batches.append((L.to_jl(feats), tokens))
         tot += orc.loss(m, feats, tokens) * B * (T + 1)
+        assert L.avg_loss_batch(ctx, param, batches[-1][0], tokens) == L.loss(ctx, param, batches[-1][0], tokens)   # rev 5: = lrcn_loss(norm_B = B)
         cnt += B * (T + 1)
     # a 29-token batch is skipped by the reference; lrcn_loss itself refuses it (max_T = 28)
     long_tok = rng.integers(0, V, size=(29, 2)).astype(np.int32)
