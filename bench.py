@@ -41,10 +41,15 @@ def pmc_traffic(dtype, per_gpu_batch):
     inside the process, and a --pmc pass is its own run).  Only quoted for the configuration AND the kernel sources it was
     measured on: the file records the digest of csrc/ at measurement time; if the sources have changed since, traffic is null
     and the note says so.  -> (bytes per launch | None, note)"""
-    pdir = os.path.join(ROOT, "profiles")
-    files = sorted(f for f in os.listdir(pdir) if f.endswith(PMC_TRAFFIC_FILE)) if os.path.isdir(pdir) else []
     if dtype != "bf16" or per_gpu_batch != 256:
         return None, "no PMC pass for this configuration"
+    return pmc_traffic_file(PMC_TRAFFIC_FILE)
+
+
+def pmc_traffic_file(suffix):
+    """The newest profiles/*<suffix> whose csrc digest equals the current sources' -> (bytes per launch | None, note)."""
+    pdir = os.path.join(ROOT, "profiles")
+    files = sorted(f for f in os.listdir(pdir) if f.endswith(suffix)) if os.path.isdir(pdir) else []
     for f in reversed(files):
         try:
             d = json.load(open(os.path.join(pdir, f)))
@@ -52,7 +57,7 @@ def pmc_traffic(dtype, per_gpu_batch):
             continue
         if d.get("csrc_digest") == csrc_digest():
             return float(d["traffic_bytes_per_launch"]), "profiles/%s (csrc digest %s matches)" % (f, d["csrc_digest"])
-    return None, "stale: no profiles/*_%s was taken on the current kernel sources (digest %s)" % (PMC_TRAFFIC_FILE, csrc_digest())
+    return None, "stale: no profiles/*_%s was taken on the current kernel sources (digest %s)" % (suffix, csrc_digest())
 
 
 def cpu_baseline(vgg_w, E, H, V, T, rng, n_layers=2):
@@ -211,7 +216,11 @@ def parse_args(argv=None):
                          "try 'abi' under a watchdog, rerun with 'torch' if it fails")
     ap.add_argument("--shard-adam", action="store_true", default=os.environ.get("LRCN_DP_SHARD_ADAM", "0")[:1] == "1",
                     help="N > 1, torch backend: reduce-scatter -> Adam on 1/N of the flat parameter buffer -> all-gather instead of all-reduce -> replicated "
-                         "Adam (same wire bytes, 1/N of the update's HBM traffic per rank).  Opt-in: it has never met a second GPU")
+                         "Adam (same wire bytes, 1/N of the update's HBM traffic per rank).  Opt-in for real N > 1 jobs: it has never met a second GPU.  "
+                         "With --emulate-world N it is the DEFAULT since round 5 (the form an 8-GPU job should run once validated; 1.30 -> 1.25 ms at "
+                         "32 rows); --replicated-update selects the replicated form there")
+    ap.add_argument("--replicated-update", action="store_true", help="--emulate-world N: replicated update! (the whole Adam on this rank) instead of "
+                    "the sharded one")
     ap.add_argument("--spinup-ms", type=float, default=150.0,
                     help="set-up, before the W warm-up steps: keep the GPU busy with VGG forwards of the benchmark's own crops for this long.  "
                          "The chip needs ~100 ms of load after idle before its clocks settle (measured: steps 1..15 after idle run 7.5 -> 7.0 ms); "
@@ -387,9 +396,10 @@ def rank_main(a, world, rank, local_rank):
     param = L.initweights(ctx, seed=42)          # identical on every rank (same seed)
     optim = L.initparams(param)
     backend = a.dp_backend if a.dp_backend != "auto" else "torch"   # 'auto' is resolved by the ladder (supervise): the rung sets LRCN_DP_BACKEND
-    emu_shard = bool(a.shard_adam) and a.emulate_world > 1   # one process: rank 0's side of the sharded update, collectives stubbed by copies
+    # one process: rank 0's side of the sharded update, collectives stubbed by copies (the default form of an emulated rank since round 5)
+    emu_shard = a.emulate_world > 1 and not a.replicated_update and (bool(a.shard_adam) or os.environ.get("LRCN_DP_SHARD_ADAM", "1")[:1] != "0")
     trainer = dp.DataParallelTrainer(ctx, param, optim, Bg, world, rank, pdrop=a.pdrop, seed=7, backend=backend,
-                                     shard_adam=bool(a.shard_adam) and (world > 1 or emu_shard), vgg_chunk=m_chunk, rows=B,
+                                     shard_adam=(bool(a.shard_adam) and world > 1) or emu_shard, vgg_chunk=m_chunk, rows=B,
                                      emulate_shards=a.emulate_world if emu_shard else 0)
 
     # synthetic inputs: uint8 crops uniform seed 1234; Zipf(1.0) word ids >= 3, seed 7; one T per batch
@@ -582,6 +592,8 @@ def caption_main(a, argv):
     if a.gpus > 1 and os.environ.get("WORLD_SIZE") is None:
         return launch(a, argv)
     sys.argv = [os.path.join(ROOT, "tools", "caption_bench.py"), "--images", "1024", "--chunk", "1024", "--iters", str(max(2, a.steps // 10))]
+    if a.no_cpu_baseline or os.environ.get("LRCN_C5_LIGHT"):   # LRCN_C5_LIGHT=1: counter passes under rocprofv3 (no CPU leg, no fixture)
+        sys.argv += ["--no-cpu-baseline", "--no-fixture"]
     runpy.run_path(sys.argv[0], run_name="__main__")
     return 0
 

@@ -84,7 +84,7 @@ int lrcn_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
 const char *lrcn_version(void);
 /* ABI revision of this header.  It changes whenever a struct layout or an existing signature changes (lrcn_config gained its trailing
  * n_layers field at revision 2; revision 3 added the entry points marked "rev 3", revision 4 those marked "rev 4", revision 5 those marked
- * "rev 5": lrcn_avg_loss_batch, lrcn_profile_segment).  A binding compiled
+ * "rev 5": lrcn_avg_loss_batch, lrcn_profile_segment, lrcn_refresh_shadows_group).  A binding compiled
  * against another revision must refuse to run: lrcn_create reads sizeof(lrcn_config) bytes of the caller's struct. */
 #define LRCN_ABI_VERSION 5
 int lrcn_abi_version(void);
@@ -101,6 +101,13 @@ int lrcn_abi_version(void);
  *     whole images (the direct-to-LDS kernels address their input with 32-bit offsets). */
 enum { LRCN_OPT_FUSED_UPDATE = 1, LRCN_OPT_DETERMINISTIC = 2, LRCN_OPT_CONV_CHUNK_BYTES = 3 };
 int lrcn_set_option(lrcn_ctx *ctx, int option, int64_t value);
+/* Shadow weights of ONE gradient group (LRCN_GRAD_GROUPS order), made on `stream` from the caller's f32 parameters into the second shadow set
+ * (rev 5; needs LRCN_OPT_FUSED_UPDATE = 1): what a host that updates the parameters ITSELF per group -- the sharded update: reduce-scatter ->
+ * lrcn_adam_update_flat on its slice -> all-gather -- calls right after a group's all-gather, so that the shadow pass of the next step runs
+ * beside the rest of the backward pass instead of at the head of the next lrcn_loss_grad.  Once all five groups of a step have been
+ * refreshed the set becomes current, under the same contract as LRCN_OPT_FUSED_UPDATE (same nine pointers next call, no foreign writes).
+ * The caller orders `stream` after the writes of the group's parameters and the context's stream after `stream`. */
+int lrcn_refresh_shadows_group(lrcn_ctx *ctx, const float *const params[9], int group, void *stream);
 /* The caller wrote parameter arrays itself (loaded a checkpoint, clipped, ...): the next call makes its shadow weights afresh (rev 3). */
 int lrcn_params_touched(lrcn_ctx *ctx);
 

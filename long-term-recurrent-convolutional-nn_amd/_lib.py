@@ -66,6 +66,7 @@ SIGNATURES = {
                             C.POINTER(C.c_double)]),
     "lrcn_loss_grad": (C.c_int, [C.c_void_p, P9, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(Dropout),
                                  P9, C.POINTER(C.c_double)]),
+    "lrcn_refresh_shadows_group": (C.c_int, [C.c_void_p, P9, C.c_int, C.c_void_p]),
     "lrcn_avg_loss_batch": (C.c_int, [C.c_void_p, P9, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "lrcn_grad_group_wait": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "lrcn_last_loss": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),

@@ -49,6 +49,8 @@ struct GemmArgs {
     int wg_cap;             // > 0: at most this many workgroups (gemm_8p.hip / conv64.hip walk the tiles persistently)
     LstmEpi lstm;           // out_mode GEMM_OUT_LSTM_FWD / _BWD only
     int cfg_pref;           // gemm_8p.hip: 0 = the dispatcher's tile menu, 2 = prefer the 256 x 128 tile (set by the bg_cus route)
+    int free_cus;           // > 0 (rows per GPU below the bg_cus route's threshold): this many CUs are free beside the capped convolution grids --
+                            // the split-K planner cuts K so that tiles x slices fit them in ONE round (round 5)
     int bg_cus;             // > 0: this contraction runs BESIDE the capped persistent convolution grids of another stream and will
                             // find about this many free CUs (lrcn_api.hip sets it for the LSTM GEMMs when lrcn_vgg_set_wg_cap is
                             // active): the dispatcher then prefers a route whose workgroups fit them in one round

@@ -303,7 +303,14 @@ static hipError_t launch_gemm_routed(hipStream_t stream, const GemmArgs &g, cons
     const bool skinny_ok = !(knob && knob[0] == '0') && !(knobs && knobs[0] == '0') && gemm_skinny_eligible(g);
     if (!(knob && knob[0] == '0') && !(knob8 && knob8[0] == '0')) {
         int64_t blocks = 0;
-        if (gemm_8p_config(g, &blocks) >= 0 && ((knob8 && knob8[0] == 'f') || blocks >= 128)) { *route = "8p"; return launch_gemm_8p(stream, g); }
+        // (beside the capped convolution grids a launch that fills 3/4 of the FREE CUs in one round counts as filling the chip; LRCN_FREE_8P_MIN:
+        // that fraction in percent, development knob)
+        static const int free_pct = getenv("LRCN_FREE_8P_MIN") ? atoi(getenv("LRCN_FREE_8P_MIN")) : 75;
+        if (gemm_8p_config(g, &blocks) >= 0 &&
+            ((knob8 && knob8[0] == 'f') || blocks >= 128 || (g.free_cus > 0 && blocks * 100 >= (int64_t)g.free_cus * free_pct && blocks <= g.free_cus))) {
+            *route = "8p";
+            return launch_gemm_8p(stream, g);
+        }
         // Beside the capped convolution grids only ~bg_cus CUs are free: a launch of many small workgroups runs in several rounds
         // on them, one of few large tiles (less operand traffic per FLOP) in one.  The recurrent GEMM of the B = 256 step
         // (256 x 4000 x 1024): 126 workgroups of 128 x 64 take 13 us alone but 50 us beside the VGG forward (4 rounds on 32 CUs);

@@ -910,6 +910,9 @@ int gemm_8p_config(const GemmArgs &g, int64_t *blocks) {
     int cfg = (g.N > 128 && (b0 >= 200 || g.N % 256 == 0 || g.N > 384)) ? 0 : 1;
     if (cfg == 0 && ((b0 < 200 && b1 >= 200) || (b0 < 128 && b1 >= 128))) cfg = 1;  // the narrower tile when only it fills the chip
     if (g.cfg_pref == 2 && g.N >= 128) cfg = 1;
+    // beside the capped convolution grids (g.free_cus CUs free): the wider tile when only IT fits them in one round -- the logits GEMM of a
+    // 32-row rank (384 x 10640): 84 tiles of 256 x 256 instead of 168 of 256 x 128 on 96 CUs
+    if (g.free_cus > 0 && g.N > 128 && b0 <= g.free_cus && b1 > g.free_cus) cfg = 0;
     {
         static const char *fc = getenv("LRCN_8P_CFG");  // kernel-development knob: force the 256 x 256 (0) or 256 x 128 (1) tile
         if (fc && (fc[0] == '0' || fc[0] == '1') && g.N > 128) cfg = fc[0] - '0';
@@ -937,7 +940,9 @@ int gemm_8p_splitk(const GemmArgs &g, int64_t *blocks) {
     if (!g.ws || (g.ldc % 4) || ((uintptr_t)g.C & 15)) return 0;
     const int kt = conv ? 9 * (g.Cin / 64) : g.K / 64;
     const int64_t b1 = (int64_t)cdiv(g.M, 256) * cdiv(g.N, 128);
-    int s = (int)(256 / b1);
+    // one workgroup per CU of the chip -- or of the CUs the capped convolution grids of the other stream leave free (g.free_cus): at 32 rows
+    // per rank the dH / dX GEMMs (16 tiles, K = 10640 / 4000) were cut into 16 / 7 slices = 256 / 112 workgroups, three / two rounds on 96 CUs
+    int s = (int)((g.free_cus > 0 ? g.free_cus : 256) / b1);
     // slices of >= 8 K-tiles; >= 12 for convolutions (measured per layer, ms without -> with: conv5 at 32 / 16 / 8 images 0.058 -> 0.045,
     // 0.045 -> 0.032, 0.044 -> 0.030; conv4_2 at 8 images 0.057 -> 0.045; but conv3_1 at 4 images, two slices of 9: 0.023 -> 0.030)
     const int min_slice = conv ? 12 : 8;

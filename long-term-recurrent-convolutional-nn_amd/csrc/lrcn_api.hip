@@ -67,6 +67,7 @@ struct lrcn_ctx {
     int64_t conv_chunk_bytes = 0;           // LRCN_OPT_CONV_CHUNK_BYTES (0 = default)
     unsigned fused_groups = 0;              // gradient groups whose fused Adam has been issued in the current step (bit per group)
     int fused_step = 0;                     // the `step` those bits belong to: a call with another step starts a new mask
+    unsigned refresh_groups = 0;            // lrcn_refresh_shadows_group: groups whose shadows of the NEXT step have been issued
     bool shadow_valid = false;              // the current set holds the shadows (direct AND transposed) of the parameters at shadow_p
     const float *shadow_p[9] = {};
     float *dWe_rm = nullptr;                // [V][ldE] f32, all zero between calls: row-major staging of the embedding gradient
@@ -280,6 +281,15 @@ int gemm(lrcn_ctx *c, int dtype, const void *A, int64_t lda, const void *B, int6
         // from 256 rows per GPU only: below, the VGG forward's own grids are small, more CUs are free, and the LSTM chain is the critical
         // path -- the hints measured 1.64 -> 1.79 ms/step at 32 rows, 2.39 -> 2.43 at 64, 4.11 -> 4.12 at 128, 7.31 -> 7.20 at 256
         static const char *kmb = getenv("LRCN_BG_MINB");  // kernel-development knob: rows per GPU from which the hints apply (default 256)
+        static const char *kfc = getenv("LRCN_FREE_CUS_HINT");  // 0: the split-K planner assumes the whole chip, as before round 5
+        if (c->vgg_wg_cap >= 8 && c->vgg_loaded && c->cur_B < (kmb ? atoi(kmb) : 256) && !(kfc && kfc[0] == '0')) {
+            static int ncu1 = 0;
+            if (!ncu1) {
+                hipDeviceProp_t pr;
+                ncu1 = (hipGetDeviceProperties(&pr, c->cfg.device) == hipSuccess) ? pr.multiProcessorCount : 256;
+            }
+            g.free_cus = ncu1 - c->vgg_wg_cap > 0 ? ncu1 - c->vgg_wg_cap : 0;
+        }
         if (c->vgg_wg_cap >= 8 && c->vgg_loaded && c->cur_B >= (kmb ? atoi(kmb) : 256) && !(kb && kb[0] == '0')) {
             static int ncu = 0;
             if (!ncu) {
@@ -296,6 +306,10 @@ int gemm(lrcn_ctx *c, int dtype, const void *A, int64_t lda, const void *B, int6
     }
     hipError_t e = launch_gemm(on_wg_stream ? c->wg_stream : c->stream, g);
     if (e != hipSuccess) FAIL(c, LRCN_EHIP, "gemm M=%d N=%d K=%d: %s", M, N, K, hipGetErrorString(e));
+    {   // kernel-development aid: LRCN_TRACE_ROUTES=1 prints which kernel family every contraction of a call took
+        static const char *kt = getenv("LRCN_TRACE_ROUTES");
+        if (kt && kt[0] == '1') fprintf(stderr, "gemm M=%d N=%d K=%d %s-> %s\n", M, N, K, on_wg_stream ? "(wg stream) " : "", gemm_debug_last_route());
+    }
     return LRCN_OK;
 }
 #define GEMM(...)                     \
@@ -929,6 +943,7 @@ int lrcn_params_touched(lrcn_ctx *c) {
     if (!c) return LRCN_EINVAL;
     c->shadow_valid = false;
     c->fused_groups = 0;  // a per-group update that stopped partway must not complete a later step's mask
+    c->refresh_groups = 0;
     return LRCN_OK;
 }
 
@@ -1304,6 +1319,31 @@ int lrcn_adam_update_group(lrcn_ctx *c, float *const p[9], const float *const g[
     }
     k_adam(stream ? reinterpret_cast<hipStream_t>(stream) : c->stream, t, step, lr, b1, b2, eps);
     KCHK(c, "adam (group)");
+    return LRCN_OK;
+}
+
+int lrcn_refresh_shadows_group(lrcn_ctx *c, const float *const p[9], int group, void *stream) {
+    DeviceGuard dg(c);
+    if (!c || !p) return LRCN_EINVAL;
+    if (group < 0 || group >= LRCN_GRAD_GROUPS) FAIL(c, LRCN_EINVAL, "group=%d outside [0,%d)", group, LRCN_GRAD_GROUPS);
+    if (!c->opt_fused) FAIL(c, LRCN_ESTATE, "lrcn_refresh_shadows_group needs LRCN_OPT_FUSED_UPDATE = 1 (the second shadow set)");
+    static const int kGroup[LRCN_GRAD_GROUPS][2] = {{7, 8}, {2, 3}, {4, 5}, {0, 1}, {6, 6}};
+    int r = ensure_alt_shadows(c);
+    if (r) return r;
+    if (c->refresh_groups == 0) c->shadow_valid = false;  // first group of a step: the current set describes the OLD parameters from now on
+    PrepPlan plan{};
+    plan_matrices(c, p, alt_shadows(c), true, plan, kGroup[group][0], kGroup[group][1]);
+    if (plan.n > 0) {  // LRCN-1f has no W2 / Wproj: an empty group is only counted
+        k_prepare_weights(stream ? reinterpret_cast<hipStream_t>(stream) : c->stream, c->dt, plan);
+        KCHK(c, "refresh_shadows_group");
+    }
+    c->refresh_groups |= 1u << group;
+    if (c->refresh_groups == (1u << LRCN_GRAD_GROUPS) - 1) {
+        c->refresh_groups = 0;
+        float *pp[9];
+        for (int k = 0; k < 9; ++k) pp[k] = const_cast<float *>(p[k]);
+        fused_update_done(c, pp);
+    }
     return LRCN_OK;
 }
 

@@ -209,8 +209,10 @@ struct RecBwdArgs {
 
 // U = hidden units per workgroup: 16, or 8 with MT = 1 (16 rows x 8 units: 250 workgroups at 32 rows, H = 1000, each pulling
 // 4 waves x 16 K-tiles x 3 KiB = 192 KiB through its CU's LDS-DMA path instead of 63 pulling 384 KiB -- see the forward kernel)
+// U = 12 with MT = 2 (round 5): 84 workgroups instead of 63 beside the VGG forward's 160 (96 CUs free); rows 12..15 of a wave's B pieces
+// come from the zero page.
 template <int MT, int U = 16> __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(const RecBwdArgs a) {
-    constexpr int BP = U / 8;
+    constexpr int BP = (U + 7) / 8;
     typedef FusedGeom<MT, BP> G;
     extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -266,20 +268,28 @@ template <int MT, int U = 16> __global__ __launch_bounds__(256) void lstm_rec_bw
 // (Wh and h fragments straight from global memory into registers in MFMA operand layout -- 16 rows x 64 B per wave instruction --
 // measured SLOWER than the ring: 10.1 vs 9.0 us forward, 17.0 vs 10.3 us backward.)
 // Row blocks of 32 (grid.y = ceil(B / 32)).
-constexpr int R2_ROWS = 32, R2_KT = 16, R2_U = 8;
+// U = 12 (round 5): the same kernel with 12 units per workgroup -- 84 workgroups for H = 1000, 16 K-tiles x (4 KiB of h + 4 x 1.5 KiB of
+// Wh rows) = exactly the CU's 160 KiB of LDS -- for the rank-of-8 training step, where the VGG forward's capped grid (160 workgroups, one
+// per CU, persistent) leaves 96 CUs: 125 workgroups of the 8-unit form would need a second round, 84 fit in one, each pulling 160 KiB
+// through its CU's LDS-DMA path where the ring form (63 workgroups of 16 units) pulls 384 KiB.  A wave's Wh rows of one K-tile are one
+// full LDS-DMA piece (rows 0..7) + one half piece under an EXEC mask (rows 8..11: lanes 0..31 only, so nothing is written past the 12th
+// row); columns 12..15 of the MFMA tile repeat columns 4..7 and are dropped.
+constexpr int R2_ROWS = 32, R2_KT = 16;
 
-__global__ __launch_bounds__(256) void lstm_rec_fwd2_kernel(const RecFwdArgs a) {
+template <int U> __global__ __launch_bounds__(256) void lstm_rec_fwd2_kernel(const RecFwdArgs a) {
+    static_assert(U == 8 || U == 12, "8 or 12 hidden units per workgroup");
+    constexpr int BROW = U * 128;  // bytes of one wave's Wh rows per K-tile
     extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // = gate
-    const int u0 = blockIdx.x * R2_U, H = a.H;
+    const int u0 = blockIdx.x * U, H = a.H;
     const int r0 = blockIdx.y * R2_ROWS;
     const int M = a.B - r0 < R2_ROWS ? a.B - r0 : R2_ROWS;
-    const int valid = H - u0 < R2_U ? H - u0 : R2_U;
+    const int valid = H - u0 < U ? H - u0 : U;
     const int KT = (int)(a.ldh / 64);  // <= R2_KT (launch check)
-    // LDS: h block, K-tile kt = 32 rows x 128 B at kt * 4096; then per wave its Wh rows, K-tile kt = 8 rows x 128 B at kt * 1024.
+    // LDS: h block, K-tile kt = 32 rows x 128 B at kt * 4096; then per wave its Wh rows, K-tile kt = U rows x 128 B at kt * BROW.
     // 16-byte chunk j of row r sits at chunk j ^ ((r >> 1) & 7) (applied to the SOURCE address: LDS-DMA writes lanes in order).
-    unsigned char *sB = smem + KT * (R2_ROWS * 128) + wave * (KT * 1024);
+    unsigned char *sB = smem + KT * (R2_ROWS * 128) + wave * (KT * BROW);
     {
         const bf16_t *Zp = reinterpret_cast<const bf16_t *>(a.zero_page) + (lane & 7) * 8;
         const int r8 = lane >> 3, row = wave * 8 + r8;  // h rows: wave w stages rows 8 w .. 8 w + 7 of every K-tile
@@ -291,19 +301,30 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd2_kernel(const RecFwdArgs a) 
         for (int kt = 0; kt < R2_KT; ++kt)
             if (kt < KT) {
                 __builtin_amdgcn_global_load_lds((glb_void *)(asrc + kt * astep), (lds_void *)(smem + kt * (R2_ROWS * 128) + wave * 1024), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((glb_void *)(bsrc + kt * bstep), (lds_void *)(sB + kt * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_void *)(bsrc + kt * bstep), (lds_void *)(sB + kt * BROW), 16, 0, 0);
             }
+        if constexpr (U == 12) {
+            if (lane < 32) {  // rows 8..11: half a piece; the inactive lanes write nothing
+                const int rb = 8 + r8;
+                const bool ok2 = rb < valid;
+                const bf16_t *b2 = ok2 ? a.Wh + (int64_t)(wave * H + u0 + rb) * a.ldh + (((lane & 7) ^ ((rb >> 1) & 7)) << 3) : Zp;
+                const int b2step = ok2 ? 64 : 0;
+#pragma unroll
+                for (int kt = 0; kt < R2_KT; ++kt)
+                    if (kt < KT) __builtin_amdgcn_global_load_lds((glb_void *)(b2 + kt * b2step), (lds_void *)(sB + kt * BROW + 1024), 16, 0, 0);
+            }
+        }
     }
     wait_vmcnt<0>();
     __syncthreads();
     f32x4v acc[2] = {f32x4v{0.f, 0.f, 0.f, 0.f}, f32x4v{0.f, 0.f, 0.f, 0.f}};
-    const int l7 = l15 & 7;
+    const int lb = U == 8 ? (l15 & 7) : (l15 < 12 ? l15 : l15 - 8);  // B row this lane's MFMA column reads (columns >= U repeat earlier ones)
     const int fa0 = l15 * 128 + (((0 + lq) ^ ((l15 >> 1) & 7)) << 4), fa1 = l15 * 128 + (((4 + lq) ^ ((l15 >> 1) & 7)) << 4);
-    const int fb0 = l7 * 128 + (((0 + lq) ^ ((l7 >> 1) & 7)) << 4), fb1 = l7 * 128 + (((4 + lq) ^ ((l7 >> 1) & 7)) << 4);
+    const int fb0 = lb * 128 + (((0 + lq) ^ ((lb >> 1) & 7)) << 4), fb1 = lb * 128 + (((4 + lq) ^ ((lb >> 1) & 7)) << 4);
 #pragma unroll
     for (int kt = 0; kt < R2_KT; ++kt) {
         if (kt < KT) {
-            const unsigned char *t = smem + kt * (R2_ROWS * 128), *tb = sB + kt * 1024;
+            const unsigned char *t = smem + kt * (R2_ROWS * 128), *tb = sB + kt * BROW;
             const uint4 b0 = *reinterpret_cast<const uint4 *>(tb + fb0), b1 = *reinterpret_cast<const uint4 *>(tb + fb1);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -314,22 +335,22 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd2_kernel(const RecFwdArgs a) 
         }
     }
     __syncthreads();  // every wave is done with the staged operands: the exchange area may overwrite them
-    float *xch = reinterpret_cast<float *>(smem);  // [gate][row][9]
-    if (l15 < R2_U) {
+    float *xch = reinterpret_cast<float *>(smem);  // [gate][row][U + 1]
+    if (l15 < U) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) xch[(wave * R2_ROWS + i * 16 + 4 * lq + r) * 9 + l15] = acc[i][r];
+            for (int r = 0; r < 4; ++r) xch[(wave * R2_ROWS + i * 16 + 4 * lq + r) * (U + 1) + l15] = acc[i][r];
     }
     __syncthreads();
-    {
-        const int ml = tid >> 3, u = tid & 7, j = u0 + u, m = r0 + ml;  // 32 rows x 8 units = one element per thread
+    for (int e = tid; e < R2_ROWS * U; e += 256) {
+        const int ml = e / U, u = e % U, j = u0 + u, m = r0 + ml;
         if (ml < M && j < H) {
             const float *gx = a.Gx + (int64_t)m * 4 * H;
-            const float f = sigm_f(xch[(0 * R2_ROWS + ml) * 9 + u] + gx[j]);
-            const float i = sigm_f(xch[(1 * R2_ROWS + ml) * 9 + u] + gx[H + j]);
-            const float o = sigm_f(xch[(2 * R2_ROWS + ml) * 9 + u] + gx[2 * H + j]);
-            const float ch = tanhf(xch[(3 * R2_ROWS + ml) * 9 + u] + gx[3 * H + j]);
+            const float f = sigm_f(xch[(0 * R2_ROWS + ml) * (U + 1) + u] + gx[j]);
+            const float i = sigm_f(xch[(1 * R2_ROWS + ml) * (U + 1) + u] + gx[H + j]);
+            const float o = sigm_f(xch[(2 * R2_ROWS + ml) * (U + 1) + u] + gx[2 * H + j]);
+            const float ch = tanhf(xch[(3 * R2_ROWS + ml) * (U + 1) + u] + gx[3 * H + j]);
             const float c = a.c_prev[(int64_t)m * H + j] * f + i * ch;
             const float h = o * tanhf(c);
             bf16_t *ac = a.acts + (int64_t)m * a.ld_a;
@@ -354,6 +375,12 @@ int rec2_max_batch() {
     return k ? atoi(k) : 64;
 }
 
+// Beside the VGG forward (`alone` false): the 12-unit forms up to this many rows (LRCN_LSTM_REC3; 0 = never, the ring forms of 16 units).
+int rec3_max_batch() {
+    const char *k = getenv("LRCN_LSTM_REC3");
+    return k ? atoi(k) : 32;
+}
+
 template <class K> hipError_t set_lds(K kern, int lds, LdsAttrMask &done) { return set_max_lds(reinterpret_cast<const void *>(kern), lds, done); }
 
 }  // namespace
@@ -373,8 +400,15 @@ hipError_t launch_lstm_rec_fwd(hipStream_t st, const void *h_prev, int64_t ldh, 
     hipError_t e;
     if (alone && B <= rec2_max_batch() && ldh / 64 <= R2_KT) {
         const int KT = (int)(ldh / 64), lds = KT * (R2_ROWS * 128 + 4 * 1024);  // >= the exchange area (4 x 32 x 9 floats)
-        if ((e = set_lds(lstm_rec_fwd2_kernel, R2_KT * (R2_ROWS * 128 + 4 * 1024), dr)) != hipSuccess) return e;
-        hipLaunchKernelGGL(lstm_rec_fwd2_kernel, dim3((H + R2_U - 1) / R2_U, (B + R2_ROWS - 1) / R2_ROWS), dim3(256), lds, st, a);
+        if ((e = set_lds(lstm_rec_fwd2_kernel<8>, R2_KT * (R2_ROWS * 128 + 4 * 1024), dr)) != hipSuccess) return e;
+        hipLaunchKernelGGL(lstm_rec_fwd2_kernel<8>, dim3((H + 7) / 8, (B + R2_ROWS - 1) / R2_ROWS), dim3(256), lds, st, a);
+        return hipGetLastError();
+    }
+    if (!alone && B <= rec3_max_batch() && ldh / 64 <= R2_KT) {
+        static LdsAttrMask d3{0};
+        const int KT = (int)(ldh / 64), lds = KT * (R2_ROWS * 128 + 4 * 1536) > 4 * R2_ROWS * 13 * 4 ? KT * (R2_ROWS * 128 + 4 * 1536) : 4 * R2_ROWS * 13 * 4;
+        if ((e = set_lds(lstm_rec_fwd2_kernel<12>, R2_KT * (R2_ROWS * 128 + 4 * 1536), d3)) != hipSuccess) return e;
+        hipLaunchKernelGGL(lstm_rec_fwd2_kernel<12>, dim3((H + 11) / 12, (B + R2_ROWS - 1) / R2_ROWS), dim3(256), lds, st, a);
         return hipGetLastError();
     }
     const dim3 grid((H + 15) / 16, B <= 32 ? 1 : (B + 63) / 64);
@@ -403,6 +437,13 @@ hipError_t launch_lstm_rec_bwd(hipStream_t st, const void *dz_s, int64_t ld4, co
         auto kern = lstm_rec_bwd_kernel<1, 8>;
         if ((e = set_lds(kern, lds, d1)) != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3((H + 7) / 8, (B + 15) / 16), dim3(256), lds, st, a);
+        return hipGetLastError();
+    }
+    if (!alone && B <= 32 && B <= rec3_max_batch()) {
+        static LdsAttrMask d12{0};
+        auto kern = lstm_rec_bwd_kernel<2, 12>;
+        if ((e = set_lds(kern, FusedGeom<2>::LDS, d12)) != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3((H + 11) / 12, 1), dim3(256), FusedGeom<2>::LDS, st, a);
         return hipGetLastError();
     }
     const dim3 grid((H + 15) / 16, B <= 32 ? 1 : (B + 63) / 64);

@@ -157,6 +157,9 @@ class HipOps:
     def update_flat(self, w, g, m, v, optim, stream):
         L.update_flat(self.ctx, w, g, m, v, optim, stream)
 
+    def refresh_shadows_group(self, param, group, stream):
+        L.refresh_shadows_group(self.ctx, param, group, stream)
+
     def last_loss(self):
         return L.last_loss(self.ctx)
 
@@ -170,8 +173,9 @@ class HipOps:
     def make_streams(self, n, avoid=()):
         if os.environ.get("LRCN_DP_GROUP_STREAMS", "0")[:1] == "1":
             return [torch.cuda.Stream(device=self.ctx.device) for _ in range(n)]
-        s = independent_stream(torch.device("cuda", self.ctx.device), list(avoid)) or torch.cuda.Stream(device=self.ctx.device)
-        return [s] * n
+        s = independent_stream(torch.device("cuda", self.ctx.device), list(avoid))
+        self.update_stream_probed = s is not None   # False: every candidate shared a queue with one of `avoid` (reported by describe())
+        return [s or torch.cuda.Stream(device=self.ctx.device)] * n
 
     def stream_ctx(self, stream):
         return torch.cuda.stream(stream)
@@ -284,7 +288,11 @@ class DataParallelTrainer:
         env = os.environ.get("LRCN_FUSED_UPDATE")
         fused = (env[:1] != "0") if env else True
         self._fused = bool(fused and not self.shard and hasattr(self.ops, "set_fused_update"))
-        if self._fused:
+        # Sharded update (round 5): the next step's shadow weights of a group are made on the update stream right after that group's
+        # all-gather (lrcn_refresh_shadows_group), beside the rest of the backward pass, instead of as one pass at the head of the next
+        # lossgradient (63 .. 138 us on the critical path of a 32-row step).  Same contract as the fused update.  LRCN_FUSED_UPDATE=0: off.
+        self._shadow_groups = bool(fused and self.shard and hasattr(self.ops, "set_fused_update") and hasattr(self.ops, "refresh_shadows_group"))
+        if self._fused or self._shadow_groups:
             self.ops.set_fused_update(True)
         shapes = [tuple(t.shape) for t in param]
         self._W = self._emu_shards or max(world, 1)   # number of parameter shards of the sharded update
@@ -415,12 +423,12 @@ class DataParallelTrainer:
             except Exception:
                 pass
             self._sparse_embed = False
-        if getattr(self, "_fused", False) and hasattr(self.ops, "set_fused_update"):
+        if (getattr(self, "_fused", False) or getattr(self, "_shadow_groups", False)) and hasattr(self.ops, "set_fused_update"):
             try:
                 self.ops.set_fused_update(False)
             except Exception:
                 pass
-            self._fused = False
+            self._fused = self._shadow_groups = False
 
     def _init_abi_comm(self, world, rank, group, device):
         """Two phases, so that no rank can be left alone inside the collective lrcn_comm_init (= ncclCommInitRank):
@@ -482,7 +490,15 @@ class DataParallelTrainer:
 
     def _make_update_streams(self):
         try:
-            streams = self.ops.make_streams(len(GRAD_GROUPS), avoid=[self._side])
+            # Round 5: the update stream must share its hardware queue with NONE of the three other chains of a step -- the VGG side stream,
+            # the main stream (the rest of the backward pass runs there while a group is exchanged and updated) and the library's
+            # weight-gradient stream.  Until round 5 only the side stream was avoided: in about one process out of three the update chain
+            # landed on the main stream's queue and ran IN ORDER with the backward pass (emulated sharded rank of 8: 1.26 instead of 1.18 ms).
+            avoid = [self._side]
+            if self.ctx is not None and torch.cuda.is_available():
+                avoid.append(torch.cuda.current_stream(self.ctx.device))
+            avoid.append(getattr(self.ops, "_wg_stream", None))
+            streams = self.ops.make_streams(len(GRAD_GROUPS), avoid=[a for a in avoid if a is not None])
         except TypeError:   # stand-in ops of the CPU tests
             return self.ops.make_streams(len(GRAD_GROUPS))
         self._bucket_streams = streams
@@ -734,6 +750,8 @@ class DataParallelTrainer:
             s = self._bucket_streams[k]
             self.ops.grad_group_wait(k, s)
             if b == a:
+                if self._shadow_groups:
+                    self.ops.refresh_shadows_group(self.param, k, s)   # an empty group still counts towards "all five refreshed"
                 continue  # LRCN-1f has no W2 / b2 group
             n = (b - a) // W
             mine = self.flat_param[a + r * n:a + (r + 1) * n]
@@ -760,16 +778,20 @@ class DataParallelTrainer:
                         dist.all_gather(parts, mine.clone(), group=self.group)
                         for i, t in enumerate(parts):
                             self.flat_param[a + i * n:a + (i + 1) * n].copy_(t)
+                if self._shadow_groups:   # the group's parameters are final on this stream: its shadows for the next step, beside the backward pass
+                    self.ops.refresh_shadows_group(self.param, k, s)
         self.ops.join(self._bucket_streams)
 
     def describe(self):
         """What this trainer's step is made of (reported in bench.py's line: rccl.pipeline)."""
         buckets = os.environ.get("LRCN_DP_BUCKETS", "1")[:1] != "0"
         return {"backend": self.backend, "update": "sharded" if self.shard else "replicated", "fused_update": bool(self._fused),
+                "shadows_by_group": bool(getattr(self, "_shadow_groups", False)),
                 "per_group_pipeline": bool(self.shard or (self.backend == "abi" and self._multi) or self._group_pipeline()),
                 "one_allreduce_of_the_flat_buffer": bool(self.world > 1 and not buckets and not self.shard),
                 "sparse_embedding_exchange": bool(getattr(self, "_sparse_embed", False)), "vgg_side_stream": self._side is not None,
-                "queue_probe": getattr(self, "queue_probe", None), "backend_note": self.backend_note or None}
+                "queue_probe": getattr(self, "queue_probe", None), "backend_note": self.backend_note or None,
+                "update_stream_on_its_own_queue": getattr(self.ops, "update_stream_probed", None)}
 
     # ---- first-contact self-check of an N-rank job (bench.py and tools/lrcn.py run it once, before anything is timed) ----
     def _dist_on(self):

@@ -290,6 +290,11 @@ def update_flat(ctx, w, g, m, v, optim, stream=None):
               n, optim.t, optim.lr, optim.beta1, optim.beta2, optim.eps, C.c_void_p(stream.cuda_stream) if stream is not None else None)
 
 
+def refresh_shadows_group(ctx, param, group, stream=None):
+    """lrcn_refresh_shadows_group: the next step's shadow weights of one gradient group, on `stream`, from the parameters as they are now."""
+    ctx._call("lrcn_refresh_shadows_group", _p9(param), int(group), C.c_void_p(stream.cuda_stream) if stream is not None else None)
+
+
 def train_step(ctx, param, optim, grads, feats, tokens, norm_B=None, pdrop=0.4, seed=0, want_loss=False):
     """Body of train1's batch loop (lrcn.jl:369-394): lossgradient + update!, one C call."""
     tok = _tokens(tokens, feats.device)

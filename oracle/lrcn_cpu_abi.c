@@ -177,6 +177,10 @@ int lrcn_loss_grad(lrcn_ctx *c, const float *const p[9], const float *feats, con
     if (!c || !p || !feats || (!tokens && T > 0) || !grads) return LRCN_EINVAL;
     return loss_common(c, p, feats, tokens, T, B, norm_B, drop, grads, loss_host);
 }
+int lrcn_refresh_shadows_group(lrcn_ctx *c, const float *const p[9], int group, void *stream) {
+    (void)p; (void)stream;
+    return (c && group >= 0 && group < LRCN_GRAD_GROUPS) ? LRCN_OK : LRCN_EINVAL; /* the host twin reads the f32 parameters directly: no shadows */
+}
 int lrcn_avg_loss_batch(lrcn_ctx *c, const float *const p[9], const float *feats, const int32_t *tokens, int T, int B, double *loss_host) {
     if (!c || !p || !feats || (!tokens && T > 0)) return LRCN_EINVAL;
     return loss_common(c, p, feats, tokens, T, B, B, NULL, NULL, loss_host); /* average_loss's body: pdrop 0, the batch's own size (lrcn.jl:412, 452-475) */

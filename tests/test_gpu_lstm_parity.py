@@ -383,23 +383,61 @@ def test_fused_recurrence_small_batch_forms_equal_ring_forms(B, H, monkeypatch):
         assert np.linalg.norm(a - b) <= 1e-2 * np.linalg.norm(b) + 1e-12, n
 
 
-def test_bf16_full_c4_dimensions_vs_emulating_oracle():
+@pytest.mark.parametrize("B,H", [(32, 1000), (21, 100), (32, 320), (17, 512)])
+def test_twelve_unit_recurrence_forms_beside_the_vgg_forward(B, H, monkeypatch):
+    # Round 5: beside the VGG forward of the rank-of-8 step (capped grid: 96 CUs free) the recurrence of <= 32 rows runs on 12 hidden
+    # units per workgroup (lstm_rec_fwd2_kernel<12>: h staged once, a wave's 12 Wh rows = one LDS-DMA piece + half a piece under an EXEC
+    # mask; lstm_rec_bwd_kernel<2, 12>) -- LRCN_LSTM_REC3=32 (default) against 0 (the 16-unit ring forms), both against the emulating and
+    # the plain oracle.  H = 1000: the benchmark's K = 1024, last workgroup with 4 valid units; H = 100: one partial row block, last
+    # workgroup 4 units, K padded to 128; H = 320 / 512: 27 / 43 workgroups, 5 / 8 K-tiles.
+    rng = np.random.default_rng(B * 7 + H)
+    E, V, T = 64, 300, 4
+    m = orc.init_weights(E, H, H, V, seed=5)
+    for n in ("W1", "W2"):
+        m.p[n] *= 2.0
+    feats = (rng.standard_normal((B, 4096)) * 0.05).astype(np.float32)
+    tokens = rng.integers(0, V, size=(T, B)).astype(np.int32)
+    emu_loss, emu_g = emulated_reference(m, feats, tokens)
+    vgg = L.synthetic_vgg_weights(seed=1)
+    res = {}
+    for knob in ("32", "0"):
+        monkeypatch.setenv("LRCN_LSTM_REC3", knob)
+        ctx = L.Context(E, H, H, V, max_B=B, max_T=T, lstm_dtype=lrcn_amd.LRCN_BF16, vgg_dtype=lrcn_amd.LRCN_BF16, max_images=1)
+        L.vgg_load(ctx, *vgg)
+        L.vgg_set_wg_cap(ctx, 160)   # what dp.py sets at 32 rows per GPU: the LSTM step is then "beside the convolutions"
+        for _ in range(2):   # twice: the second call reads LDS-resident state of nothing, but scratch buffers carry the first call's values
+            grads, val = L.lossgradient(ctx, L.model_from_arrays(m.p), L.to_jl(feats), tokens)
+        res[knob] = (val, [L.from_jl(g).astype(np.float64) for g in grads])
+        ctx.close()
+        assert_bf16_matches_emulation(val, res[knob][1], emu_loss, emu_g, "LRCN_LSTM_REC3=%s B=%d H=%d" % (knob, B, H))
+    assert abs(res["32"][0] - res["0"][0]) <= 1e-4 * abs(emu_loss)
+    for n, a, b in zip(orc.PARAM_NAMES, res["32"][1], res["0"][1]):
+        assert np.linalg.norm(a - b) <= 1e-2 * np.linalg.norm(b) + 1e-12, n
+
+
+@pytest.mark.parametrize("T,beside", [(3, False), (11, True)])
+def test_bf16_full_c4_dimensions_vs_emulating_oracle(T, beside):
     # BASELINE configs[3] dimensions (E = H = 1000, V = 10640: K = 1000 padded to 1024, 4H = 4000 -> 4032, V -> 10688) on a row subset the
-    # oracle finishes in seconds (32 rows = one rank of 8, T = 3), device-independent dropout masks: loss and all nine gradients
+    # oracle finishes in seconds (32 rows = one rank of 8), device-independent dropout masks: loss and all nine gradients
     # elementwise against the bf16-emulating oracle.  (tests/test_gpu_fullsize.py covers B = 256, T = 11 through size-independent
-    # properties; this is the oracle comparison at the benchmark's own dimensions.)
-    rng = np.random.default_rng(32)
+    # properties; this is the oracle comparison at the benchmark's own dimensions.)  T = 11, beside = True: the rank-of-8 step EXACTLY as
+    # bench.py --emulate-world 8 runs it -- M = 384 time-batched rows, VGG weights loaded and the convolution grids capped at 160, which
+    # selects the 12-unit recurrence kernels and the split-K plans cut for the 96 free CUs (round 5).
+    rng = np.random.default_rng(32 + T)
     E = H = 1000
-    V, B, T = 10640, 32, 3
+    V, B = 10640, 32
     m = orc.init_weights(E, H, H, V, seed=42)
     feats = (rng.standard_normal((B, 4096)) * 0.05).astype(np.float32)
     tokens = rng.integers(0, V, size=(T, B)).astype(np.int32)
     mask1 = ((rng.random((T + 1, B, E)) > 0.4) / 0.6).astype(np.float32)
     mask2 = ((rng.random((T + 1, B, H)) > 0.4) / 0.6).astype(np.float32)
     emu_loss, emu_g = emulated_reference(m, feats, tokens, norm_B=256, mask1=mask1, mask2=mask2)
-    ctx = L.Context(E, H, H, V, max_B=B, max_T=T, lstm_dtype=lrcn_amd.LRCN_BF16)
+    ctx = L.Context(E, H, H, V, max_B=B, max_T=T, lstm_dtype=lrcn_amd.LRCN_BF16, vgg_dtype=lrcn_amd.LRCN_BF16, max_images=1 if beside else 0)
+    if beside:
+        L.vgg_load(ctx, *L.synthetic_vgg_weights(seed=1))
+        L.vgg_set_wg_cap(ctx, 160)
     grads, val = L.lossgradient(ctx, L.model_from_arrays(m.p), L.to_jl(feats), tokens, norm_B=256, mask1=mask1, mask2=mask2)
-    assert_bf16_matches_emulation(val, grads, emu_loss, emu_g, "C4 dimensions, 32 of 256 rows")
+    assert_bf16_matches_emulation(val, grads, emu_loss, emu_g, "C4 dimensions, 32 of 256 rows, T=%d%s" % (T, " beside the VGG grids" if beside else ""))
     ctx.close()
 
 

@@ -17,12 +17,58 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 import lrcn_amd  # noqa: E402
 from lrcn_amd import lrcn as L  # noqa: E402
+
+
+def cpu_baseline_c5(vgg_w, param, K, nword, V):
+    """The CPU leg of the C5 line (kind "port": the reference has no CPU path and cannot run here): the SAME two calls through the SAME C ABI
+    on this box's host cores -- oracle/liblrcn_cpu_f32.so behind lrcn_vgg_forward_u8 (f32; the host has no e4m3 path) + lrcn_beam_search
+    (generate / beam_search, lrcn.jl:585-678, one image at a time as the reference decodes) -- on a bounded sample: 8 crops, 4 captions."""
+    import ctypes as C
+    from lrcn_amd import _lib
+    from oracle import oracle as orc
+    n_img, n_cap = 8, 4
+    ncpu = orc.effective_cpus()
+    A = orc.cpu_abi(_lib.SIGNATURES, fast=True)
+    A.orc_set_num_threads(ncpu)
+    cfg = _lib.Config(0, 1000, 1000, 1000, V, K, 1, _lib.LRCN_F32, _lib.LRCN_F32, n_img, 2)
+    h = C.c_void_p()
+    assert A.lrcn_create(C.byref(cfg), C.byref(h)) == 0
+
+    def fp(a):
+        return a.ctypes.data_as(C.c_void_p)
+
+    conv_w, conv_b, fc6, fc7 = vgg_w
+    keep = [orc.fa(L.from_jl(a)) for a in conv_w] + [orc.fa(b.cpu().numpy()) for b in conv_b] + [orc.fa(L.from_jl(fc6[0])), orc.fa(fc6[1].cpu().numpy()),
+                                                                                                 orc.fa(L.from_jl(fc7[0])), orc.fa(fc7[1].cpu().numpy())]
+    assert A.lrcn_vgg_load(h, _lib.P13(*[fp(a).value for a in keep[:13]]), _lib.P13(*[fp(a).value for a in keep[13:26]]), fp(keep[26]),
+                           fp(keep[27]), fp(keep[28]), fp(keep[29])) == 0
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, size=(n_img, 224, 224, 3), dtype=np.uint8)
+    feats = np.zeros((n_img, 4096), np.float32, order="F")
+    mean = (C.c_float * 3)(*L.VGG_MEAN)
+    t0 = time.time()
+    assert A.lrcn_vgg_forward_u8(h, fp(img), n_img, mean, fp(feats)) == 0
+    t_vgg = (time.time() - t0) / n_img
+    host_p = [orc.fa(L.from_jl(t)) for t in param]
+    p9 = _lib.P9(*[fp(a).value if a.size else None for a in host_p])
+    toks, ln, pr = (C.c_int32 * (nword + 2))(), C.c_int(), C.c_float()
+    t0 = time.time()
+    for n in range(n_cap):
+        f1 = orc.fa(feats[n:n + 1] * np.float32(0.01))
+        assert A.lrcn_beam_search(h, p9, fp(f1), K, nword, toks, C.byref(ln), C.byref(pr)) == 0
+    t_cap = (time.time() - t0) / n_cap
+    A.lrcn_destroy(h)
+    return {"value": 1.0 / (t_vgg + t_cap), "unit": "captions/sec", "cores": ncpu, "kind": "port",
+            "sample": "oracle/liblrcn_cpu_f32.so = include/lrcn.h on the host: lrcn_vgg_forward_u8 on %d crops (f32, %.3f s/img) + lrcn_beam_search K=%d "
+                      "nword=%d on %d of them, one image at a time as generate does (%.3f s/caption); %d threads = the container's CPU share"
+                      % (n_img, t_vgg, K, nword, n_cap, t_cap, ncpu)}
 
 
 def main():
@@ -34,6 +80,7 @@ def main():
     ap.add_argument("--overlap", type=int, default=1, help="1: the VGG forward of pass k+1 runs on a side HIP stream (capped "
                     "convolution grids) beside the beam search of pass k, as dp.py does for training; 0: in order on one stream")
     ap.add_argument("--cap", type=int, default=-1, help="convolution-grid cap for the overlapped VGG forward (-1: 7/8 of the CUs)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fixture", action="store_true", help="skip the caption-agreement fixture (parity.c5_fixture) after the timed region")
     a = ap.parse_args()
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
@@ -45,7 +92,8 @@ def main():
     vdt = lrcn_amd.LRCN_FP8 if a.vgg == "fp8" else lrcn_amd.LRCN_BF16
     ctx = L.Context(1000, 1000, 1000, V, max_B=a.chunk * K, max_T=1, lstm_dtype=lrcn_amd.LRCN_BF16, vgg_dtype=vdt, max_images=N,
                     device=local)
-    L.vgg_load(ctx, *L.synthetic_vgg_weights(seed=1))
+    vgg_w = L.synthetic_vgg_weights(seed=1)
+    L.vgg_load(ctx, *vgg_w)
     param = L.initweights(ctx, seed=42)
     img = torch.as_tensor(np.random.default_rng(1234 + rank).integers(0, 256, size=(N, 224, 224, 3), dtype=np.uint8)).cuda()
     if vdt == lrcn_amd.LRCN_FP8:
@@ -118,6 +166,14 @@ def main():
     torch.cuda.synchronize()
     t_vgg = time.perf_counter() - t1
     if rank == 0:
+        import bench as _bench
+        traffic, traffic_note = _bench.pmc_traffic_file("pmc_traffic_caption_bench_c5.json") if (a.vgg == "fp8" and N == 1024) else (None, "no PMC pass for this configuration")
+        cpu = cpu_baseline_c5(vgg_w, param, K, nword, V) if (world == 1 and not a.no_cpu_baseline) else None
+        fixture = None
+        if world == 1 and not a.no_fixture:
+            ctx.close()   # the fixture builds its own contexts
+            import c5_fixture
+            fixture = c5_fixture.run_fixture(steps=1500)
         # roofline of the dominant kernel family (the 12 convolution launches; SURVEY 8d: 30.693 GFLOP per image): fp8 runs conv2_2..conv5_3
         # (24.972 GF) on e4m3 MFMA and conv1_1 + conv1_2 + conv2_1 (5.721 GF) on bf16 MFMA, so the peak is the FLOP-weighted harmonic blend
         GF_ALL, GF_BF16 = 30.693, 2 * (224 * 224 * 64 * (27 + 576) + 112 * 112 * 128 * 576) / 1e9
@@ -135,7 +191,11 @@ def main():
                                      "images_per_gpu_per_pass": N, "beam_chunk": a.chunk, "vgg_overlapped": bool(a.overlap), "parallelism": "replicas x%d" % world,
                                      "ms_vgg_forward_alone": t_vgg * 1e3, "mean_caption_len": float(np.mean([len(t) for t, _ in outs]))},
                           "rccl": {"world": world, "backend": "none (replicas: one barrier + a max over ranks of the elapsed time)"},
-                          "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                          **({"cpu_baseline": cpu} if cpu else {}),
+                          **({"parity": {"c5_fixture": fixture, "tolerance": "BASELINE.md section 3: top caption identical on >= 95 % of fixture images (else "
+                                                                              "BLEU within +-0.5); asserted by tests/test_gpu_config5.py"}} if fixture else {}),
+                          "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+                                       "traffic_source": traffic_note,
                                        "kernel": "conv64_kernel (bf16: conv1_1+conv1_2 fused, conv2_1) + gemm8p_kernel<*,CONV3,*,F8> (e4m3: conv2_2..conv5_3): 12 "
                                                  "launches per VGG forward, timed while the beam search of the previous pass runs beside them",
                                        "avg_launch_ms": 1e3 * avg_launch_s, "flops_per_launch": flops_per_launch}}))

@@ -13,7 +13,7 @@ python3 bench.py > "$out/bench_line.json" 2> "$out/bench.err" || { tail "$out/be
 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > "$out/bench_line_driver_shape.json" 2>> "$out/bench.err"
 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --inputs hbm > "$out/bench_line_driver_shape_inputs_hbm.json" 2>> "$out/bench.err"
 python3 bench.py --emulate-world 8 --steps 96 --warmup 16 --no-cpu-baseline > "$out/bench_line_emulated_rank_of_8.json" 2>> "$out/bench.err"
-python3 bench.py --emulate-world 8 --steps 96 --warmup 16 --no-cpu-baseline --shard-adam > "$out/bench_line_emulated_rank_of_8_sharded_update.json" 2>> "$out/bench.err"
+python3 bench.py --emulate-world 8 --steps 96 --warmup 16 --no-cpu-baseline --replicated-update > "$out/bench_line_emulated_rank_of_8_replicated_update.json" 2>> "$out/bench.err"
 python3 bench.py --emulate-world 8 --steps 96 --warmup 16 --no-cpu-baseline --vgg-chunk-images 0 > "$out/bench_line_emulated_rank_of_8_one_forward_per_step.json" 2>> "$out/bench.err"
 python3 bench.py --emulate-world 8 --steps 20 --warmup 5 --no-cpu-baseline > "$out/bench_line_emulated_rank_of_8_driver_shape.json" 2>> "$out/bench.err"
 python3 bench.py --emulate-world 4 --steps 48 --warmup 16 --no-cpu-baseline > "$out/bench_line_emulated_rank_of_4.json" 2>> "$out/bench.err"
@@ -28,13 +28,16 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/write" -o
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats32" -o p -- python3 "$root/bench.py" --emulate-world 8 --steps 48 --warmup 16 --no-cpu-baseline > "$out/bench_under_rocprof_b32.json" 2> "$out/stats32.log"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/statsc2" -o p -- python3 "$root/bench.py" --config c2 --steps 20 --warmup 5 --no-cpu-baseline > "$out/bench_under_rocprof_c2.json" 2> "$out/statsc2.log"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/statsc5" -o p -- python3 "$root/bench.py" --config c5 --steps 30 > "$out/bench_under_rocprof_c5.json" 2> "$out/statsc5.log"
+LRCN_C5_LIGHT=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/fetchc5" -o p -- python3 "$root/bench.py" --config c5 --steps 20 > /dev/null 2> "$out/fetchc5.log"
+LRCN_C5_LIGHT=1 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/writec5" -o p -- python3 "$root/bench.py" --config c5 --steps 20 > /dev/null 2> "$out/writec5.log"
 cd "$root"
 cp "$out"/stats/p_kernel_stats.csv "$out/kernel_stats.csv"
 cp "$out"/stats32/p_kernel_stats.csv "$out/kernel_stats_b32.csv"
 cp "$out"/statsc2/p_kernel_stats.csv "$out/kernel_stats_c2.csv"
 cp "$out"/statsc5/p_kernel_stats.csv "$out/kernel_stats_c5.csv"
 python3 tools/pmc_traffic.py "$out"/fetch/p_counter_collection.csv "$out"/write/p_counter_collection.csv "$out/pmc_traffic.json" > /dev/null
-rm -rf "$out/stats" "$out/stats32" "$out/statsc2" "$out/statsc5" "$out/fetch" "$out/write"   # the raw traces are tens of MB; the summaries are what is kept
+python3 tools/pmc_traffic.py "$out"/fetchc5/p_counter_collection.csv "$out"/writec5/p_counter_collection.csv "$out/pmc_traffic_c5.json" > /dev/null
+rm -rf "$out/stats" "$out/stats32" "$out/statsc2" "$out/statsc5" "$out/fetch" "$out/write" "$out/fetchc5" "$out/writec5"   # the raw traces are tens of MB; the summaries are what is kept
 tail -c 1200 "$out/bench_line.json"; echo; python3 - <<PY
 import csv
 rows=list(csv.DictReader(open("$out/kernel_stats.csv")))
