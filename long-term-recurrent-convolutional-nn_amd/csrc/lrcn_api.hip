@@ -145,6 +145,7 @@ struct lrcn_ctx {
     hipStream_t wg_stream = nullptr;
     bool wg_stream_owned = true;   // false: handed in through lrcn_set_wg_stream (not destroyed here)
     hipEvent_t wg_fork[4] = {}, wg_done = nullptr;
+    hipEvent_t xc_fork = nullptr, xc_done = nullptr;  // the image-embedding GEMM of the forward pass on the weight-gradient stream (loss_impl)
     void *wg_ws = nullptr;
     void *pin = nullptr;      // pinned host staging for results larger than HIP's fast pageable-copy path (lrcn_beam_search_batch)
     size_t pin_bytes = 0;
@@ -642,20 +643,45 @@ int loss_impl(lrcn_ctx *c, const float *const p[9], const float *feats, const in
     r = prepare_weights(c, p, bwd, false, epi);
     if (r) return r;
     k_build_tokens(st, tokens, T, B, V, c->tok_in, c->tok_tgt, c->logp);  // reads the caller's (T, B) ids once (T = 0: never)
-    // feats (B x 4096 column-major = memory [4096][B]) -> F [B][4096] (T)
-    k_transpose(st, dt, 1, feats, B, LRCN_CNNOUT, B, c->F, LRCN_CNNOUT, 0);
-    // input = input * param[end-3]   lrcn.jl:558
-    GEMM(c, dt, c->F, LRCN_CNNOUT, c->Wcd, LRCN_CNNOUT, c->xcnn, c->ldh, B, h, LRCN_CNNOUT, nullptr, true);
-    // embeddings of [bos, tokens...] with the :542 dropout.  LRCN-1f: the LSTM input is dropout(hcat(embedding, x_cnn)) -- the
-    // gather fills columns [0, E), the concat kernel appends x_cnn and applies the one mask over all E + h columns
-    {
-        SegScope seg(c, LRCN_SEG_EMBED_GATHER, st, 2.0 * M * E * es);  // (T+1) B rows of E elements read and written
-        k_embed_gather(st, dt, c->WeT, c->ldE, c->tok_in, S, B, E, two ? d1 : none, c->Xemb, c->ldX1);
+    // input = input * param[end-3]   lrcn.jl:558.  The two-layer model needs x_cnn only at LSTM-2's input, after the whole first
+    // recurrence: its three launches (transpose, split-K GEMM, reduce: ~20 us at 32 rows) run on the weight-gradient stream beside that
+    // chain and are joined before the concat (round 5).  Not beside the capped VGG forward from 256 rows (as the weight gradients:
+    // there a second stream of LSTM-side workgroups takes CUs from the convolutions); LRCN_WG_STREAM=0 / 1 forces it off / on.
+    const char *kwgf = getenv("LRCN_WG_STREAM");
+    static const char *kxf = getenv("LRCN_XCNN_FORK");  // development knob: 0 keeps the image embedding on the main stream
+    const bool xfork = two && !(kxf && kxf[0] == '0') && (kwgf ? kwgf[0] != '0' : !(c->vgg_wg_cap >= 8 && c->vgg_loaded && B >= 256));
+    auto image_embedding = [&](hipStream_t s_, bool on_wg) -> int {
+        // feats (B x 4096 column-major = memory [4096][B]) -> F [B][4096] (T)
+        k_transpose(s_, dt, 1, feats, B, LRCN_CNNOUT, B, c->F, LRCN_CNNOUT, 0);
+        return gemm(c, dt, c->F, LRCN_CNNOUT, c->Wcd, LRCN_CNNOUT, c->xcnn, c->ldh, B, h, LRCN_CNNOUT, nullptr, true, false, false, false, on_wg);
+    };
+    int rx = LRCN_OK;
+    if (xfork) {
+        HIPCHK(c, hipEventRecord(c->xc_fork, st));
+        HIPCHK(c, hipStreamWaitEvent(c->wg_stream, c->xc_fork, 0));
+        rx = image_embedding(c->wg_stream, true);
+        (void)hipEventRecord(c->xc_done, c->wg_stream);
+    } else {
+        rx = image_embedding(st, false);
+        if (rx) return rx;
     }
-    if (!two) k_concat_x2(st, dt, c->Xemb, c->ldX1, c->xcnn, c->ldh, S, B, E, h, d1);
-    // LSTM 1
-    GEMM(c, dt, c->Xemb, c->ldX1, c->W1x, c->ldX1, c->G1, 4 * H1, M, 4 * H1, X1, p[1], true);
-    r = lstm_layer_fwd(c, S, B, H1, c->ldH1, c->ld4H1, c->G1, c->W1h, c->A1, c->C1, c->H1all, epi ? c->W1h_gi : nullptr);
+    auto first_layer = [&]() -> int {
+        // embeddings of [bos, tokens...] with the :542 dropout.  LRCN-1f: the LSTM input is dropout(hcat(embedding, x_cnn)) -- the
+        // gather fills columns [0, E), the concat kernel appends x_cnn and applies the one mask over all E + h columns
+        {
+            SegScope seg(c, LRCN_SEG_EMBED_GATHER, st, 2.0 * M * E * es);  // (T+1) B rows of E elements read and written
+            k_embed_gather(st, dt, c->WeT, c->ldE, c->tok_in, S, B, E, two ? d1 : none, c->Xemb, c->ldX1);
+        }
+        if (!two) k_concat_x2(st, dt, c->Xemb, c->ldX1, c->xcnn, c->ldh, S, B, E, h, d1);
+        // LSTM 1
+        GEMM(c, dt, c->Xemb, c->ldX1, c->W1x, c->ldX1, c->G1, 4 * H1, M, 4 * H1, X1, p[1], true);
+        return lstm_layer_fwd(c, S, B, H1, c->ldH1, c->ld4H1, c->G1, c->W1h, c->A1, c->C1, c->H1all, epi ? c->W1h_gi : nullptr);
+    };
+    r = first_layer();
+    if (xfork) {  // joined on EVERY exit: the side chain reads the caller's feats
+        if (hipStreamWaitEvent(st, c->xc_done, 0) != hipSuccess) (void)hipStreamSynchronize(c->wg_stream);
+        if (rx) return rx;
+    }
     if (r) return r;
     const void *Htop = c->H1all;  // the hidden states the logits are computed from
     if (two) {
@@ -987,6 +1013,8 @@ void lrcn_destroy(lrcn_ctx *c) {
     for (auto &e : c->wg_fork)
         if (e) (void)hipEventDestroy(e);
     if (c->wg_done) (void)hipEventDestroy(c->wg_done);
+    if (c->xc_fork) (void)hipEventDestroy(c->xc_fork);
+    if (c->xc_done) (void)hipEventDestroy(c->xc_done);
     if (c->pin) (void)hipHostFree(c->pin);
     if (c->wg_stream && c->wg_stream_owned) (void)hipStreamDestroy(c->wg_stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
@@ -1106,6 +1134,8 @@ int lrcn_create(const lrcn_config *cfg, lrcn_ctx **out) {
         for (auto &e : c->wg_fork)
             if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return LRCN_EHIP;
         if (hipEventCreateWithFlags(&c->wg_done, hipEventDisableTiming) != hipSuccess) return LRCN_EHIP;
+        if (hipEventCreateWithFlags(&c->xc_fork, hipEventDisableTiming) != hipSuccess) return LRCN_EHIP;
+        if (hipEventCreateWithFlags(&c->xc_done, hipEventDisableTiming) != hipSuccess) return LRCN_EHIP;
         if (cfg->max_images > 0) DALLOC(c, c->vgg_ws, c->gemm_ws_bytes);
         for (int i = 0; i < 4; ++i) {
             DALLOC(c, c->st_f32[i], sizeof(float) * B * Hm);
