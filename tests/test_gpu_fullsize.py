@@ -245,7 +245,11 @@ def test_rank_of_8_step_with_four_batches_per_vgg_forward_follows_the_one_per_st
     la, wa = run(m)
     lb, wb = run(1)
     assert np.isfinite(la).all() and la[-1] < la[0]
-    np.testing.assert_allclose(la, lb, rtol=2e-3)
+    # (round 5: the two runs also cut their split-K contractions differently -- the planner fits tiles x slices to the CUs the convolution
+    # grid cap leaves free, 96 at cap 160 with four batches per forward, 32 at cap 224 with one -- so f32 sums are taken in another order,
+    # bf16 roundings flip, and nine Adam steps amplify that: equal at step 1, 2.5e-3 apart at step 9)
+    assert abs(la[0] - lb[0]) <= 1e-5 * abs(lb[0])
+    np.testing.assert_allclose(la, lb, rtol=5e-3)
     # (the parameters themselves are not compared: Adam moves an element by ~lr whatever its gradient's size, so an element whose tiny
     # gradient changes sign between the two runs ends up 2 lr per step apart -- seen: 0.0126 after nine steps)
     assert np.isfinite(wa).all() and np.isfinite(wb).all()
