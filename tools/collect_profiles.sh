@@ -12,7 +12,8 @@ python3 bench.py > "$out/bench_line.json" 2> "$out/bench.err" || { tail "$out/be
 # the driver's own shape (5 warm-up + 20 timed steps) and the other BASELINE configs, one line each
 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > "$out/bench_line_driver_shape.json" 2>> "$out/bench.err"
 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --inputs hbm > "$out/bench_line_driver_shape_inputs_hbm.json" 2>> "$out/bench.err"
-python3 bench.py --emulate-world 8 --steps 96 --warmup 16 --no-cpu-baseline > "$out/bench_line_emulated_rank_of_8.json" 2>> "$out/bench.err"
+python3 bench.py --emulate-world 8 --steps 192 --warmup 32 --no-cpu-baseline > "$out/bench_line_emulated_rank_of_8.json" 2>> "$out/bench.err"
+bash tools/emulated_modes.sh > "$out/emulated_rank_of_8_update_modes.txt" 2>> "$out/bench.err"
 python3 bench.py --emulate-world 8 --steps 96 --warmup 16 --no-cpu-baseline --replicated-update > "$out/bench_line_emulated_rank_of_8_replicated_update.json" 2>> "$out/bench.err"
 python3 bench.py --emulate-world 8 --steps 96 --warmup 16 --no-cpu-baseline --vgg-chunk-images 0 > "$out/bench_line_emulated_rank_of_8_one_forward_per_step.json" 2>> "$out/bench.err"
 python3 bench.py --emulate-world 8 --steps 20 --warmup 5 --no-cpu-baseline > "$out/bench_line_emulated_rank_of_8_driver_shape.json" 2>> "$out/bench.err"
@@ -31,6 +32,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$out/statsc5" -o p -- p
 LRCN_C5_LIGHT=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/fetchc5" -o p -- python3 "$root/bench.py" --config c5 --steps 20 > /dev/null 2> "$out/fetchc5.log"
 LRCN_C5_LIGHT=1 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/writec5" -o p -- python3 "$root/bench.py" --config c5 --steps 20 > /dev/null 2> "$out/writec5.log"
 cd "$root"
+f32=$(find "$out/stats32" -name "*kernel_trace.csv" | head -1)
+python3 tools/beside_vs_alone.py "$f32" 400 > "$out/beside_vs_alone_b32.txt" 2>&1 || true
+python3 tools/step_chain.py "$f32" 3 > "$out/step_chain_b32.txt" 2>&1 || true
 cp "$out"/stats/p_kernel_stats.csv "$out/kernel_stats.csv"
 cp "$out"/stats32/p_kernel_stats.csv "$out/kernel_stats_b32.csv"
 cp "$out"/statsc2/p_kernel_stats.csv "$out/kernel_stats_c2.csv"
