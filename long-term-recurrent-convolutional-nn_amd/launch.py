@@ -191,10 +191,18 @@ def supervise_rank(script, argv, rungs, stall_s=300.0, rung_s=900.0, is_line=Non
                 th = threading.Thread(target=lambda: out_chunks.append(p.stdout.read()), daemon=True)
                 th.start()
             why = None
+            finished_but_stuck = False
             t_start = time.time()
             while p.poll() is None:
                 time.sleep(0.05)
                 now = time.time()
+                last_stage = ((_read(hb) or "").strip().splitlines() or [""])[-1]
+                if last_stage.endswith(" finished") and now - os.path.getmtime(hb) > float(os.environ.get("LRCN_BENCH_TEARDOWN_S", "20")):
+                    # the rank has measured, reduced and (rank 0) printed; it hangs in its teardown (destroy_process_group, a library's atexit):
+                    # the number stands, the process does not
+                    finished_but_stuck = True
+                    stop_child()
+                    break
                 peers = [r for r in range(world) if r != rank and (_read(os.path.join(rdv, "rung%d.rank%d.rc" % (k, r))) or "0").split()[0] != "0"]
                 if peers:
                     why = "rank %s failed in this rung" % ",".join(map(str, peers))
@@ -209,6 +217,8 @@ def supervise_rank(script, argv, rungs, stall_s=300.0, rung_s=900.0, is_line=Non
             rc = p.wait()
             if rank == 0:
                 th.join(timeout=5)
+            if finished_but_stuck:
+                rc = 0
             mine = 0 if (rc == 0 and why is None) else (rc if rc not in (0, None) else 124)
             _write_atomic(os.path.join(rdv, "rung%d.rank%d.rc" % (k, rank)), "%d %s" % (mine, why or ("exit code %d" % rc if rc else "ok")))
             # the rung's verdict: every rank's code (a rank that stopped its child because a peer failed reports so)

@@ -11,6 +11,7 @@ exists; it measures nothing.  Failure injection (environment):
     LRCN_BENCH_DRYRUN_FAIL_RUNG=name[:rank]  that rank (default: every rank) exits with an error on the named rung
     LRCN_BENCH_DRYRUN_HANG_RUNG=name[:rank]  that rank stops making progress on the named rung (a hung collective)
     LRCN_BENCH_DRYRUN_BAD_SELFCHECK=name     on the named rung rank 1 perturbs a parameter before the self-check (replicas differ)
+    LRCN_BENCH_DRYRUN_HANG_TEARDOWN=name[:rank]  that rank never returns from its teardown AFTER the line has been printed
     LRCN_BENCH_DRYRUN_HANG=path              every rank writes its pid to path.<rank> and sleeps (launcher kill tests)"""
 import json
 import os
@@ -108,6 +109,10 @@ def dryrun_rank_main(a, world, rank, local_rank):
               flush=True)
     if world > 1:
         dist.barrier()
+    beat("finished")
+    if _hit(os.environ.get("LRCN_BENCH_DRYRUN_HANG_TEARDOWN"), rung, rank):   # e.g. a destroy_process_group that never returns
+        time.sleep(3600)
+    if world > 1:
         dist.destroy_process_group()
     return 0
 

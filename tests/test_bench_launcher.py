@@ -122,6 +122,19 @@ def test_one_rank_failing_on_the_default_rung_moves_every_rank_to_plain(how):
     assert "rung 'default' failed" in r.stderr
 
 
+def test_a_teardown_that_hangs_after_the_line_does_not_cost_the_rung_its_number():
+    """Rank 1 never returns from its teardown on the first rung, after the timed region, the reduction and rank 0's print: its supervisor stops it
+    after LRCN_BENCH_TEARDOWN_S and the rung still counts -- the line comes from "default", not from a rerun on "plain"."""
+    env = _env()
+    env["LRCN_BENCH_DRYRUN_HANG_TEARDOWN"] = "default:1"
+    env["LRCN_BENCH_TEARDOWN_S"] = "2"
+    env["LRCN_BENCH_STALL_S"] = "60"
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "0"], env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _one_line(r.stdout)
+    assert d["rccl"]["mode"] == "default" and d["rccl"]["rung"] == "1 of 2" and d["rccl"]["fallback_reason"] is None
+
+
 def test_every_rung_failing_is_an_error_without_a_line():
     env = _env()
     env["LRCN_BENCH_DRYRUN_FAIL_ABI"] = "1"
