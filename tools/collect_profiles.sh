@@ -28,7 +28,7 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/fetch" -o
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/write" -o p -- python3 "$root/bench.py" --steps 8 --warmup 2 --no-cpu-baseline > /dev/null 2> "$out/write.log"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats32" -o p -- python3 "$root/bench.py" --emulate-world 8 --steps 48 --warmup 16 --no-cpu-baseline > "$out/bench_under_rocprof_b32.json" 2> "$out/stats32.log"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/statsc2" -o p -- python3 "$root/bench.py" --config c2 --steps 20 --warmup 5 --no-cpu-baseline > "$out/bench_under_rocprof_c2.json" 2> "$out/statsc2.log"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/statsc5" -o p -- python3 "$root/bench.py" --config c5 --steps 30 > "$out/bench_under_rocprof_c5.json" 2> "$out/statsc5.log"
+LRCN_C5_LIGHT=1 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/statsc5" -o p -- python3 "$root/bench.py" --config c5 --steps 30 > "$out/bench_under_rocprof_c5.json" 2> "$out/statsc5.log"
 LRCN_C5_LIGHT=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/fetchc5" -o p -- python3 "$root/bench.py" --config c5 --steps 20 > /dev/null 2> "$out/fetchc5.log"
 LRCN_C5_LIGHT=1 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/writec5" -o p -- python3 "$root/bench.py" --config c5 --steps 20 > /dev/null 2> "$out/writec5.log"
 cd "$root"
