@@ -79,7 +79,9 @@ def main():
     ap.add_argument("--vgg", default="fp8", choices=["fp8", "bf16"])
     ap.add_argument("--overlap", type=int, default=1, help="1: the VGG forward of pass k+1 runs on a side HIP stream (capped "
                     "convolution grids) beside the beam search of pass k, as dp.py does for training; 0: in order on one stream")
-    ap.add_argument("--cap", type=int, default=-1, help="convolution-grid cap for the overlapped VGG forward (-1: 7/8 of the CUs)")
+    ap.add_argument("--cap", type=int, default=0, help="convolution-grid cap for the overlapped VGG forward (0 = none, the default since round 5: here "
+                    "the DECODE is the longer chain -- 27 of a pass's 36 ms -- and a cap of 7/8 of the CUs, training's choice, left it 32 CUs: same-box "
+                    "28.2 k captions/s at 224, 29.1 k uncapped, 27.9 k at 240, 27.5 k without any overlap; -1: 7/8 of the CUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fixture", action="store_true", help="skip the caption-agreement fixture (parity.c5_fixture) after the timed region")
     a = ap.parse_args()
@@ -102,7 +104,9 @@ def main():
     main = torch.cuda.current_stream()
     side = torch.cuda.Stream() if a.overlap else None
     if side is not None:
-        L.vgg_set_wg_cap(ctx, a.cap if a.cap >= 0 else (torch.cuda.get_device_properties(local).multi_processor_count * 7 // 8) & ~7)
+        cap = a.cap if a.cap >= 0 else (torch.cuda.get_device_properties(local).multi_processor_count * 7 // 8) & ~7
+        if cap >= 8:
+            L.vgg_set_wg_cap(ctx, cap)
 
     def vgg_async(k):
         """VGG forward of pass k into fbuf[k & 1]; returns the event the decode of that pass waits for."""
