@@ -20,8 +20,10 @@ struct LstmEpi {
     const float *c_prev;    // [M][H] or NULL (first step of the sequence)
     const float *c_new;     // BWD: [M][H] cell state of step s-1
     float *c_out;           // FWD: [M][H]
-    void *acts;             // FWD: out, BWD: in -- activated gates [M][ld_a], columns [f | i | o | g]
+    void *acts;             // FWD: out (NULL: not kept -- a decode step has no backward pass), BWD: in -- activated gates [M][ld_a], columns [f | i | o | g]
     void *h_new;            // FWD: [M][ld_h]
+    int gx_bcast;           // FWD: 1 = Gx is ONE row [4H] added to every row (the bias of a decode step whose GEMM contracts [x | h] itself)
+    float *h_f32;           // FWD, optional: [M][H] f32 copy of h (the ABI's state arrays)
     const float *dh_ext;    // BWD: [M][H] dh of step s-1 from the layer above / the loss
     float *dc;              // BWD: [M][H] in/out
     void *dz_out;           // BWD: [M][ld_a] dZ of step s-1

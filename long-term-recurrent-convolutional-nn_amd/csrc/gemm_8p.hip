@@ -433,17 +433,21 @@ __device__ __forceinline__ bool gemm8p_tile(const GemmArgs &g, unsigned char *sm
             const f32x4v a = *reinterpret_cast<const f32x4v *>(smem + lrow * (BN * 4) + ((ch ^ (lrow & 31)) << 4));
             if constexpr (EPI == GEMM_OUT_LSTM_FWD) {  // columns 4u .. 4u+3 = the gates f, i, o, g of unit u
                 const int u = col0 >> 2;
-                const float *gx = e.Gx + (int64_t)row * 4 * H + u;
+                const float *gx = e.Gx + (e.gx_bcast ? 0 : (int64_t)row * 4 * H) + u;
                 const float f = sigm8p(a[0] + gx[0]), in = sigm8p(a[1] + gx[H]), o = sigm8p(a[2] + gx[2 * H]), chg = tanhf(a[3] + gx[3 * H]);
                 const float cp = e.c_prev ? e.c_prev[(int64_t)row * H + u] : 0.0f;
                 const float c = cp * f + in * chg;
-                bf16_t *ac = reinterpret_cast<bf16_t *>(e.acts) + (int64_t)row * e.ld_a + u;
-                ac[0] = (bf16_t)f;
-                ac[H] = (bf16_t)in;
-                ac[2 * H] = (bf16_t)o;
-                ac[3 * H] = (bf16_t)chg;
+                if (e.acts) {
+                    bf16_t *ac = reinterpret_cast<bf16_t *>(e.acts) + (int64_t)row * e.ld_a + u;
+                    ac[0] = (bf16_t)f;
+                    ac[H] = (bf16_t)in;
+                    ac[2 * H] = (bf16_t)o;
+                    ac[3 * H] = (bf16_t)chg;
+                }
                 e.c_out[(int64_t)row * H + u] = c;
-                reinterpret_cast<bf16_t *>(e.h_new)[(int64_t)row * e.ld_h + u] = (bf16_t)(o * tanhf(c));
+                const float hv = o * tanhf(c);
+                reinterpret_cast<bf16_t *>(e.h_new)[(int64_t)row * e.ld_h + u] = (bf16_t)hv;
+                if (e.h_f32) e.h_f32[(int64_t)row * H + u] = hv;
             } else {  // columns = four consecutive hidden units (H % 4 == 0 is checked at launch)
                 typedef __bf16 bf16x4e __attribute__((ext_vector_type(4)));
                 const int u = col0;
@@ -1060,8 +1064,8 @@ hipError_t launch_gemm_8p(hipStream_t stream, const GemmArgs &g0, int splitk) {
     if (cfg < 0) return hipErrorInvalidValue;
     gemm_debug_note_route(nullptr, splitk > 1 ? splitk : cfg);
     if (epi == GEMM_OUT_LSTM_FWD || epi == GEMM_OUT_LSTM_BWD) {  // 256 x 128 tiles, cell math in the epilogue
-        if (g.dtype != GEMM_T_BF16 || g.a_mode != GEMM_A_PLAIN || splitk > 1 || cfg != 1 || (g.N & 3) || !g.lstm.acts || g.lstm.H < 1 ||
-            (g.lstm.H & 3) || (g.lstm.ld_a & 3))
+        if (g.dtype != GEMM_T_BF16 || g.a_mode != GEMM_A_PLAIN || splitk > 1 || cfg != 1 || (g.N & 3) ||
+            (!g.lstm.acts && epi == GEMM_OUT_LSTM_BWD) || g.lstm.H < 1 || (g.lstm.H & 3) || (g.lstm.ld_a & 3))
             return hipErrorInvalidValue;
         return epi == GEMM_OUT_LSTM_FWD ? launch_one<4, 2, 2, 2, GEMM_A_PLAIN, true, false, GEMM_OUT_LSTM_FWD>(stream, g, 1)
                                                : launch_one<4, 2, 2, 2, GEMM_A_PLAIN, true, false, GEMM_OUT_LSTM_BWD>(stream, g, 1);

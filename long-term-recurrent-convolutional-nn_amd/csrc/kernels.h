@@ -93,6 +93,9 @@ struct PrepDesc {
     void *dG;
     int64_t ldG;
     int giH;
+    // permH > 0: the DIRECT copies dA / dB are written with their rows in (unit, gate)-interleaved order (source row g*permH + u -> row
+    // 4u + g): the concatenated [x | h] decode weights of the cell-epilogue decode step (round 5)
+    int permH;
 };
 struct PrepPlan {
     PrepDesc d[PREP_MAX];

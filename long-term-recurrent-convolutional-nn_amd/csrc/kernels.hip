@@ -525,19 +525,20 @@ template <typename T, bool ADAM = false> __global__ __launch_bounds__(256) void 
                     if (c + k >= P.cs && c + k < P.C) reinterpret_cast<T *>(P.dG)[(int64_t)rg * P.ldG + (c + k - P.cs)] = from_f32<T>(v[k]);
             }
             const bool sideA = c + 3 < P.cs, sideB = c >= P.cs;
+            const int rd = P.permH > 0 ? (r % P.permH) * 4 + r / P.permH : r;  // destination row of the direct copies
             if (vec && c + 3 < P.C && sideA && alA) {
-                if (P.dA) store4(reinterpret_cast<T *>(P.dA) + (int64_t)r * P.ldA + c, v);
+                if (P.dA) store4(reinterpret_cast<T *>(P.dA) + (int64_t)rd * P.ldA + c, v);
             } else if (vec && c + 3 < P.C && sideB && alB) {
-                if (P.dB) store4(reinterpret_cast<T *>(P.dB) + (int64_t)r * P.ldB + (c - P.cs), v);
+                if (P.dB) store4(reinterpret_cast<T *>(P.dB) + (int64_t)rd * P.ldB + (c - P.cs), v);
             } else {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int cc = c + k;
                     if (cc >= P.C) continue;
                     if (cc < P.cs) {
-                        if (P.dA) reinterpret_cast<T *>(P.dA)[(int64_t)r * P.ldA + cc] = from_f32<T>(v[k]);
+                        if (P.dA) reinterpret_cast<T *>(P.dA)[(int64_t)rd * P.ldA + cc] = from_f32<T>(v[k]);
                     } else if (P.dB) {
-                        reinterpret_cast<T *>(P.dB)[(int64_t)r * P.ldB + (cc - P.cs)] = from_f32<T>(v[k]);
+                        reinterpret_cast<T *>(P.dB)[(int64_t)rd * P.ldB + (cc - P.cs)] = from_f32<T>(v[k]);
                     }
                 }
             }

@@ -384,7 +384,7 @@ void plan_matrices(const lrcn_ctx *c, const float *const p[9], const ShadowSet &
 }
 
 // f32 column-major params -> K-contiguous shadows in T (direct and transposed).  See DESIGN.md "shadow weights".
-int prepare_weights(lrcn_ctx *c, const float *const p[9], bool need_bwd, bool cat = false, bool gi = false) {
+int prepare_weights(lrcn_ctx *c, const float *const p[9], bool need_bwd, bool cat = false, bool gi = false, bool cat_perm = false) {
     const int dt = c->dt, H1 = c->H1, H2 = c->H2, X1 = c->X1;
     if (!p[0] || !p[1] || !p[5] || !p[6] || !p[7] || !p[8] || (c->nl == 2 && (!p[2] || !p[3] || !p[4]))) FAIL(c, LRCN_EINVAL, "null parameter tensor");
     hipStream_t st = c->stream;
@@ -411,13 +411,15 @@ int prepare_weights(lrcn_ctx *c, const float *const p[9], bool need_bwd, bool ca
         }
     }
     if (cat) {  // batched decode: W1 / W2 with the x and h column blocks each padded to whole K-steps, side by side
-        auto add = [&](const float *src, int R, int C, int cs, void *dA, int64_t ldA, void *dB, int64_t ldB) {
+        // cat_perm: the rows in (unit, gate)-interleaved order, for the decode step with the cell math in the GEMM's epilogue
+        auto add = [&](const float *src, int R, int C, int cs, void *dA, int64_t ldA, void *dB, int64_t ldB, int permH) {
             PrepDesc &d = plan.d[plan.n++];
             d = PrepDesc{};
             d.src = src; d.R = R; d.C = C; d.cs = cs; d.dA = dA; d.ldA = ldA; d.dB = dB; d.ldB = ldB;
+            d.permH = cat_perm ? permH : 0;
         };
-        add(p[0], 4 * H1, X1 + H1, X1, c->W1cat, c->ldXH1, boff(c->W1cat, c->ldX1, c->esz), c->ldXH1);
-        if (two) add(p[2], 4 * H2, 2 * H2, H2, c->W2cat, c->ldXH2, boff(c->W2cat, c->ldH2, c->esz), c->ldXH2);
+        add(p[0], 4 * H1, X1 + H1, X1, c->W1cat, c->ldXH1, boff(c->W1cat, c->ldX1, c->esz), c->ldXH1, H1);
+        if (two) add(p[2], 4 * H2, 2 * H2, H2, c->W2cat, c->ldXH2, boff(c->W2cat, c->ldH2, c->esz), c->ldXH2, H2);
     }
     k_prepare_weights(st, dt, plan);
     KCHK(c, "prepare_weights");
@@ -908,10 +910,58 @@ int step_internal(lrcn_ctx *c, const float *const p[9], int B, const DropSpec &d
 // The same step for the batched beam decode, on the concatenated buffers: st_xh1 = [x | h1], st_xh2 = [x2 | h2] (T, the
 // h blocks already hold this step's input states), one GEMM per LSTM against W1cat / W2cat.  LRCN-1f: st_xh1 = [emb | x_cnn | h1]
 // (the caller wrote the x_cnn columns once: they do not change during a decode).
-int step_decode(lrcn_ctx *c, const float *const p[9], int B, const DropSpec &d2) {
+// The batched decode step with the cell math in the gate GEMM's epilogue (gemm_8p.hip GEMM_OUT_LSTM_FWD; round 5): from 256 hypotheses
+// the gate GEMM is a chip-filling contraction (5120 x 4000 x 2048 at 1024 images x 5 beams), and the f32 pre-activations it used to write
+// for a separate cell kernel -- 82 MB out and back per layer and step, plus the kernel -- never leave the workgroup.  The concatenated
+// weights are then made with (unit, gate)-interleaved rows (prepare_weights cat_perm), the bias rides in as a broadcast row, the
+// activated gates are not kept (no backward pass).  LRCN_DECODE_EPI=0: GEMM + cell kernel as before.
+bool decode_epi_on(const lrcn_ctx *c, int B) {
+    const char *k = getenv("LRCN_DECODE_EPI");  // read per call (the tests switch it inside one process)
+    return !(k && k[0] == '0') && c->dt == GEMM_T_BF16 && B >= 256 && !(c->H1 & 3) && !(c->H2 & 3);
+}
+int decode_gates_epi(lrcn_ctx *c, const void *xh, int64_t ldxh, const void *Wcat, int K, const float *bias, int B, int H, float *cstate,
+                     void *hT, float *h_f32) {
+    GemmArgs g{};
+    g.dtype = c->dt;
+    g.A = xh; g.lda = ldxh;
+    g.B = Wcat; g.ldb = ldxh;
+    g.M = B; g.N = 4 * H;
+    g.K = (int)round_up64(K, 64);  // whole 128-byte K-steps: both operands carry zeros in the padding (as gemm() does)
+    if (g.K > ldxh) FAIL(c, LRCN_EINVAL, "decode step: K = %d exceeds the operand rows (%lld)", g.K, (long long)ldxh);
+    g.a_mode = GEMM_A_PLAIN;
+    g.out_mode = GEMM_OUT_LSTM_FWD;
+    g.zero_page = c->zero_page;
+    g.lstm.H = H; g.lstm.ld_a = 4 * H; g.lstm.ld_h = ldxh;
+    g.lstm.Gx = bias; g.lstm.gx_bcast = 1;
+    g.lstm.c_prev = cstate; g.lstm.c_out = cstate;   // in place: every element is read and written by the same thread
+    g.lstm.acts = nullptr;
+    g.lstm.h_new = hT;
+    g.lstm.h_f32 = h_f32;
+    hipError_t e = launch_gemm_8p(c->stream, g);
+    if (e != hipSuccess) FAIL(c, LRCN_EHIP, "decode step (gate GEMM + cell epilogue): %s", hipGetErrorString(e));
+    return LRCN_OK;
+}
+
+int step_decode(lrcn_ctx *c, const float *const p[9], int B, const DropSpec &d2, bool epi = false) {
     const int dt = c->dt, H1 = c->H1, H2 = c->H2, h = c->h, V = c->V;
     hipStream_t st = c->stream;
     void *h1T = boff(c->st_xh1, c->ldX1, c->esz), *h2T = boff(c->st_xh2, c->ldH2, c->esz);
+    if (epi) {
+        int r = decode_gates_epi(c, c->st_xh1, c->ldXH1, c->W1cat, (int)c->ldX1 + H1, p[1], B, H1, c->st_f32[1], h1T, c->st_f32[0]);
+        if (r) return r;
+        if (c->nl == 1) {
+            GEMM(c, dt, h1T, c->ldXH1, c->Wod, c->ldH2, c->st_logits, c->ldV, B, V, H2, p[8], true);
+            KCHK(c, "step_decode (1 layer, cell epilogue)");
+            return LRCN_OK;
+        }
+        GEMM(c, dt, h1T, c->ldXH1, c->Wpd, c->ldH1, c->st_xh2, c->ldXH2, B, h, H1, nullptr, false);
+        k_concat_x2(st, dt, c->st_xh2, c->ldXH2, c->xcnn, c->ldh, 1, B, h, h, d2);
+        r = decode_gates_epi(c, c->st_xh2, c->ldXH2, c->W2cat, (int)c->ldH2 + H2, p[3], B, H2, c->st_f32[3], h2T, c->st_f32[2]);
+        if (r) return r;
+        GEMM(c, dt, h2T, c->ldXH2, c->Wod, c->ldH2, c->st_logits, c->ldV, B, V, H2, p[8], true);
+        KCHK(c, "step_decode (cell epilogue)");
+        return LRCN_OK;
+    }
     GEMM(c, dt, c->st_xh1, c->ldXH1, c->W1cat, c->ldXH1, c->st_g, 4 * H1, B, 4 * H1, (int)c->ldX1 + H1, p[1], true);
     k_lstm_fwd(st, dt, c->st_g, 4 * H1, c->st_f32[1], B, H1, c->st_a, c->ld4H1, c->st_f32[1], h1T, c->ldXH1, c->st_f32[0]);
     if (c->nl == 1) {
@@ -1734,7 +1784,8 @@ int lrcn_beam_search_batch(lrcn_ctx *c, const float *const p[9], const float *fe
     const int dt = c->dt, E = c->E, H1 = c->H1, H2 = c->H2, h = c->h, V = c->V;
     const int R = N * K, Lh = nword + 2;
     hipStream_t st = c->stream;
-    int r = prepare_weights(c, p, false, true);
+    const bool epi = decode_epi_on(c, R);
+    int r = prepare_weights(c, p, false, true, false, epi);
     if (r) return r;
     // input = input * param[end-3] per image (lrcn.jl:611), each row repeated for the image's K hypotheses
     k_transpose(st, dt, 1, feats, N, LRCN_CNNOUT, N, c->F, LRCN_CNNOUT, 0);
@@ -1755,7 +1806,7 @@ int lrcn_beam_search_batch(lrcn_ctx *c, const float *const p[9], const float *fe
     int cur = 0;
     for (int current = 1; current <= nword + 1; ++current) {
         k_embed_gather(st, dt, c->WeT, c->ldE, c->bs_last, 1, R, E, none, c->st_xh1, c->ldXH1);  // lrcn.jl:650
-        r = step_decode(c, p, R, none);                                                     // :651, all N*K hypotheses batched
+        r = step_decode(c, p, R, none, epi);                                                // :651, all N*K hypotheses batched
         if (r) return r;
         if (!k_softmax_topk_rows(st, c->st_logits, c->ldV, R, V, K, c->st_topi, c->st_topv)) {  // :652, :655-656 in one pass
             k_softmax_rows(st, c->st_logits, c->ldV, R, V, c->st_prob, c->ldV);

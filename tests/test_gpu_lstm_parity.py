@@ -498,3 +498,47 @@ def test_bf16_single_step_and_beam_search_vs_emulating_oracle():
             assert abs(p - rp) <= 5e-2 * abs(rp) + 1e-30, (i, p, rp)
     assert same >= 4, same   # a near-tie may still fall the other way in bf16: at most one of five
     ctx.close()
+
+
+@pytest.mark.parametrize("E,H,V,N,K,layers", [(64, 64, 301, 64, 5, 2), (48, 96, 517, 90, 3, 2), (64, 64, 301, 60, 5, 1), (1000, 1000, 10640, 52, 5, 2)])
+def test_batched_decode_with_the_cell_epilogue_equals_gemm_plus_cell_kernel(E, H, V, N, K, layers, monkeypatch):
+    # Round 5: from 256 hypotheses the batched beam search runs its gate GEMMs with the cell math in the epilogue (gemm_8p.hip
+    # GEMM_OUT_LSTM_FWD on (unit, gate)-interleaved concatenated weights, bias as a broadcast row, no activations kept) instead of GEMM ->
+    # f32 pre-activations -> cell kernel.  Same arithmetic per element; the contraction may be summed in another order (another tile
+    # shape), so with decisive distributions the decodes must agree on (nearly) every image and in probability, and both must agree with
+    # the bf16-EMULATING oracle's decode (generate / beam_search, lrcn.jl:585-678) on the images the oracle is run on.
+    # N * K = 320 / 270 / 300 / 260 rows (M tails of the 256-row tile), H = 96: 384 interleaved columns = three 128-column tiles,
+    # LRCN-1f, and BASELINE configs[4]'s own dimensions.
+    rng = np.random.default_rng(E + V + N)
+    m = orc.init_weights(E, H, H, V, seed=4, n_layers=layers)
+    for n in ("W1", "W2", "Wout"):
+        if m.p[n].size:
+            m.p[n] *= 2.0
+    m.p["Wout"][:] *= 3.0 if H < 1000 else 8.0
+    m.p["bout"][:] = (rng.standard_normal((1, V)) * 2.0).astype(np.float32)
+    m.p["b1"][:] += (rng.standard_normal(m.p["b1"].shape) * 0.5).astype(np.float32)   # a bias that matters: it rides in as the broadcast row
+    feats = (rng.standard_normal((N, 4096)) * 0.05).astype(np.float32)
+    nword = 8
+    ctx = L.Context(E, H, H, V, max_B=N * K, max_T=2, lstm_dtype=lrcn_amd.LRCN_BF16, n_layers=layers)
+    param = L.model_from_arrays(m.p)
+    out = {}
+    for knob in ("1", "0"):
+        monkeypatch.setenv("LRCN_DECODE_EPI", knob)
+        out[knob] = L.beam_search_batch(ctx, param, L.to_jl(feats), K, nword)
+    same = sum(a[0] == b[0] for a, b in zip(out["1"], out["0"]))
+    assert same >= N - max(1, N // 20), (same, N)
+    for (ta, pa), (tb, pb) in zip(out["1"], out["0"]):
+        if ta == tb:
+            assert abs(pa - pb) <= 2e-2 * abs(pb) + 1e-30
+        else:
+            assert abs(np.log(pa + 1e-300) - np.log(pb + 1e-300)) < 0.3   # only a near-tie may fall the other way
+    if H < 1000:
+        agree = 0
+        for i in range(6):
+            with orc.emulate_bf16():
+                rt, rp = orc.beam_search(m, feats[i], K, nword)
+            if out["1"][i][0] == list(rt):
+                agree += 1
+                assert abs(out["1"][i][1] - rp) <= 5e-2 * abs(rp) + 1e-30
+        assert agree >= 5, agree
+    ctx.close()
