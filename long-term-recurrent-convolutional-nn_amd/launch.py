@@ -268,4 +268,15 @@ def supervise_rank(script, argv, rungs, stall_s=300.0, rung_s=900.0, is_line=Non
         stop_child()
         for sg, h in old.items():
             signal.signal(sg, h)
+        # the rendezvous directory goes when every supervisor has left it (rank 0 waits briefly for the others' exit marks)
+        try:
+            _write_atomic(os.path.join(rdv, "exit.rank%d" % rank), "1")
+            if rank == 0:
+                t0 = time.time()
+                while time.time() - t0 < 3 and any(_read(os.path.join(rdv, "exit.rank%d" % r)) is None for r in range(world)):
+                    time.sleep(0.05)
+                import shutil
+                shutil.rmtree(rdv, ignore_errors=True)
+        except OSError:
+            pass
     return rc_final
