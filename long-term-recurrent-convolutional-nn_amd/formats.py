@@ -8,6 +8,9 @@
     `get_params_cnn` (`:697-721`) up to and including `fc7` and returns the arrays `lrcn_vgg_load` takes.
   * Karpathy features (`feature_extractor.jl:13-50`): `dataset.json` + `vgg_feats.mat` (`feats` 4096 x N, column
     `imgid + 1`) -> {integer filename stem: float32[4096]}; the feature dictionary itself is stored as `.npz`.
+  * a trained REFERENCE model / feature dictionary: `julia/export_jld_to_npy.jl` (run where Julia + JLD exist) writes the `.jld`
+    payloads as plain `.npy` files by hand; `load_npy_dir` / `load_feature_npy_dir` (and load_checkpoint / load_features given a
+    directory) read them.
   * crops: `center_crop_224` restates `read_image_data`'s geometry (`lrcn.jl:755-765`): resize so that the shorter side is
     224 (integer `div`), centre crop, grey -> 3 channels; returns the uint8 `[row][col][3]` crop that
     `lrcn_vgg_forward_u8` consumes (the float arithmetic `255 x - averageImage` and the H/W swap happen on the GPU).
@@ -40,6 +43,8 @@ def save_checkpoint(path, model, vocab, adam=None, meta=None):
 
 def load_checkpoint(path):
     """-> (model list of 9 float32 arrays, vocab dict, adam dict or None, meta dict)."""
+    if os.path.isdir(path):   # a reference .jld exported by julia/export_jld_to_npy.jl
+        return load_npy_dir(path)
     z = np.load(path, allow_pickle=False)  # a checkpoint is data: nothing in it may execute on load
     model = [z["param_%d_%s" % (i, n)] for i, n in enumerate(PARAM_NAMES)]
     if "vocab_json" in z.files:
@@ -55,6 +60,49 @@ def load_checkpoint(path):
     return model, vocab, adam, json.loads(str(z["meta"]))
 
 
+def load_npy_dir(path):
+    """A trained REFERENCE model exported from its `.jld` file by `julia/export_jld_to_npy.jl` (the reference saves `model` + `vocab` as
+    JLD/HDF5, lrcn.jl:183-186, 228-231, and this image has no HDF5 reader): a directory with `param_<k>_<name>.npy` -- the nine arrays
+    of `initweights` (lrcn.jl:489-510) in Julia's column-major order, `fortran_order: True`, so NumPy sees the reference's shapes --
+    and `vocab.tsv` (word TAB 1-based id, lrcn.jl:248-255).  -> (model list of 9 float32 arrays, vocab dict, None, meta dict), the
+    tuple load_checkpoint returns (no optimizer state: the reference never saved any)."""
+    model = []
+    for i, n in enumerate(PARAM_NAMES):
+        a = np.load(os.path.join(path, "param_%d_%s.npy" % (i, n)), allow_pickle=False)
+        if a.dtype != np.float32 or a.ndim != 2:
+            raise ValueError("%s: expected a 2-D float32 array, got %s %s" % (n, a.dtype, a.shape))
+        model.append(a)
+    E_H1, H1x4 = model[0].shape
+    if model[1].shape != (1, H1x4) or model[6].shape[1] != E_H1 - H1x4 // 4 or model[7].shape[1] != model[6].shape[0] or \
+            model[8].shape != (1, model[6].shape[0]):
+        raise ValueError("the nine arrays do not have initweights' shapes (lrcn.jl:489-510): %s" % [m.shape for m in model])
+    vocab = {}
+    with open(os.path.join(path, "vocab.tsv"), encoding="utf-8") as f:
+        for line in f:
+            line = line.rstrip("\n")
+            if not line:
+                continue
+            w, i = line.rsplit("\t", 1)
+            vocab[w] = int(i)
+    if len(vocab) != model[6].shape[0]:
+        raise ValueError("vocab.tsv holds %d words, Wembed has %d rows" % (len(vocab), model[6].shape[0]))
+    return model, vocab, None, {"source": "exported from a reference .jld by julia/export_jld_to_npy.jl"}
+
+
+def load_feature_npy_dir(path, normalize=False):
+    """A reference feature dictionary (`Dict{Int,Array{Float32}}`, lrcn.jl:206-207, 220; feature_extractor.jl:50) exported by
+    `julia/export_jld_to_npy.jl feats`: `feature_ids.npy` (int64) + `features.npy` (4096 x N).  -> {image id: float32[4096]}."""
+    ids = np.load(os.path.join(path, "feature_ids.npy"), allow_pickle=False)
+    m = np.load(os.path.join(path, "features.npy"), allow_pickle=False)
+    if m.ndim != 2 or m.shape[0] != 4096 or m.shape[1] != ids.shape[0]:
+        raise ValueError("features.npy must be 4096 x %d, got %s" % (ids.shape[0], m.shape))
+    out = {}
+    for j, i in enumerate(ids):
+        f = np.ascontiguousarray(m[:, j], dtype=np.float32)
+        out[int(i)] = f / f.sum() if normalize else f
+    return out
+
+
 def save_features(path, feats):
     """feats: {image id: float32[4096]} (the reference's Dict{Int,Array{Float32}} saved as feats.jld)."""
     ids = np.array(sorted(feats), dtype=np.int64)
@@ -64,6 +112,8 @@ def save_features(path, feats):
 def load_features(path, normalize=False):
     """-> {image id: float32[4096]}.  normalize=True divides each vector by its sum, which is what the reference's
     `featsn` files hold and what `generate` does for fresh images (`lrcn.jl:597`)."""
+    if os.path.isdir(path):   # a reference feature dictionary exported by julia/export_jld_to_npy.jl
+        return load_feature_npy_dir(path, normalize)
     z = np.load(path)
     out = {}
     for i, f in zip(z["ids"], z["feats"]):

@@ -300,3 +300,56 @@ def test_cli_flag_surface():
                  "--batchsize", "--lr", "--gclip", "--seed", "--atype", "--train", "--cnn", "--extfeatures", "--flickr", "--coco",
                  "--beam_width", "--bestfile"):
         assert flag in out.stdout
+
+
+def _write_npy_like_the_julia_exporter(path, a):
+    """Byte for byte what julia/export_jld_to_npy.jl's write_npy emits (that script cannot run here: no Julia): magic, version 1.0, uint16
+    header length, the dict with fortran_order True and the shape as Julia prints it, space padding to a multiple of 64, newline, then the
+    array's COLUMN-MAJOR memory image."""
+    a = np.asarray(a)
+    descr = {"float32": "<f4", "int64": "<i8"}[a.dtype.name]
+    shape = ", ".join(str(n) for n in a.shape) + ("," if a.ndim == 1 else "")
+    d = "{'descr': '%s', 'fortran_order': True, 'shape': (%s), }" % (descr, shape)
+    pad = (64 - (10 + len(d) + 1) % 64) % 64
+    header = d + " " * pad + "\n"
+    with open(path, "wb") as f:
+        f.write(b"\x93NUMPY\x01\x00")
+        f.write(np.uint16(len(header)).tobytes())
+        f.write(header.encode("latin1"))
+        f.write(np.asfortranarray(a).tobytes(order="F"))
+
+
+def test_reference_jld_export_directory_loads(tmp_path):
+    # a trained reference model exported by julia/export_jld_to_npy.jl (JLD/HDF5 cannot be read in this image): the directory format
+    # formats.load_npy_dir / load_feature_npy_dir read, written here exactly as the Julia script writes it
+    from lrcn_amd import formats as fmt
+    from lrcn_amd import lrcn as L
+    rng = np.random.default_rng(0)
+    E, H, V = 12, 8, 23
+    model = [rng.standard_normal(tuple(sh)).astype(np.float32) for sh in L.param_shapes(E, H, H, V)]
+    d = tmp_path / "model_npy"
+    d.mkdir()
+    for k, (n, a) in enumerate(zip(fmt.PARAM_NAMES, model)):
+        _write_npy_like_the_julia_exporter(str(d / ("param_%d_%s.npy" % (k, n))), a)
+    words = ["~~", "``", "##"] + ["w%d" % i for i in range(V - 3)]
+    (d / "vocab.tsv").write_text("".join("%s\t%d\n" % (w, i + 1) for i, w in enumerate(words)), encoding="utf-8")
+    got, vocab, adam, meta = fmt.load_checkpoint(str(d))       # a directory goes to load_npy_dir
+    assert adam is None and "jld" in meta["source"]
+    for a, b in zip(got, model):
+        assert a.shape == b.shape and a.dtype == np.float32
+        np.testing.assert_array_equal(a, b)
+    assert vocab["~~"] == 1 and vocab["``"] == 2 and vocab["##"] == 3 and len(vocab) == V
+    (d / "vocab.tsv").write_text("only\t1\n", encoding="utf-8")
+    with pytest.raises(ValueError):
+        fmt.load_npy_dir(str(d))
+    # feature dictionary: ids + a 4096 x N matrix
+    f = tmp_path / "feats_npy"
+    f.mkdir()
+    ids = np.array([7, 42, 100003], np.int64)
+    m = rng.random((4096, 3)).astype(np.float32)
+    _write_npy_like_the_julia_exporter(str(f / "feature_ids.npy"), ids)
+    _write_npy_like_the_julia_exporter(str(f / "features.npy"), m)
+    feats = fmt.load_features(str(f))
+    assert sorted(feats) == [7, 42, 100003]
+    np.testing.assert_array_equal(feats[42], m[:, 1])
+    np.testing.assert_allclose(fmt.load_features(str(f), normalize=True)[7].sum(), 1.0, rtol=1e-5)
