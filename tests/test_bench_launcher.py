@@ -215,3 +215,26 @@ def test_ranks_never_outlive_the_launcher(tmp_path, how):
             break
         time.sleep(0.1)
     assert not alive, alive
+
+
+def test_sub_reports_and_rungs_are_plain_functions():
+    """roofline.sub is arithmetic on lrcn_profile_segment's accumulators (bench.sub_reports), and the ladder's rung list is data
+    (launch.default_rungs): both checked without a GPU."""
+    import importlib
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    from lrcn_amd import launch
+    segs = {"update": (2.0, 8, 8 * 1.116e9), "rec_fwd": (8.0, 16, 16 * 88e6), "rec_bwd": (0.0, 0, 0.0), "embed_gather": (0.16, 8, 8 * 12.3e6),
+            "embed_grad": (0.72, 8, 8 * 54.8e6), "preprocess": (0.2, 8, 8 * 115.6e6), "upload": (5.6, 8, 8 * 38.5e6)}
+    sub = bench.sub_reports(segs, 8)
+    assert "recurrence_weight_stream_bwd" not in sub                      # a segment that never ran is not reported
+    assert abs(sub["adam"]["GB/s"] - 4464.0) < 1.0 and sub["adam"]["peak_GB/s"] == 8000.0 and abs(sub["adam"]["frac_of_peak"] - 0.558) < 1e-3
+    assert sub["upload"]["peak_GB/s"] == 64.0 and abs(sub["upload"]["GB/s"] - 55.0) < 0.1   # the upload is priced against PCIe, not HBM
+    assert abs(sub["adam"]["ms_per_step"] - 0.25) < 1e-9 and abs(sub["adam"]["algorithmic_MB_per_step"] - 1116.0) < 1e-6
+    names = [r[0] for r in launch.default_rungs("torch")]
+    assert names == ["default", "plain"] and [r[0] for r in launch.default_rungs("auto")] == ["abi", "default", "plain"]
+    plain = dict(launch.default_rungs("abi"))["plain"]
+    assert plain["LRCN_DP_BACKEND"] == "torch" and plain["LRCN_DP_BUCKETS"] == "0" and plain["LRCN_DP_SPARSE_EMBED"] == "0" and plain["LRCN_FUSED_UPDATE"] == "0"
+    a = bench.parse_args(["--emulate-world", "8"])
+    assert a.emulate_world == 8 and not a.replicated_update and bench.metric_name(a).startswith("EMULATED")
+    assert bench.metric_name(bench.parse_args([])) == bench.HEADLINE_METRIC
