@@ -384,8 +384,9 @@ def rank_main(a, world, rank, local_rank):
     rows = dp.shard_rows(Bg, world * a.emulate_world, rank)
     B = rows.stop - rows.start
 
+    plain_rung = os.environ.get("LRCN_BENCH_RUNG") == "plain"   # the ladder's last rung: command-line choices that would make it less plain do not apply
     # training batches per VGG forward: 8 at 32 rows per GPU, 4 at 64; one from 128 rows (measured: no gain there, dp.vgg_wg_cap_for)
-    m_chunk = max(1, a.vgg_chunk_images // B) if B <= 64 else 1
+    m_chunk = max(1, a.vgg_chunk_images // B) if (B <= 64 and not plain_rung) else 1
     m_chunk = 1 << (m_chunk.bit_length() - 1)   # a power of two of batches (tile counts stay round: 160 images measured slower than 128)
     while a.steps % m_chunk:   # ... that divides the timed step count: the timed region then holds exactly K batches of VGG forward and K LSTM steps
         m_chunk //= 2
@@ -399,7 +400,7 @@ def rank_main(a, world, rank, local_rank):
     # one process: rank 0's side of the sharded update, collectives stubbed by copies (the default form of an emulated rank since round 5)
     emu_shard = a.emulate_world > 1 and not a.replicated_update and (bool(a.shard_adam) or os.environ.get("LRCN_DP_SHARD_ADAM", "1")[:1] != "0")
     trainer = dp.DataParallelTrainer(ctx, param, optim, Bg, world, rank, pdrop=a.pdrop, seed=7, backend=backend,
-                                     shard_adam=(bool(a.shard_adam) and world > 1) or emu_shard, vgg_chunk=m_chunk, rows=B,
+                                     shard_adam=(bool(a.shard_adam) and world > 1 and not plain_rung) or emu_shard, vgg_chunk=m_chunk, rows=B,
                                      emulate_shards=a.emulate_world if emu_shard else 0)
 
     # synthetic inputs: uint8 crops uniform seed 1234; Zipf(1.0) word ids >= 3, seed 7; one T per batch

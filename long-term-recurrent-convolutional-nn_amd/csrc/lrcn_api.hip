@@ -396,6 +396,7 @@ int prepare_weights(lrcn_ctx *c, const float *const p[9], bool need_bwd, bool ca
         if (same) return LRCN_OK;
     }
     c->shadow_valid = false;
+    c->refresh_groups = 0;  // a full shadow pass supersedes a per-group refresh sequence that was left unfinished
     PrepPlan plan{};
     if (gi) {
         if (!c->W1h_gi) DALLOC(c, c->W1h_gi, c->esz * 4 * H1 * c->ldH1);

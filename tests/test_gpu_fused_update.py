@@ -99,3 +99,52 @@ def test_options_are_validated():
     ok, why = L.comm_probe(ctx)
     assert ok, why
     ctx.close()
+
+
+@pytest.mark.parametrize("n_layers", [2, 1])
+def test_shadows_refreshed_per_group_equal_the_shadow_pass(n_layers):
+    """lrcn_refresh_shadows_group (rev 5): a host that updates the parameters itself (the sharded update: lrcn_adam_update_flat on slices)
+    refreshes the next step's shadow weights group by group; once all five groups are in, the next lossgradient must skip its shadow
+    pass and give BIT-identical gradients to the same call after lrcn_params_touched (which makes the shadows afresh); an unfinished
+    sequence (four of five groups) must NOT be taken for a finished one, neither now nor after a later complete sequence."""
+    E, H, V, B, T = 72, 64, 301, 6, 5
+    rng = np.random.default_rng(9)
+    ctx = L.Context(E, H, H, V, max_B=B, max_T=T, lstm_dtype=lrcn_amd.LRCN_BF16, n_layers=n_layers)
+    ctx.set_option(_lib.LRCN_OPT_FUSED_UPDATE, 1)
+    param = L.initweights(ctx, seed=3)
+    feats = L.to_jl((rng.standard_normal((B, 4096)) * 0.05).astype(np.float32))
+    toks = rng.integers(0, V, size=(T, B)).astype(np.int32)
+    mask1 = ((rng.random((T + 1, B, E if n_layers == 2 else E + H // 2)) > 0.4) / 0.6).astype(np.float32)
+    mask2 = ((rng.random((T + 1, B, H)) > 0.4) / 0.6).astype(np.float32) if n_layers == 2 else None
+
+    def grads_now():
+        g, val = L.lossgradient(ctx, param, feats, toks, mask1=mask1, mask2=mask2)
+        torch.cuda.synchronize()
+        return val, [L.from_jl(x).copy() for x in g]
+
+    grads_now()                                     # makes the first shadow set from the initial parameters
+    for k, p in enumerate(param):                   # the host changes every parameter itself ...
+        if p.numel():
+            p.mul_(1.0 + 0.01 * (k + 1))
+    for g in (0, 1, 2, 3):                          # ... and refreshes four of the five groups only
+        L.refresh_shadows_group(ctx, param, g)
+    v_partial, g_partial = grads_now()              # must have made its shadows afresh (the sequence was unfinished)
+    ctx.params_touched()
+    v_ref, g_ref = grads_now()
+    assert v_partial == v_ref
+    for n, a, b in zip(L.PARAM_NAMES, g_partial, g_ref):
+        if n != "Wembed":                           # (a float-atomic scatter: order-dependent in its last bits)
+            np.testing.assert_array_equal(a, b, err_msg=n)
+    for p in param:
+        if p.numel():
+            p.mul_(0.97)
+    for g in (4, 2, 0, 1, 3):                       # all five, any order: the refreshed set becomes current
+        L.refresh_shadows_group(ctx, param, g)
+    v_new, g_new = grads_now()
+    ctx.params_touched()
+    v_ref2, g_ref2 = grads_now()
+    assert v_new == v_ref2 and v_new != v_ref
+    for n, a, b in zip(L.PARAM_NAMES, g_new, g_ref2):
+        if n != "Wembed":
+            np.testing.assert_array_equal(a, b, err_msg=n)
+    ctx.close()
