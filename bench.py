@@ -508,6 +508,10 @@ def rank_main(a, world, rank, local_rank):
     _lib.check(ctx._h, _lib.lib().lrcn_profile_get(ctx._h, C.byref(conv_ms), C.byref(conv_n)))
     _lib.check(ctx._h, _lib.lib().lrcn_profile(ctx._h, 0))
     loss = trainer.loss_value()
+    if getattr(trainer, "_tail_events", None):   # LRCN_DP_DEBUG_TAIL=1 (development)
+        tails = [a_.elapsed_time(b_) for a_, b_ in trainer._tail_events[-a.steps:]]
+        print("update chain past the end of the backward pass, ms per step: median %.3f min %.3f max %.3f  first16 %s" % (
+            sorted(tails)[len(tails) // 2], min(tails), max(tails), [round(t, 3) for t in tails[:16]]), file=sys.stderr)
     # SURVEY 8(d)'s HBM-bound sub-reports, from a SEPARATE untimed pass of the same pipeline (the event pairs of lrcn_profile level 2 sit
     # between dependent launches and would cost the timed step a few microseconds each): rank 0 of a one-rank job only
     sub = None

@@ -741,6 +741,10 @@ class DataParallelTrainer:
         [reduce-scatter(SUM)] -> [Adam on this rank's slice] -> [all-gather of the parameters]; then one join."""
         if self._bucket_streams is None:
             self._bucket_streams = self._make_update_streams()
+        tail = os.environ.get("LRCN_DP_DEBUG_TAIL")   # development: how long the update chain runs past the end of the backward pass
+        if tail:
+            e_bwd = torch.cuda.Event(enable_timing=True)
+            e_bwd.record(torch.cuda.current_stream(self.ctx.device))
         self.optim.t += 1
         W, r = self._W, self.rank
         # a one-rank process group given explicitly (tests on a one-GPU box): the collectives are issued all the same
@@ -780,6 +784,10 @@ class DataParallelTrainer:
                             self.flat_param[a + i * n:a + (i + 1) * n].copy_(t)
                 if self._shadow_groups:   # the group's parameters are final on this stream: its shadows for the next step, beside the backward pass
                     self.ops.refresh_shadows_group(self.param, k, s)
+        if tail:
+            e_upd = torch.cuda.Event(enable_timing=True)
+            e_upd.record(self._bucket_streams[-1])
+            self._tail_events = getattr(self, "_tail_events", []) + [(e_bwd, e_upd)]
         self.ops.join(self._bucket_streams)
 
     def describe(self):
