@@ -921,7 +921,9 @@ bool decode_epi_on(const lrcn_ctx *c, int B) {
     return !(k && k[0] == '0') && c->dt == GEMM_T_BF16 && B >= 256 && !(c->H1 & 3) && !(c->H2 & 3);
 }
 int decode_gates_epi(lrcn_ctx *c, const void *xh, int64_t ldxh, const void *Wcat, int K, const float *bias, int B, int H, float *cstate,
-                     void *hT, float *h_f32) {
+                     void *h_out, int64_t ld_h_out, float *h_f32) {
+    // h_out must NOT be the h columns of `xh`: every tile of this launch reads them as A-operand columns, and tiles of one row block run in
+    // different rounds (2.5 rounds of 256 x 128 tiles at 5120 x 4000), so an in-place h(t) would reach tiles that still need h(t-1).
     GemmArgs g{};
     g.dtype = c->dt;
     g.A = xh; g.lda = ldxh;
@@ -932,11 +934,11 @@ int decode_gates_epi(lrcn_ctx *c, const void *xh, int64_t ldxh, const void *Wcat
     g.a_mode = GEMM_A_PLAIN;
     g.out_mode = GEMM_OUT_LSTM_FWD;
     g.zero_page = c->zero_page;
-    g.lstm.H = H; g.lstm.ld_a = 4 * H; g.lstm.ld_h = ldxh;
+    g.lstm.H = H; g.lstm.ld_a = 4 * H; g.lstm.ld_h = ld_h_out;
     g.lstm.Gx = bias; g.lstm.gx_bcast = 1;
     g.lstm.c_prev = cstate; g.lstm.c_out = cstate;   // in place: every element is read and written by the same thread
     g.lstm.acts = nullptr;
-    g.lstm.h_new = hT;
+    g.lstm.h_new = h_out;
     g.lstm.h_f32 = h_f32;
     hipError_t e = launch_gemm_8p(c->stream, g);
     if (e != hipSuccess) FAIL(c, LRCN_EHIP, "decode step (gate GEMM + cell epilogue): %s", hipGetErrorString(e));
@@ -948,18 +950,20 @@ int step_decode(lrcn_ctx *c, const float *const p[9], int B, const DropSpec &d2,
     hipStream_t st = c->stream;
     void *h1T = boff(c->st_xh1, c->ldX1, c->esz), *h2T = boff(c->st_xh2, c->ldH2, c->esz);
     if (epi) {
-        int r = decode_gates_epi(c, c->st_xh1, c->ldXH1, c->W1cat, (int)c->ldX1 + H1, p[1], B, H1, c->st_f32[1], h1T, c->st_f32[0]);
+        // the cell epilogue writes h(t) to st_h1 / st_h2 (never into the [x | h] operand it is still reading); k_gather_state rebuilds
+        // the h blocks of st_xh1 / st_xh2 from the f32 states for the next step
+        int r = decode_gates_epi(c, c->st_xh1, c->ldXH1, c->W1cat, (int)c->ldX1 + H1, p[1], B, H1, c->st_f32[1], c->st_h1, c->ldH1, c->st_f32[0]);
         if (r) return r;
         if (c->nl == 1) {
-            GEMM(c, dt, h1T, c->ldXH1, c->Wod, c->ldH2, c->st_logits, c->ldV, B, V, H2, p[8], true);
+            GEMM(c, dt, c->st_h1, c->ldH1, c->Wod, c->ldH2, c->st_logits, c->ldV, B, V, H2, p[8], true);
             KCHK(c, "step_decode (1 layer, cell epilogue)");
             return LRCN_OK;
         }
-        GEMM(c, dt, h1T, c->ldXH1, c->Wpd, c->ldH1, c->st_xh2, c->ldXH2, B, h, H1, nullptr, false);
+        GEMM(c, dt, c->st_h1, c->ldH1, c->Wpd, c->ldH1, c->st_xh2, c->ldXH2, B, h, H1, nullptr, false);
         k_concat_x2(st, dt, c->st_xh2, c->ldXH2, c->xcnn, c->ldh, 1, B, h, h, d2);
-        r = decode_gates_epi(c, c->st_xh2, c->ldXH2, c->W2cat, (int)c->ldH2 + H2, p[3], B, H2, c->st_f32[3], h2T, c->st_f32[2]);
+        r = decode_gates_epi(c, c->st_xh2, c->ldXH2, c->W2cat, (int)c->ldH2 + H2, p[3], B, H2, c->st_f32[3], c->st_h2, c->ldH2, c->st_f32[2]);
         if (r) return r;
-        GEMM(c, dt, h2T, c->ldXH2, c->Wod, c->ldH2, c->st_logits, c->ldV, B, V, H2, p[8], true);
+        GEMM(c, dt, c->st_h2, c->ldH2, c->Wod, c->ldH2, c->st_logits, c->ldV, B, V, H2, p[8], true);
         KCHK(c, "step_decode (cell epilogue)");
         return LRCN_OK;
     }

@@ -220,6 +220,13 @@ def supervise_rank(script, argv, rungs, stall_s=300.0, rung_s=900.0, is_line=Non
             if finished_but_stuck:
                 rc = 0
             mine = 0 if (rc == 0 and why is None) else (rc if rc not in (0, None) else 124)
+            out = "".join(out_chunks)
+            lines = [ln for ln in out.splitlines() if is_line(ln)] if (rank == 0 and is_line) else []
+            if rank == 0 and is_line is not None and mine == 0 and not lines:
+                # a rung that exits 0 everywhere WITHOUT its line has failed, and every supervisor must learn so from the same place: the
+                # verdict below is read from the rc files alone, so rank 0 publishes the missing line as its own non-zero code before any
+                # rank reads (ranks 1..N-1 used to leave with rc 0 while rank 0 went on to the next rung alone)
+                mine, why = 65, "exited 0 but printed no result line"
             _write_atomic(os.path.join(rdv, "rung%d.rank%d.rc" % (k, rank)), "%d %s" % (mine, why or ("exit code %d" % rc if rc else "ok")))
             # the rung's verdict: every rank's code (a rank that stopped its child because a peer failed reports so)
             t0 = time.time()
@@ -234,9 +241,7 @@ def supervise_rank(script, argv, rungs, stall_s=300.0, rung_s=900.0, is_line=Non
                 time.sleep(0.05)
             bad = {r: c for r, c in codes.items() if c.split()[0] != "0"}
             missing = [r for r in range(world) if r not in codes]
-            out = "".join(out_chunks)
-            lines = [ln for ln in out.splitlines() if is_line(ln)] if (rank == 0 and is_line) else []
-            if not bad and not missing and (rank != 0 or lines or is_line is None):
+            if not bad and not missing:
                 if rank == 0:
                     line = lines[-1] if lines else ""
                     if annotate and line:

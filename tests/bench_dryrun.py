@@ -12,6 +12,7 @@ exists; it measures nothing.  Failure injection (environment):
     LRCN_BENCH_DRYRUN_HANG_RUNG=name[:rank]  that rank stops making progress on the named rung (a hung collective)
     LRCN_BENCH_DRYRUN_BAD_SELFCHECK=name     on the named rung rank 1 perturbs a parameter before the self-check (replicas differ)
     LRCN_BENCH_DRYRUN_HANG_TEARDOWN=name[:rank]  that rank never returns from its teardown AFTER the line has been printed
+    LRCN_BENCH_DRYRUN_NO_LINE=name           on the named rung rank 0 finishes with exit code 0 but never prints its line
     LRCN_BENCH_DRYRUN_HANG=path              every rank writes its pid to path.<rank> and sleeps (launcher kill tests)"""
 import json
 import os
@@ -97,7 +98,7 @@ def dryrun_rank_main(a, world, rank, local_rank):
     if selfcheck is not None:
         selfcheck["params_identical_after_last_step"] = bool(trainer.check_replicas()[0])
     loss = trainer.loss_value()
-    if rank == 0:
+    if rank == 0 and os.environ.get("LRCN_BENCH_DRYRUN_NO_LINE") != rung:
         print(json.dumps({"metric": "DRYRUN (CPU stand-ins, gloo) -- " + bench.metric_name(a), "value": Bg * a.steps / dt_s, "unit": "images/sec",
                           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt_s / a.steps, "higher_is_better": True,
                           "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "dryrun",

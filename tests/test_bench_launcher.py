@@ -135,6 +135,57 @@ def test_a_teardown_that_hangs_after_the_line_does_not_cost_the_rung_its_number(
     assert d["rccl"]["mode"] == "default" and d["rccl"]["rung"] == "1 of 2" and d["rccl"]["fallback_reason"] is None
 
 
+def test_a_rung_that_exits_zero_without_its_line_is_left_by_every_rank():
+    """ADVICE r5 (launch.py): all ranks exit 0 on "default" but rank 0 printed nothing.  The verdict must be the same on every supervisor --
+    rank 0 publishes the missing line as its own failure -- so that both ranks rerun on "plain" (before: rank 1 left with rc 0, rank 0
+    raised IndexError / would have gone on alone into a rendezvous nobody joins)."""
+    env = _env()
+    env["LRCN_BENCH_DRYRUN_NO_LINE"] = "default"
+    env["LRCN_BENCH_STALL_S"] = "20"
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"], env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _one_line(r.stdout)
+    assert d["rccl"]["mode"] == "plain" and d["rccl"]["rung"] == "2 of 2" and d["rccl"]["world"] == 2
+    assert "printed no result line" in d["rccl"]["fallback_reason"], d["rccl"]["fallback_reason"]
+    assert "Traceback" not in r.stderr
+    # and on the LAST rung: an error for every rank, no line, no traceback
+    env["LRCN_BENCH_RUNGS_ONLY"] = "plain"
+    env["LRCN_BENCH_DRYRUN_NO_LINE"] = "plain"
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"], env)
+    assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "giving up" in r.stderr and "IndexError" not in r.stderr and "printed no result line" in r.stderr   # (torchrun prints its own ChildFailedError)
+
+
+def test_eight_ranks_walk_the_ladder_with_a_stalled_rank_five():
+    """the shape the driver launches (8 ranks, torchrun form) on CPU stand-ins: rank 5 stops making progress on the
+    default rung; all eight supervisors stop their children and rerun on "plain"; the line carries n_gpus = 8 and a passed self-check."""
+    env = _env()
+    env["LRCN_BENCH_STALL_S"] = "10"
+    env["LRCN_BENCH_DRYRUN_HANG_RUNG"] = "default:5"
+    env["OMP_NUM_THREADS"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", "29631",
+           BENCH, "--gpus", "8", "--steps", "2", "--warmup", "1"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _one_line(r.stdout)
+    rc = d["rccl"]
+    assert d["n_gpus"] == 8 and rc["world"] == 8 and rc["mode"] == "plain" and rc["rung"] == "2 of 2"
+    # (a hung collective stalls EVERY rank at the same stage: the reason names the lowest stalled rank, not necessarily the culprit)
+    assert "default: rank" in rc["fallback_reason"] and "no progress" in rc["fallback_reason"], rc["fallback_reason"]
+    assert rc["selfcheck"]["violations"] == [] and rc["selfcheck"]["params_identical_after_last_step"]
+    assert d["config"]["per_gpu_batch"] == 1
+
+
+def test_eight_ranks_default_rung_self_launched():
+    env = _env()
+    env["OMP_NUM_THREADS"] = "1"
+    r = _run(["--gpus", "8", "--steps", "2", "--warmup", "1"], env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _one_line(r.stdout)
+    assert d["n_gpus"] == 8 and d["rccl"]["mode"] == "default" and d["rccl"]["rung"] == "1 of 2" and d["rccl"]["fallback_reason"] is None
+    assert d["rccl"]["selfcheck"]["violations"] == []
+
+
 def test_every_rung_failing_is_an_error_without_a_line():
     env = _env()
     env["LRCN_BENCH_DRYRUN_FAIL_ABI"] = "1"

@@ -1,0 +1,102 @@
+"""GPU: the batched beam decode (generate / beam_search, lrcn.jl:585-678) at the PRODUCTION shape of BASELINE configs[4] -- a chunk of
+1024 images x 5 beams = 5120 hypotheses, E = H = 1000, V = 10640 -- with the cell math in the gate GEMM's epilogue (gemm_8p.hip
+GEMM_OUT_LSTM_FWD) against the GEMM + cell-kernel decode (LRCN_DECODE_EPI=0) and the bf16-emulating oracle.
+
+Why this file exists: round 5's epilogue wrote h(t) into the h columns of the very [x | h] operand the launch was still
+reading.  5120 x 4000 gates are 640 tiles of 256 x 128 at one workgroup per CU = 2.5 rounds, and the XCD renumbering spreads the tiles of
+one row block over different rounds, so late tiles contracted against h(t) instead of h(t-1).  Every decode test of round 5 had <= 320
+rows (2 row blocks, 64 tiles, one round) and could not see it.  The epilogue now writes to st_h1 / st_h2; these tests pin the shape where
+the race lived, alone and beside a concurrent VGG forward (tiles then trickle, as in tools/caption_bench.py)."""
+import numpy as np
+import pytest
+import torch
+
+import lrcn_amd
+from lrcn_amd import lrcn as L
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+E = H = 1000
+V = 10640
+K, NWORD = 5, 8
+
+
+def decisive_model(seed=4):
+    """Random weights scaled until the word distributions are peaky (no near-ties): a decode is then a function of the state arithmetic,
+    not of which side of a tie a rounding falls on."""
+    rng = np.random.default_rng(seed)
+    m = orc.init_weights(E, H, H, V, seed=seed)
+    for n in ("W1", "W2", "Wout"):
+        m.p[n] *= 2.0
+    m.p["Wout"][:] *= 8.0
+    m.p["bout"][:] = (rng.standard_normal((1, V)) * 2.0).astype(np.float32)
+    m.p["b1"][:] += (rng.standard_normal(m.p["b1"].shape) * 0.5).astype(np.float32)
+    return m
+
+
+def compare(a, b, N):
+    same = sum(x[0] == y[0] for x, y in zip(a, b))
+    assert same >= N - N // 50, (same, N)   # >= 98 %: a near-tie may fall the other way under another summation order
+    for (ta, pa), (tb, pb) in zip(a, b):
+        if ta == tb:
+            assert abs(pa - pb) <= 2e-2 * abs(pb) + 1e-30, (pa, pb)
+        else:
+            assert abs(np.log(pa + 1e-300) - np.log(pb + 1e-300)) < 0.3, (pa, pb)
+    return same
+
+
+@pytest.mark.parametrize("N", [1024, 819])   # 5120 rows = 20 full row blocks; 4095 rows = an M tail in the last of 16
+def test_5120_hypotheses_cell_epilogue_equals_gemm_plus_cell_kernel_and_the_oracle(N, monkeypatch):
+    m = decisive_model()
+    feats = (np.random.default_rng(N).standard_normal((N, 4096)) * 0.05).astype(np.float32)
+    ctx = L.Context(E, H, H, V, max_B=N * K, max_T=2, lstm_dtype=lrcn_amd.LRCN_BF16)
+    param = L.model_from_arrays(m.p)
+    out = {}
+    for knob in ("1", "0", "1"):   # the epilogue decode twice: it must also repeat itself
+        monkeypatch.setenv("LRCN_DECODE_EPI", knob)
+        r = L.beam_search_batch(ctx, param, L.to_jl(feats), K, NWORD)
+        if knob in out:
+            assert [t for t, _ in r] == [t for t, _ in out[knob]], "the epilogue decode does not repeat itself"
+        out[knob] = r
+    compare(out["1"], out["0"], N)
+    # hypotheses spread over the row blocks, against the emulating oracle's per-image decode
+    agree = 0
+    picks = [0, 1, N // 2, N - 2, N - 1]
+    for i in picks:
+        with orc.emulate_bf16():
+            rt, rp = orc.beam_search(m, feats[i], K, NWORD)
+        if out["1"][i][0] == list(rt):
+            agree += 1
+            assert abs(out["1"][i][1] - rp) <= 5e-2 * abs(rp) + 1e-30
+    assert agree >= len(picks) - 1, agree
+    ctx.close()
+
+
+def test_5120_hypotheses_beside_a_concurrent_vgg_forward(monkeypatch):
+    """tools/caption_bench.py's situation: the VGG forward of the next pass runs on a side stream beside the decode, so the decode's tiles
+    trickle onto whatever CUs come free and rounds interleave arbitrarily."""
+    N = 1024
+    m = decisive_model(seed=5)
+    feats = (np.random.default_rng(77).standard_normal((N, 4096)) * 0.05).astype(np.float32)
+    ctx = L.Context(E, H, H, V, max_B=N * K, max_T=2, lstm_dtype=lrcn_amd.LRCN_BF16)
+    vctx = L.Context(8, 8, 8, 17, max_B=2, max_T=1, vgg_dtype=lrcn_amd.LRCN_BF16, max_images=256)
+    L.vgg_load(vctx, *L.synthetic_vgg_weights(seed=1))
+    img = torch.as_tensor(np.random.default_rng(3).integers(0, 256, size=(256, 224, 224, 3), dtype=np.uint8)).cuda()
+    fbuf = L.jl_empty(256, L.CNNOUT)
+    side = torch.cuda.Stream()
+    vctx.use_stream(side)
+    param = L.model_from_arrays(m.p)
+    monkeypatch.setenv("LRCN_DECODE_EPI", "0")
+    alone = L.beam_search_batch(ctx, param, L.to_jl(feats), K, NWORD)
+    monkeypatch.setenv("LRCN_DECODE_EPI", "1")
+    torch.cuda.synchronize()
+    for _ in range(6):   # ~35 ms of convolution launches queued on the side stream: they outlast the decode
+        L.convnet_u8(vctx, img, feats=fbuf)
+    beside = L.beam_search_batch(ctx, param, L.to_jl(feats), K, NWORD)
+    busy = not side.query()
+    torch.cuda.synchronize()
+    compare(beside, alone, N)
+    assert busy, "the VGG forwards finished before the decode: nothing ran beside it"
+    vctx.close()
+    ctx.close()
