@@ -20,7 +20,12 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
 
-FEAT_SCALE = float(os.environ.get("C5_FEAT_SCALE", "0.01"))   # fc7 of the He-normal synthetic VGG is O(100); the reference's own features are O(1) before normalisation
+# fc7 of the He-normal synthetic VGG is O(100).  Round 5 scaled it by 0.01 (features O(1)): the image embedding x_cnn = feats * Wcnn then
+# starts at ~0.8 per element and LSTM-2's gates near saturation, and the loss sits on a plateau at ln(classes) that the optimiser leaves after
+# 600..1100 steps, at a step that moves with the last bits of the gradients.  At 0.003 (measured in round 6, tools/r06/c5_spread2.sh,
+# profiles/r06_c5_fixture_spread.txt: scales 0.0003..0.1 x 5 row-sampling seeds) there is no plateau at all: 9.27 -> 3.4 -> 2.1 -> 1.1 ->
+# 0.5 at steps 0 / 100 / 200 / 300 / 400 for every seed.  (The reference's own features are divided by their sum: O(1e-4).)
+FEAT_SCALE = float(os.environ.get("C5_FEAT_SCALE", "0.003"))
 TARGET_LOSS = float(os.environ.get("C5_TARGET", "0.05"))     # training stops on this loss (two consecutive checks), not on a step count
 MAX_STEPS = int(os.environ.get("C5_MAX_STEPS", "8000"))      # budget: > 5x the slowest escape from the ln(classes) plateau ever observed
 
@@ -117,7 +122,7 @@ def run_fixture(classes=16, train_per_class=8, test_per_class=4, T=8, steps=400,
     N = te_img.shape[0]
     ctx = L.Context(1000, 1000, 1000, V, max_B=max(32, N * K), max_T=T, lstm_dtype=lrcn_amd.LRCN_BF16)
     param, trace, taken = train_decoder(L, lrcn_amd, ctx, tr_feat, caps[tr_id], steps=steps, target=target if (target is None or target > 0) else None, max_steps=max_steps,
-                                        deterministic=deterministic)
+                                        deterministic=deterministic, seed=int(os.environ.get("C5_SEED", "3")))
     dec, feats = {}, {}
     for p in precisions:
         feats[p] = vgg_features(L, lrcn_amd, dts[p], w, te_img, calib=tr_img[:32])

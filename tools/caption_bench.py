@@ -177,7 +177,7 @@ def main():
         if world == 1 and not a.no_fixture:
             ctx.close()   # the fixture builds its own contexts
             import c5_fixture
-            fixture = c5_fixture.run_fixture(steps=1500)
+            fixture = c5_fixture.run_fixture(steps=600)
         # roofline of the dominant kernel family (the 12 convolution launches; SURVEY 8d: 30.693 GFLOP per image): fp8 runs conv2_2..conv5_3
         # (24.972 GF) on e4m3 MFMA and conv1_1 + conv1_2 + conv2_1 (5.721 GF) on bf16 MFMA, so the peak is the FLOP-weighted harmonic blend
         GF_ALL, GF_BF16 = 30.693, 2 * (224 * 224 * 64 * (27 + 576) + 112 * 112 * 128 * 576) / 1e9
