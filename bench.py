@@ -32,6 +32,62 @@ PEAK_BF16_TFLOPS = 2516.0                # MI355X dense bf16 MFMA (MI355X_MICROA
 PEAK_F32_TFLOPS = 157.3
 
 
+class HwSampler:
+    """Shader clock and socket power HELD DURING THE TIMED REGION ("a 7.19 ms lease is explained by a number").  A host
+    thread reads the amdgpu hwmon nodes of this rank's device -- freq1_input (sclk, Hz) and power1_input (socket power, microwatts) under
+    /sys/bus/pci/devices/<bdf>/hwmon/hwmon*; plain sysfs reads, no SMI library, no GPU call, ~0.1 ms per sample -- every `period_s` between
+    start() and stop().  The step is power-bound (0.95-0.97 of the 1400 W cap), so the clock the package holds under
+    this lease's silicon, cooling and neighbours IS the lease-to-lease spread of the headline.  Absent nodes (another driver, a
+    container without sysfs) -> {"available": false}; never an error."""
+
+    def __init__(self, device_index, period_s=0.004):
+        self.period_s, self.samples, self._stop, self._th, self.dir = period_s, [], False, None, None
+        try:
+            import glob
+            import torch
+            p = torch.cuda.get_device_properties(device_index)
+            bdf = "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
+            d = glob.glob("/sys/bus/pci/devices/%s/hwmon/hwmon*" % bdf)
+            if d and os.path.exists(os.path.join(d[0], "freq1_input")):
+                self.dir, self.bdf = d[0], bdf
+        except Exception:
+            self.dir = None
+
+    def _read(self, name):
+        try:
+            with open(os.path.join(self.dir, name)) as f:
+                return float(f.read())
+        except Exception:
+            return None
+
+    def _loop(self):
+        while not self._stop:
+            self.samples.append((self._read("freq1_input"), self._read("power1_input")))
+            time.sleep(self.period_s)
+
+    def start(self):
+        if self.dir is None:
+            return
+        import threading
+        self._th = threading.Thread(target=self._loop, daemon=True)
+        self._th.start()
+
+    def stop(self):
+        self._stop = True
+        if self._th is not None:
+            self._th.join(timeout=1.0)
+        if self.dir is None:
+            return {"available": False}
+
+        def stats(v, scale):
+            v = sorted(x * scale for x in v if x is not None)
+            return {"n": len(v), "min": round(v[0], 1), "median": round(v[len(v) // 2], 1), "max": round(v[-1], 1)} if v else None
+        cap = self._read("power1_cap")
+        return {"available": True, "source": "sysfs hwmon of %s, sampled every %.0f ms on a host thread inside the timed region" % (self.bdf, 1e3 * self.period_s),
+                "sclk_mhz": stats([s[0] for s in self.samples], 1e-6), "socket_power_w": stats([s[1] for s in self.samples], 1e-6),
+                "power_cap_w": cap * 1e-6 if cap else None}
+
+
 PMC_TRAFFIC_FILE = "pmc_traffic_bench_bf16_b256.json"   # profiles/<latest tag>_pmc_traffic_bench_bf16_b256.json
 
 
@@ -271,6 +327,16 @@ def launch(a, argv):
     waits for it under a watchdog, relays rank 0's JSON line and exits with the job's code.  Every rank of that job is itself a GPU-free
     supervisor that walks the ladder of supervise() below -- the same thing happens when the driver starts the torchrun job itself."""
     from lrcn_amd import launch as lch   # imports neither torch nor the HIP library
+    # The outer watchdog has to outlast the ladder it guards (ADVICE r5: a fixed 900 s around 2-3 rungs of up to rung_s each fired while the
+    # fallback rung was still running, and the job ended with rc 124 and no number): every rung may take its whole budget plus the
+    # supervisors' teardown and verdict exchange, so the default is derived from the rung list; an explicit --watchdog-s / LRCN_BENCH_WATCHDOG_S
+    # larger than that is honoured, a smaller one is raised to it.
+    n_rungs = len(lch.default_rungs(a.dp_backend))
+    rung_s = float(os.environ.get("LRCN_BENCH_RUNG_S", "900"))
+    stall_s = float(os.environ.get("LRCN_BENCH_STALL_S", "300"))
+    need_s = n_rungs * (rung_s + 60.0) + stall_s + 120.0
+    if a.watchdog_s < need_s and not os.environ.get("LRCN_BENCH_WATCHDOG_EXACT"):
+        a.watchdog_s = need_s
     rc, out = lch.run_ranks(SCRIPT, list(argv), a.gpus, {"LRCN_BENCH_LAUNCHED": "1"}, a.watchdog_s)
     if rc == 124:
         print("bench.py: the %d-rank job did not finish within %.0f s and was stopped" % (a.gpus, a.watchdog_s), file=sys.stderr)
@@ -310,6 +376,32 @@ def supervise(a, argv):
 
     return lch.supervise_rank(SCRIPT, list(argv), rungs, stall_s=float(os.environ.get("LRCN_BENCH_STALL_S", "300")),
                               rung_s=float(os.environ.get("LRCN_BENCH_RUNG_S", "900")), is_line=is_json_line, annotate=annotate)
+
+
+PMC_MFMA_FILE = "pmc_mfma_busy_bench_bf16_b256.json"   # profiles/<tag>_pmc_mfma_busy_bench_bf16_b256.json (tools/pmc_mfma.py)
+
+
+def pmc_mfma(dtype, per_gpu_batch):
+    """Matrix-pipe utilisation of the convolution family and of the LSTM chain's contractions from the committed SQ-counter passes of this
+    same command (tools/pmc_sq_passes.sh -> tools/pmc_mfma.py), quoted under the same rule as the traffic: only for the configuration and
+    the kernel sources it was measured on.  -> (dict | None, note)"""
+    if dtype != "bf16" or per_gpu_batch != 256:
+        return None, "no SQ-counter pass for this configuration"
+    pdir = os.path.join(ROOT, "profiles")
+    files = sorted(f for f in os.listdir(pdir) if f.endswith(PMC_MFMA_FILE)) if os.path.isdir(pdir) else []
+    for f in reversed(files):
+        try:
+            d = json.load(open(os.path.join(pdir, f)))
+        except Exception:
+            continue
+        if d.get("csrc_digest") == csrc_digest():
+            fam = d["families"]
+            return ({"conv_family": fam["conv"]["mfma_busy"], "lstm_gemm_family": fam.get("lstm", {}).get("mfma_busy"),
+                     "conv_waves_parked": fam["conv"]["waves_parked (SQ_WAIT_ANY / SQ_WAVE_CYCLES)"],
+                     "lstm_waves_parked": fam.get("lstm", {}).get("waves_parked (SQ_WAIT_ANY / SQ_WAVE_CYCLES)"),
+                     "definition": "SQ_VALU_MFMA_BUSY_CYCLES / (4 SQ_BUSY_CU_CYCLES), time-weighted over the family's launches; kernels serialised by --pmc"},
+                    "profiles/%s (csrc digest %s matches)" % (f, d["csrc_digest"]))
+    return None, "stale: no profiles/*_%s was taken on the current kernel sources (digest %s)" % (PMC_MFMA_FILE, csrc_digest())
 
 
 def csrc_digest():
@@ -491,10 +583,14 @@ def rank_main(a, world, rank, local_rank):
     e0 = torch.cuda.Event(enable_timing=True)
     e0.record()
     step_ev.append(e0)
+    hw = HwSampler(local_rank) if rank == 0 and os.environ.get("LRCN_BENCH_HW_SAMPLER", "1")[:1] != "0" else None
+    if hw:
+        hw.start()
     t0 = time.perf_counter()
     run(a.steps, events=True)
     barrier()
     dt_s = time.perf_counter() - t0
+    hw_held = hw.stop() if hw else None
     beat("timed region done")
     if selfcheck is not None:
         same, _ = trainer.check_replicas()
@@ -539,6 +635,7 @@ def rank_main(a, world, rank, local_rank):
         achieved = flops_per_launch / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
         peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
         traffic, traffic_note = pmc_traffic(a.dtype, B)
+        mfma_busy, mfma_note = pmc_mfma(a.dtype, B)
         out = {
             "metric": metric_name(a, fake_multi),
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -569,10 +666,11 @@ def rank_main(a, world, rank, local_rank):
                      "selfcheck": selfcheck,
                      "pipeline": trainer.describe() if hasattr(trainer, "describe") else None},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": traffic, "traffic_source": traffic_note,
+                         "traffic": traffic, "traffic_source": traffic_note, "mfma_busy": mfma_busy, "mfma_busy_source": mfma_note,
                          "kernel": "conv64f_kernel (conv1_1+conv1_2 fused) + conv64_kernel (conv2_1) + gemm8p_kernel<*,CONV3,*> (conv2_2..conv5_3): 12 launches/step"
                                    if a.dtype == "bf16" else "gemm_glds_kernel<float,*,CONV3,*> v_mfma_f32_32x32x2_f32 (conv1_2..conv5_3)",
                          "avg_launch_ms": 1e3 * avg_launch_s, "flops_per_launch": flops_per_launch, "sub": sub},
+            "hw_held_in_timed_region": hw_held,
         }
         if a.emulate_world > 1:
             out["config"]["emulate_world"] = a.emulate_world

@@ -1,6 +1,6 @@
-# LRCNHip.jl -- the binding a maintainer of lrcn.jl would add to route the hot path through liblrcn_hip.so.
+# UNTESTED: no Julia in the image this repository is built and tested in (SURVEY.md section 0.2) -- nothing below has ever been run.
 #
-# UNTESTED: Julia is not available in the build environment of this repository (SURVEY.md section 0.2).  It is written
+# LRCNHip.jl -- the binding a maintainer of lrcn.jl would add to route the hot path through liblrcn_hip.so.  It is written
 # for Julia >= 1.6 with plain `ccall`; arrays are device buffers owned by the caller (e.g. AMDGPU.jl ROCArray{Float32}
 # or raw pointers from lrcn_malloc).  Julia arrays are column-major, which is exactly what include/lrcn.h expects, so
 # nothing is copied or transposed.  Token ids: the reference is 1-based (eos/bos/unk = 1/2/3, lrcn.jl:248-255); the ABI
@@ -8,7 +8,8 @@
 module LRCNHip
 
 const lib = get(ENV, "LRCN_HIP_LIB", "liblrcn_hip.so")
-const ABI_VERSION = 4   # include/lrcn.h LRCN_ABI_VERSION: the revision the struct layouts below were written against
+const ABI_VERSION = 5   # include/lrcn.h LRCN_ABI_VERSION: the revision the struct layouts below were written against (rev 5 added entry
+                        # points only -- lrcn_avg_loss_batch is wrapped below -- the struct layouts are those of rev 2..4)
 function __init__()
     v = ccall((:lrcn_abi_version, lib), Cint, ())
     v == ABI_VERSION || error("liblrcn_hip implements ABI revision $v, LRCNHip.jl was written against $ABI_VERSION")

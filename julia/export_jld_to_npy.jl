@@ -1,4 +1,6 @@
-# export_jld_to_npy.jl -- run ON A MACHINE WITH JULIA + JLD (this repository's image has neither: UNTESTED here).
+# UNTESTED: no Julia in the image this repository is built and tested in -- nothing below has ever been run.
+#
+# export_jld_to_npy.jl -- run ON A MACHINE WITH JULIA + JLD (this repository's image has neither).
 #
 # The reference saves its trained model and vocabulary as JLD/HDF5 (`save(o[:savefile], "model", model, "vocab", vocab)`, lrcn.jl:183-186;
 # best model per epoch :228-231) and its feature dictionaries as `Dict{Int,Array{Float32}}` (lrcn.jl:206-207, 220;
@@ -13,6 +15,13 @@
 # unchanged: W1 (E+H1) x 4H1, b1 1 x 4H1, ..., Wembed V x E (initweights, lrcn.jl:489-510).  Vocabulary ids stay 1-based as in the
 # reference (lrcn.jl:248-255: eos 1, bos 2, unk 3); the C ABI's 0-based shift happens in lrcn_amd.captions.
 using JLD
+
+# The reference does not save KnetArrays directly: `save` goes through its own wrapper type (lrcn.jl:776-781 -- `type KnetJLD; a::Array; end`
+# with JLD.writeas / JLD.readas methods).  A standalone reader has to define a type of that NAME and field, or JLD reconstructs an opaque
+# placeholder that `Array(p)` cannot convert (ADVICE r5).  Julia >= 0.7 spells `type` as `mutable struct`.
+mutable struct KnetJLD
+    a::Array
+end
 
 const PARAM_NAMES = ["W1", "b1", "W2", "b2", "Wproj", "Wcnn", "Wembed", "Wout", "bout"]
 
@@ -35,7 +44,9 @@ function write_npy(path, a::Array)
     end
 end
 
-to_host(p) = convert(Array{Float32}, isa(p, Array) ? p : Array(p))   # KnetArray / KnetJLD wrapper (lrcn.jl:776-781) -> Array
+# Array as saved on a CPU run; the KnetJLD wrapper of a GPU run (field `a`, above; also whatever placeholder JLD built if the type did not
+# resolve, as long as it kept that field); anything else that converts
+to_host(p) = convert(Array{Float32}, isa(p, Array) ? p : (isdefined(p, :a) ? getfield(p, :a) : Array(p)))
 
 function export_model(jld, out)
     mkpath(out)

@@ -73,7 +73,9 @@ def load_npy_dir(path):
             raise ValueError("%s: expected a 2-D float32 array, got %s %s" % (n, a.dtype, a.shape))
         model.append(a)
     E_H1, H1x4 = model[0].shape
-    if model[1].shape != (1, H1x4) or model[6].shape[1] != E_H1 - H1x4 // 4 or model[7].shape[1] != model[6].shape[0] or \
+    x1 = E_H1 - H1x4 // 4   # LSTM-1's input width: E for the reference's two-layer model, E + h for LRCN-1f (the embedding and x_cnn side by side)
+    one_layer = model[2].size == 0 and model[4].size == 0
+    if model[1].shape != (1, H1x4) or model[6].shape[1] != (x1 - model[5].shape[1] if one_layer else x1) or model[7].shape[1] != model[6].shape[0] or \
             model[8].shape != (1, model[6].shape[0]):
         raise ValueError("the nine arrays do not have initweights' shapes (lrcn.jl:489-510): %s" % [m.shape for m in model])
     vocab = {}

@@ -247,6 +247,7 @@ def test_ranks_never_outlive_the_launcher(tmp_path, how):
     import time
     env = _env()
     env["LRCN_BENCH_DRYRUN_HANG"] = str(tmp_path / "pid")
+    env["LRCN_BENCH_WATCHDOG_EXACT"] = "1"   # take --watchdog-s as given (by default it is raised to what the ladder's rungs may need)
     args = [sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0"] + (["--watchdog-s", "8"] if how == "watchdog" else [])
     p = subprocess.Popen(args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     pids = []
@@ -266,6 +267,29 @@ def test_ranks_never_outlive_the_launcher(tmp_path, how):
             break
         time.sleep(0.1)
     assert not alive, alive
+
+
+def test_outer_watchdog_outlasts_the_ladder(monkeypatch):
+    """the launcher's single outer watchdog must not fire while a fallback rung still has budget: n_rungs x (rung_s + teardown)
+    + one stall window.  Checked on the arithmetic (run_ranks is replaced; nothing is launched)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from lrcn_amd import launch as lch
+    seen = {}
+    monkeypatch.setattr(lch, "run_ranks", lambda script, argv, n, env, wd: (seen.setdefault("wd", wd), (0, ""))[1])
+    monkeypatch.delenv("LRCN_BENCH_WATCHDOG_EXACT", raising=False)
+    monkeypatch.setenv("LRCN_BENCH_RUNG_S", "900")
+    monkeypatch.setenv("LRCN_BENCH_STALL_S", "300")
+    for backend, n_rungs in (("torch", 2), ("auto", 3)):
+        seen.clear()
+        a = bench.parse_args(["--gpus", "2", "--dp-backend", backend])
+        bench.launch(a, ["--gpus", "2", "--dp-backend", backend])
+        assert len(lch.default_rungs(backend)) == n_rungs
+        assert seen["wd"] >= n_rungs * 960 + 300, (backend, seen["wd"])
+    seen.clear()
+    a = bench.parse_args(["--gpus", "2", "--watchdog-s", "100000"])
+    bench.launch(a, ["--gpus", "2"])
+    assert seen["wd"] == 100000
 
 
 def test_sub_reports_and_rungs_are_plain_functions():

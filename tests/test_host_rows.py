@@ -342,6 +342,16 @@ def test_reference_jld_export_directory_loads(tmp_path):
     (d / "vocab.tsv").write_text("only\t1\n", encoding="utf-8")
     with pytest.raises(ValueError):
         fmt.load_npy_dir(str(d))
+    # this repository's one-layer model (LRCN-1f: W1 takes [embedding | x_cnn | h], W2 / b2 / Wproj are empty) passes the shape check too
+    # (the check demanded Wembed columns == rows(W1) - H1, the two-layer relation)
+    d1 = tmp_path / "model_1f_npy"
+    d1.mkdir()
+    model1 = [rng.standard_normal(tuple(sh)).astype(np.float32) for sh in L.param_shapes(E, H, H, V, n_layers=1)]
+    for k, (n, a) in enumerate(zip(fmt.PARAM_NAMES, model1)):
+        _write_npy_like_the_julia_exporter(str(d1 / ("param_%d_%s.npy" % (k, n))), a)
+    (d1 / "vocab.tsv").write_text("".join("%s\t%d\n" % (w, i + 1) for i, w in enumerate(words)), encoding="utf-8")
+    got1 = fmt.load_npy_dir(str(d1))[0]
+    assert [a.shape for a in got1] == [tuple(sh) for sh in L.param_shapes(E, H, H, V, n_layers=1)]
     # feature dictionary: ids + a 4096 x N matrix
     f = tmp_path / "feats_npy"
     f.mkdir()

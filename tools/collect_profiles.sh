@@ -32,6 +32,10 @@ LRCN_C5_LIGHT=1 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/st
 LRCN_C5_LIGHT=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/fetchc5" -o p -- python3 "$root/bench.py" --config c5 --steps 20 > /dev/null 2> "$out/fetchc5.log"
 LRCN_C5_LIGHT=1 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/writec5" -o p -- python3 "$root/bench.py" --config c5 --steps 20 > /dev/null 2> "$out/writec5.log"
 cd "$root"
+# matrix-pipe utilisation of the convolution family and of the LSTM chain's contractions (round 6): four SQ-counter passes of the headline command
+tools/pmc_sq_passes.sh profiles_${tag}_sqbench bench.py --steps 8 --warmup 2 --no-cpu-baseline > "$out/sq.log" 2>&1 || tail -5 "$out/sq.log"
+python3 tools/pmc_mfma.py gpurun_out/profiles_${tag}_sqbench_sq.json "$out/pmc_mfma_busy.json" > /dev/null || true
+rm -f gpurun_out/profiles_${tag}_sqbench_p?.json gpurun_out/profiles_${tag}_sqbench_p?.log gpurun_out/profiles_${tag}_sqbench_sq.json
 f32=$(find "$out/stats32" -name "*kernel_trace.csv" | head -1)
 python3 tools/beside_vs_alone.py "$f32" 400 > "$out/beside_vs_alone_b32.txt" 2>&1 || true
 python3 tools/step_chain.py "$f32" 3 > "$out/step_chain_b32.txt" 2>&1 || true
