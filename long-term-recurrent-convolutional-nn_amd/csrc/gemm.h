@@ -5,7 +5,18 @@
 #include <stdint.h>
 
 enum { GEMM_A_PLAIN = 0, GEMM_A_CONV3 = 1 };
-enum { GEMM_OUT_PLAIN = 0, GEMM_OUT_CONV = 1, GEMM_OUT_POOL = 2, GEMM_OUT_LSTM_FWD = 3, GEMM_OUT_LSTM_BWD = 4 };
+enum { GEMM_OUT_PLAIN = 0, GEMM_OUT_CONV = 1, GEMM_OUT_POOL = 2, GEMM_OUT_LSTM_FWD = 3, GEMM_OUT_LSTM_BWD = 4, GEMM_OUT_SMAX_TOPK = 5 };
+
+// GEMM_OUT_SMAX_TOPK (gemm_8p.hip, bf16, 256 x 256 tiles; round 6): the logits GEMM of a batched beam-decode step whose C never reaches HBM.
+// softmax + sortperm of lrcn.jl:652-656 need, per row, max / sum-exp over all V columns and the K best columns; each tile reduces ITS 256
+// columns (+ bias) to two records per row -- one per 128-column half: {max, sum exp(x - max), the SMAX_KC largest logits and their column ids}
+// -- and softmax_topk_merge_kernel (kernels.hip) combines the V / 128 records of a row.  218 MB of f32 logits per step at 5120 x 10640 become
+// 28 MB of records.  A record is SMAX_REC floats (64 bytes): [0] max, [1] sum, [2 .. 2+KC) values, [8 .. 8+KC) column ids (int bits).
+enum { SMAX_KC = 6, SMAX_REC = 16 };
+struct SmaxEpi {
+    float *part;   // [M][nrec][SMAX_REC]
+    int nrec;      // records per row = 2 * ceil(N / 256)
+};
 
 // Epilogue operands of the two LSTM out-modes of gemm_8p.hip (bf16 only): the recurrent GEMM of a timestep with the cell update
 // (forward) / the cell backward of the previous step (backward) computed in the accumulator registers -- no f32 round trip of the
@@ -18,6 +29,8 @@ struct LstmEpi {
     int64_t ld_a, ld_h;     // leading dimensions of acts / dz (elements) and of h_new
     const float *Gx;        // FWD: [M][4H] input-side pre-activations (+ bias) of this step
     const float *c_prev;    // [M][H] or NULL (first step of the sequence)
+    const int *c_prev_idx;  // FWD, optional: row r reads c_prev[c_prev_idx[r]] (the beam decode: a hypothesis continues its PARENT's cell state; then
+                            // c_out must not alias c_prev)
     const float *c_new;     // BWD: [M][H] cell state of step s-1
     float *c_out;           // FWD: [M][H]
     void *acts;             // FWD: out (NULL: not kept -- a decode step has no backward pass), BWD: in -- activated gates [M][ld_a], columns [f | i | o | g]
@@ -50,6 +63,7 @@ struct GemmArgs {
     unsigned inv_w2, inv_h2;  // gemm_8p.hip: reciprocals of W / 2 and H / 2 for decode_pixel_fast (set by launch_gemm_8p; 0 = divide)
     int wg_cap;             // > 0: at most this many workgroups (gemm_8p.hip / conv64.hip walk the tiles persistently)
     LstmEpi lstm;           // out_mode GEMM_OUT_LSTM_FWD / _BWD only
+    SmaxEpi smax;           // out_mode GEMM_OUT_SMAX_TOPK only (bias = the logits' bias row; C unused)
     int cfg_pref;           // gemm_8p.hip: 0 = the dispatcher's tile menu, 2 = prefer the 256 x 128 tile (set by the bg_cus route)
     int free_cus;           // > 0 (rows per GPU below the bg_cus route's threshold): this many CUs are free beside the capped convolution grids --
                             // the split-K planner cuts K so that tiles x slices fit them in ONE round (round 5)

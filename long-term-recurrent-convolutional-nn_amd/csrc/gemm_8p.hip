@@ -411,6 +411,42 @@ __device__ __forceinline__ bool gemm8p_tile(const GemmArgs &g, unsigned char *sm
         //    (a first version did the math straight from the MFMA layout -- 16 rows per memory instruction -- and ran 3-10x slower).
         constexpr int CPRF = BN / 4;  // 16-byte chunks per staged f32 row
         static_assert(CPRF == 32, "LSTM epilogues are built for the 256 x 128 tile");
+        const LstmEpi &e = g.lstm;
+        const int H = e.H;
+        typedef __bf16 bf16x4e __attribute__((ext_vector_type(4)));
+        // FWD (round 6): a thread owns FOUR CONSECUTIVE UNITS of a row -- chunks 4q .. 4q+3 of the staged row -- in 4 rows (r64 + 64 j), so
+        // that every global access is a 16-byte (f32) / 8-byte (bf16) vector whatever the gate layout of Gx / acts ([f | i | o | g] blocks:
+        // four units of one gate are contiguous), and everything the cell math READS (c_prev, Gx or the bias row) is requested BEFORE the
+        // accumulators are staged: the loads fly under the LDS round trip instead of sixteen dependent 4-byte round trips per thread
+        // (round 5's form: one unit per thread and iteration, 5 scalar loads + 6 scalar stores each -- 45 us fused against 27 + 9.6 us
+        // as two launches at 256 rows, and 175 us per decode-step layer at 5120 hypotheses).
+        const int q8 = tid & 7, r64 = tid >> 3;
+        const int u0 = (n0 >> 2) + 4 * q8;          // first of the thread's four hidden units (H % 4 == 0: a quad is inside or outside as a whole)
+        const bool uok = u0 < H;
+        [[maybe_unused]] f32x4v cpv[4], gxv[4][4];
+        if constexpr (EPI == GEMM_OUT_LSTM_FWD) {
+            const f32x4v z4 = f32x4v{0.f, 0.f, 0.f, 0.f};
+            if (e.gx_bcast) {   // one row [4H] for every row of the tile (the bias of a decode step)
+#pragma unroll
+                for (int gt = 0; gt < 4; ++gt) gxv[0][gt] = uok ? *reinterpret_cast<const f32x4v *>(e.Gx + (int64_t)gt * H + u0) : z4;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = m0 + r64 + 64 * j;
+                const bool ok = uok && row < M;
+                if (ok && e.c_prev) {
+                    const int64_t prow = e.c_prev_idx ? e.c_prev_idx[row] : row;
+                    cpv[j] = *reinterpret_cast<const f32x4v *>(e.c_prev + prow * H + u0);
+                } else {
+                    cpv[j] = z4;
+                }
+#pragma unroll
+                for (int gt = 0; gt < 4; ++gt) {   // (statically indexed copies: a run-time row index would put the array in scratch)
+                    if (!e.gx_bcast) gxv[j][gt] = ok ? *reinterpret_cast<const f32x4v *>(e.Gx + (int64_t)row * 4 * H + (int64_t)gt * H + u0) : z4;
+                    else if (j > 0) gxv[j][gt] = gxv[0][gt];
+                }
+            }
+        }
 #pragma unroll
         for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
@@ -424,32 +460,52 @@ __device__ __forceinline__ bool gemm8p_tile(const GemmArgs &g, unsigned char *sm
                         *reinterpret_cast<f32x4v *>(smem + lrow * (BN * 4) + ((ch ^ (lrow & 31)) << 4)) = acc[mh][i][nh][n];
                     }
         __syncthreads();
-        const LstmEpi &e = g.lstm;
-        const int H = e.H;
+        if constexpr (EPI == GEMM_OUT_LSTM_FWD) {  // staged columns 4u .. 4u+3 = the gates f, i, o, g of unit u (interleaved weight rows)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int lrow = r64 + 64 * j, row = m0 + lrow;
+                if (!uok || row >= M) continue;
+                f32x4v fv, iv, ov, gv, cn, hv;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {   // unit u0 + k
+                    const f32x4v a = *reinterpret_cast<const f32x4v *>(smem + lrow * (BN * 4) + (((4 * q8 + k) ^ (lrow & 31)) << 4));
+                    const float f = sigm8p(a[0] + gxv[j][0][k]), in = sigm8p(a[1] + gxv[j][1][k]), o = sigm8p(a[2] + gxv[j][2][k]),
+                                chg = tanhf(a[3] + gxv[j][3][k]);
+                    const float c = cpv[j][k] * f + in * chg;
+                    fv[k] = f; iv[k] = in; ov[k] = o; gv[k] = chg; cn[k] = c;
+                    hv[k] = o * tanhf(c);
+                }
+                if (e.acts) {
+                    bf16_t *ac = reinterpret_cast<bf16_t *>(e.acts) + (int64_t)row * e.ld_a + u0;
+                    bf16x4e t;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) t[k] = (bf16_t)fv[k];
+                    *reinterpret_cast<bf16x4e *>(ac) = t;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) t[k] = (bf16_t)iv[k];
+                    *reinterpret_cast<bf16x4e *>(ac + H) = t;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) t[k] = (bf16_t)ov[k];
+                    *reinterpret_cast<bf16x4e *>(ac + 2 * H) = t;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) t[k] = (bf16_t)gv[k];
+                    *reinterpret_cast<bf16x4e *>(ac + 3 * H) = t;
+                }
+                *reinterpret_cast<f32x4v *>(e.c_out + (int64_t)row * H + u0) = cn;
+                bf16x4e hb;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) hb[k] = (bf16_t)hv[k];
+                *reinterpret_cast<bf16x4e *>(reinterpret_cast<bf16_t *>(e.h_new) + (int64_t)row * e.ld_h + u0) = hb;
+                if (e.h_f32) *reinterpret_cast<f32x4v *>(e.h_f32 + (int64_t)row * H + u0) = hv;
+            }
+            return false;
+        }
         for (int idx = tid; idx < BM * CPRF; idx += 512) {
             const int lrow = idx / CPRF, ch = idx - lrow * CPRF;
             const int row = m0 + lrow, col0 = n0 + 4 * ch;
             if (row >= M || col0 >= N) continue;
             const f32x4v a = *reinterpret_cast<const f32x4v *>(smem + lrow * (BN * 4) + ((ch ^ (lrow & 31)) << 4));
-            if constexpr (EPI == GEMM_OUT_LSTM_FWD) {  // columns 4u .. 4u+3 = the gates f, i, o, g of unit u
-                const int u = col0 >> 2;
-                const float *gx = e.Gx + (e.gx_bcast ? 0 : (int64_t)row * 4 * H) + u;
-                const float f = sigm8p(a[0] + gx[0]), in = sigm8p(a[1] + gx[H]), o = sigm8p(a[2] + gx[2 * H]), chg = tanhf(a[3] + gx[3 * H]);
-                const float cp = e.c_prev ? e.c_prev[(int64_t)row * H + u] : 0.0f;
-                const float c = cp * f + in * chg;
-                if (e.acts) {
-                    bf16_t *ac = reinterpret_cast<bf16_t *>(e.acts) + (int64_t)row * e.ld_a + u;
-                    ac[0] = (bf16_t)f;
-                    ac[H] = (bf16_t)in;
-                    ac[2 * H] = (bf16_t)o;
-                    ac[3 * H] = (bf16_t)chg;
-                }
-                e.c_out[(int64_t)row * H + u] = c;
-                const float hv = o * tanhf(c);
-                reinterpret_cast<bf16_t *>(e.h_new)[(int64_t)row * e.ld_h + u] = (bf16_t)hv;
-                if (e.h_f32) e.h_f32[(int64_t)row * H + u] = hv;
-            } else {  // columns = four consecutive hidden units (H % 4 == 0 is checked at launch)
-                typedef __bf16 bf16x4e __attribute__((ext_vector_type(4)));
+            {  // BWD: columns = four consecutive hidden units (H % 4 == 0 is checked at launch)
                 const int u = col0;
                 const int64_t o = (int64_t)row * H + u;
                 const f32x4v dhe = *reinterpret_cast<const f32x4v *>(e.dh_ext + o), cn = *reinterpret_cast<const f32x4v *>(e.c_new + o),
@@ -481,6 +537,101 @@ __device__ __forceinline__ bool gemm8p_tile(const GemmArgs &g, unsigned char *sm
                 *reinterpret_cast<bf16x4e *>(z + 3 * H) = zg;
                 *reinterpret_cast<f32x4v *>(e.dc + o) = dco;
             }
+        }
+        return false;
+    }
+    // ---------------------------------------------------------------- softmax / top-K partials (gemm.h SmaxEpi): the logits stay on chip
+    if constexpr (EPI == GEMM_OUT_SMAX_TOPK) {
+        static_assert(BM == 256 && BN == 256 && SWAP && !F8, "built for the 256 x 256 tile");
+        // Two phases, one per 128-column half h of the tile: the waves that own those columns (wc >> 1 == h) stage accumulator + bias as f32
+        // (256 rows x 512 bytes = the whole ring; 16-byte chunk c of row r at chunk c ^ (r & 31)), columns past N as -inf; then thread t scans
+        // 64 of them for row t >> 1 (part t & 1) and carries {max, sum exp, SMAX_KC best} over both phases: its 128 columns are
+        // n0 + 128 h + 64 part + [0, 64), h = 0, 1.  Pass A of a phase finds the 64 values' maximum, pass B (a second LDS read: cheaper than 64
+        // live registers beside the other half's accumulators) adds exp(x - max) and offers every value that beats the list's last entry.
+        // List order: value descending, equal values by ascending column (columns are scanned ascending and only a strictly larger value
+        // moves in front of an entry).
+        const SmaxEpi &e = g.smax;
+        const int srow = tid >> 1, part = tid & 1;
+        float m_run = -INFINITY, s_run = 0.0f;
+        float tv[SMAX_KC];
+        int ti[SMAX_KC];
+#pragma unroll
+        for (int k = 0; k < SMAX_KC; ++k) {
+            tv[k] = -INFINITY;
+            ti[k] = 0x7FFFFFFF;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if ((wc >> 1) == h) {
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        const int lcol = (wc & 1) * WTN + nh * QN + n * 16 + 4 * lq;   // column inside the half
+                        const int col = n0 + h * 128 + lcol;
+                        f32x4v bias = f32x4v{0.f, 0.f, 0.f, 0.f};
+                        const bool cok = col < N;                                    // N % 4 == 0 (checked at launch): a quad is in or out as a whole
+                        if (g.bias && cok) bias = *reinterpret_cast<const f32x4v *>(g.bias + col);
+#pragma unroll
+                        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                            for (int i = 0; i < MT; ++i) {
+                                const int lrow = wr * WTM + mh * QM + i * 16 + l15;
+                                f32x4v a = acc[mh][i][nh][n] + bias;
+                                if (!cok) a = f32x4v{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                                *reinterpret_cast<f32x4v *>(smem + lrow * 512 + (((lcol >> 2) ^ (lrow & 31)) << 4)) = a;
+                            }
+                    }
+            }
+            __syncthreads();
+            const unsigned char *rowp = smem + srow * 512;
+            const int sw = srow & 31;
+            float cm = -INFINITY;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const f32x4v x = *reinterpret_cast<const f32x4v *>(rowp + (((part * 16 + c) ^ sw) << 4));
+                cm = fmaxf(cm, fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])));
+            }
+            if (cm > m_run) {   // (cm = -inf -- every column of this part past N -- never enters)
+                s_run *= __expf(m_run - cm);   // exp(-inf) = 0 the first time
+                m_run = cm;
+            }
+            if (cm != -INFINITY) {
+                const int cbase = n0 + h * 128 + part * 64;
+#pragma unroll 4
+                for (int c = 0; c < 16; ++c) {
+                    const f32x4v x = *reinterpret_cast<const f32x4v *>(rowp + (((part * 16 + c) ^ sw) << 4));
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float xv = x[k];
+                        s_run += __expf(xv - m_run);
+                        if (xv > tv[SMAX_KC - 1]) {
+                            float cv = xv;
+                            int ci = cbase + 4 * c + k;
+                            bool ins = false;
+#pragma unroll
+                            for (int j = 0; j < SMAX_KC; ++j) {
+                                ins = ins || cv > tv[j];
+                                if (ins) {
+                                    const float ov = tv[j];
+                                    const int oi = ti[j];
+                                    tv[j] = cv; ti[j] = ci;
+                                    cv = ov; ci = oi;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();   // the ring is overwritten by the next phase / the next tile's DMA
+        }
+        const int row = m0 + srow;
+        if (row < M) {
+            float *rec = e.part + ((int64_t)row * e.nrec + (2 * (n0 >> 8) + part)) * SMAX_REC;
+            *reinterpret_cast<f32x4v *>(rec) = f32x4v{m_run, s_run, tv[0], tv[1]};
+            *reinterpret_cast<f32x4v *>(rec + 4) = f32x4v{tv[2], tv[3], tv[4], tv[5]};
+            *reinterpret_cast<f32x4v *>(rec + 8) = f32x4v{__int_as_float(ti[0]), __int_as_float(ti[1]), __int_as_float(ti[2]), __int_as_float(ti[3])};
+            *reinterpret_cast<f32x4v *>(rec + 12) = f32x4v{__int_as_float(ti[4]), __int_as_float(ti[5]), 0.0f, 0.0f};
         }
         return false;
     }
@@ -852,7 +1003,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs g) {
 
 template <int WM, int WN, int MT, int NT, int AMODE, bool SWAP, bool F8 = false, int EPI = 0> hipError_t launch_one(hipStream_t s, const GemmArgs &g, int splitk) {
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
-    constexpr int ring = 2 * (BM + BN) * 128, ctile = BM * BN * (EPI ? 4 : 2);  // the LSTM epilogues stage the f32 tile
+    constexpr int ring = 2 * (BM + BN) * 128, ctile = EPI == GEMM_OUT_SMAX_TOPK ? BM * 512 : BM * BN * (EPI ? 4 : 2);  // the LSTM epilogues stage the f32 tile, SMAX a 128-column half
     constexpr int lds = ring > ctile ? ring : ctile;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static LdsAttrMask attr_done{0};
@@ -1047,6 +1198,21 @@ hipError_t launch_gemm_8p(hipStream_t stream, const GemmArgs &g0, int splitk) {
     if (epi == GEMM_OUT_LSTM_FWD || epi == GEMM_OUT_LSTM_BWD) {
         g.out_mode = GEMM_OUT_PLAIN;  // tile menu and operand checks are those of a plain contraction; the kernel template carries the mode
         g.cfg_pref = 2;
+    }
+    if (epi == GEMM_OUT_SMAX_TOPK) {  // 256 x 256 tiles, the logits reduced to per-row records in the epilogue: C is never written
+        static_assert(SMAX_KC == 6 && SMAX_REC == 16, "record layout of the epilogue's four 16-byte stores");
+        g.out_mode = GEMM_OUT_PLAIN;
+        g.c_f32 = 1;
+        g.C = g.smax.part;   // (operand checks want a non-null C)
+        g.ldc = g.N;
+        if (g.dtype != GEMM_T_BF16 || g.a_mode != GEMM_A_PLAIN || splitk > 1 || (g.N & 3) || g.M < 256 || g.N < 256 || !g.smax.part ||
+            g.smax.nrec != 2 * cdiv(g.N, 256) || ((uintptr_t)g.smax.part & 15) || (g.bias && ((uintptr_t)g.bias & 15)) || !gemm_glds_eligible(g))
+            return hipErrorInvalidValue;
+        static const char *dbg5 = getenv("LRCN_DBG");
+        g.dbg = dbg5 ? atoi(dbg5) : 0;
+        g.inv_w2 = g.inv_h2 = 0;
+        gemm_debug_note_route(nullptr, 0);
+        return launch_one<2, 4, 4, 2, GEMM_A_PLAIN, true, false, GEMM_OUT_SMAX_TOPK>(stream, g, 1);
     }
     static const char *dbg = getenv("LRCN_DBG");  // kernel-development ablation flags (gemm.h)
     g.dbg = dbg ? atoi(dbg) : 0;

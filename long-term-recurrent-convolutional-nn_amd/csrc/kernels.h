@@ -200,6 +200,13 @@ void k_conv11_fused(hipStream_t st, int src_is_u8, const void *src, int N, int S
 // softmax + top-K of every row in one pass (false: V too large for the register-resident form, use the two kernels)
 bool k_softmax_topk_rows(hipStream_t st, const float *logits, int64_t ld, int R, int V, int K, int32_t *idx, float *val);
 // out[i][r][:] = in[i][parent[r]][:] for the four recurrent states (row stride C[i]); hT[i] != NULL also receives a T copy (ld ldT[i])
+// second half of the logits GEMM's softmax / top-K epilogue (gemm.h SmaxEpi): records [R][nrec][SMAX_REC] -> idx / val [R][K] as k_softmax_topk_rows;
+// false = not applicable (K >= SMAX_KC, too many records)
+bool k_softmax_topk_merge(hipStream_t st, const float *part, int nrec, int R, int K, int32_t *idx, float *val);
+// bf16 batched decode, one launch per step: embedding of each hypothesis' last token + h1 / h2 of its parent into the [x | h] operands
+void k_decode_prep(hipStream_t st, const void *wembT, int64_t ld_w, const int32_t *last, const int32_t *parent, int R, int E, const void *h1,
+                   int64_t ld_h1, int H1, const void *h2, int64_t ld_h2, int H2, void *xh1, int64_t ld_xh1, int64_t off_h1, void *xh2, int64_t ld_xh2,
+                   int64_t off_h2);
 void k_gather_state(hipStream_t st, int dtype, const float *const in[4], float *const out[4], void *const hT[4], const int64_t ldT[4],
                     const int C[4], const int32_t *parent, int R);
 

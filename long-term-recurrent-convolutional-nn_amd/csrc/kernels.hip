@@ -1181,6 +1181,122 @@ __global__ __launch_bounds__(256) void softmax_topk_rows_kernel(const float *log
     }
 }
 
+// The second half of GEMM_OUT_SMAX_TOPK (gemm.h SmaxEpi; round 6): one wave per row combines the row's nrec = V / 128 records {max, sum exp,
+// SMAX_KC best logits + columns} into what softmax_topk_rows_kernel returns for the full row of logits: the K largest float32
+// PROBABILITIES p = exp(x - lse), lse = max + log(sum), in descending order, equal probabilities by ascending column (lrcn.jl:652-656 --
+// a stable descending sort of p).  As there, the rounds go on past K while the next candidate still shares the K-th probability
+// (distinct logits that round to one float), then the tie group is put in index order.  A record keeps SMAX_KC = K + 1 candidates
+// of its 128 columns, so a tie group that crosses the K boundary is exact as long as no more than SMAX_KC of it fall into one record.
+// Lane l owns records l, l + 64, ...; every record's list is sorted, so a lane's best candidate is the best list HEAD, and retiring a
+// candidate shifts that list (static indices only).
+template <int NR>
+__global__ __launch_bounds__(256) void softmax_topk_merge_kernel(const float *part, int nrec, int R, int K, int32_t *idx, float *val) {
+    __shared__ float wv[4][64];
+    __shared__ int wi[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + w;
+    if (row >= R) return;   // wave-uniform; no block-wide barrier below
+    const float *rp = part + (int64_t)row * nrec * SMAX_REC;
+    float m[NR], sx[NR], v[NR][SMAX_KC];
+    int ix[NR][SMAX_KC];
+    float gm = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+        const int rec = lane + 64 * q;
+        m[q] = -INFINITY;
+        sx[q] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < SMAX_KC; ++j) {
+            v[q][j] = -INFINITY;
+            ix[q][j] = 0x7FFFFFFF;
+        }
+        if (rec < nrec) {
+            const float4 a = *reinterpret_cast<const float4 *>(rp + (int64_t)rec * SMAX_REC), b = *reinterpret_cast<const float4 *>(rp + (int64_t)rec * SMAX_REC + 4),
+                         c = *reinterpret_cast<const float4 *>(rp + (int64_t)rec * SMAX_REC + 8), d = *reinterpret_cast<const float4 *>(rp + (int64_t)rec * SMAX_REC + 12);
+            m[q] = a.x; sx[q] = a.y;
+            v[q][0] = a.z; v[q][1] = a.w; v[q][2] = b.x; v[q][3] = b.y; v[q][4] = b.z; v[q][5] = b.w;
+            ix[q][0] = __float_as_int(c.x); ix[q][1] = __float_as_int(c.y); ix[q][2] = __float_as_int(c.z); ix[q][3] = __float_as_int(c.w);
+            ix[q][4] = __float_as_int(d.x); ix[q][5] = __float_as_int(d.y);
+        }
+        gm = fmaxf(gm, m[q]);
+    }
+    gm = wave_max(gm);
+    float se = 0.0f;
+#pragma unroll
+    for (int q = 0; q < NR; ++q)
+        if (m[q] != -INFINITY) se += sx[q] * __expf(m[q] - gm);
+    se = wave_sum(se);
+    const float lse = gm + logf(se);
+    auto local_best = [&](float &lv, int &li) {
+        lv = -INFINITY;
+        li = 0x7FFFFFFF;
+#pragma unroll
+        for (int q = 0; q < NR; ++q)
+            if (v[q][0] > lv || (v[q][0] == lv && ix[q][0] < li)) {
+                lv = v[q][0];
+                li = ix[q][0];
+            }
+    };
+    float lv;
+    int li;
+    local_best(lv, li);
+    float pK = -1.0f;
+    int n = 0;
+    for (int k = 0; k < 64; ++k) {
+        float bv = lv;
+        int bi = li;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o);
+            const int oi = __shfl_xor(bi, o);
+            if (ov > bv || (ov == bv && oi < bi)) {
+                bv = ov;
+                bi = oi;
+            }
+        }
+        const float pv = expf(bv - lse);
+        if (k >= K && (pv != pK || bi == 0x7FFFFFFF)) break;  // wave-uniform
+        if (lane == 0) {
+            wi[w][k] = bi;
+            wv[w][k] = pv;
+        }
+        n = k + 1;
+        if (k == K - 1) pK = pv;
+        if (li == bi && bi != 0x7FFFFFFF) {  // the owner retires the winner: its list moves up by one
+#pragma unroll
+            for (int q = 0; q < NR; ++q)
+                if (ix[q][0] == bi) {
+#pragma unroll
+                    for (int j = 0; j + 1 < SMAX_KC; ++j) {
+                        v[q][j] = v[q][j + 1];
+                        ix[q][j] = ix[q][j + 1];
+                    }
+                    v[q][SMAX_KC - 1] = -INFINITY;
+                    ix[q][SMAX_KC - 1] = 0x7FFFFFFF;
+                }
+            local_best(lv, li);
+        }
+    }
+    if (lane == 0) {
+        for (int k = 1; k < n; ++k) {  // equal probabilities (distinct logits, same float): ascending index
+            const float vv = wv[w][k];
+            const int ii = wi[w][k];
+            int q = k;
+            while (q > 0 && wv[w][q - 1] == vv && wi[w][q - 1] > ii) {
+                wv[w][q] = wv[w][q - 1];
+                wi[w][q] = wi[w][q - 1];
+                --q;
+            }
+            wv[w][q] = vv;
+            wi[w][q] = ii;
+        }
+        for (int k = 0; k < K; ++k) {
+            idx[row * K + k] = wi[w][k];
+            val[row * K + k] = wv[w][k];
+        }
+    }
+}
+
 // Beam reordering of the four recurrent state tensors in one launch (lrcn.jl:673-676): out[i][r] = in[i][parent[r]], plus
 // the K-contiguous T copies of h1 / h2 that the next step's recurrent GEMMs read.
 struct GatherState {
@@ -1200,6 +1316,29 @@ template <typename T> __global__ void gather_state_kernel(const GatherState g, c
         const float v = s[c];
         o[c] = v;
         if (t) t[c] = from_f32<T>(v);
+    }
+}
+
+// The batched beam decode's per-step gather (round 6), bf16 only: row r of the next step's [x | h1] operand = the embedding of hypothesis
+// r's last token (lrcn.jl:650) next to h1 of its PARENT hypothesis (lrcn.jl:673-676), and the h2 block of [x2 | h2] likewise -- what
+// embed_gather + gather_state did in two launches, without the four f32 state tensors' round trip (82 MB in, 82 MB out per step at 5120
+// hypotheses: the cell state now stays where the epilogue wrote it and is READ through `parent`, LstmEpi::c_prev_idx).  16-byte vectors:
+// every row starts 128-byte aligned (leading dimensions are multiples of 64 elements).  parent == NULL: the first step (h blocks zero).
+__global__ __launch_bounds__(256) void decode_prep_kernel(const bf16_t *wembT, int64_t ld_w, const int32_t *last, const int32_t *parent, int E,
+                                                          const bf16_t *h1, int64_t ld_h1, int H1, const bf16_t *h2, int64_t ld_h2, int H2,
+                                                          bf16_t *xh1, int64_t ld_xh1, int64_t off_h1, bf16_t *xh2, int64_t ld_xh2, int64_t off_h2) {
+    const int r = blockIdx.x;
+    auto copy = [&](const bf16_t *src, bf16_t *dst, int n) {   // exactly n elements: whole 16-byte vectors, then a scalar tail (LRCN-1f keeps
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(src);  // x_cnn right behind the embedding columns)
+        uint4 *d4 = reinterpret_cast<uint4 *>(dst);
+        for (int i = threadIdx.x; i < n / 8; i += 256) d4[i] = s4[i];
+        for (int i = (n & ~7) + threadIdx.x; i < n; i += 256) dst[i] = src[i];
+    };
+    copy(wembT + (int64_t)last[r] * ld_w, xh1 + (int64_t)r * ld_xh1, E);
+    if (parent) {
+        const int pr = parent[r];
+        copy(h1 + (int64_t)pr * ld_h1, xh1 + (int64_t)r * ld_xh1 + off_h1, H1);
+        if (h2) copy(h2 + (int64_t)pr * ld_h2, xh2 + (int64_t)r * ld_xh2 + off_h2, H2);
     }
 }
 
@@ -1478,6 +1617,20 @@ void k_gather_state(hipStream_t st, int dtype, const float *const in[4], float *
         g.in[i] = in[i]; g.out[i] = out[i]; g.hT[i] = hT[i]; g.ldT[i] = ldT[i]; g.C[i] = C[i];
     }
     DISPATCH_T(dtype, hipLaunchKernelGGL(gather_state_kernel<T>, dim3(R, 4), dim3(256), 0, st, g, parent));
+}
+bool k_softmax_topk_merge(hipStream_t st, const float *part, int nrec, int R, int K, int32_t *idx, float *val) {
+    if (K < 1 || K >= SMAX_KC || nrec < 1 || nrec > 256 || (reinterpret_cast<uintptr_t>(part) & 15)) return false;
+    const dim3 grid((R + 3) / 4);
+    if (nrec <= 64) hipLaunchKernelGGL(softmax_topk_merge_kernel<1>, grid, dim3(256), 0, st, part, nrec, R, K, idx, val);
+    else if (nrec <= 128) hipLaunchKernelGGL(softmax_topk_merge_kernel<2>, grid, dim3(256), 0, st, part, nrec, R, K, idx, val);
+    else hipLaunchKernelGGL(softmax_topk_merge_kernel<4>, grid, dim3(256), 0, st, part, nrec, R, K, idx, val);
+    return true;
+}
+void k_decode_prep(hipStream_t st, const void *wembT, int64_t ld_w, const int32_t *last, const int32_t *parent, int R, int E, const void *h1,
+                   int64_t ld_h1, int H1, const void *h2, int64_t ld_h2, int H2, void *xh1, int64_t ld_xh1, int64_t off_h1, void *xh2, int64_t ld_xh2,
+                   int64_t off_h2) {
+    hipLaunchKernelGGL(decode_prep_kernel, dim3(R), dim3(256), 0, st, (const bf16_t *)wembT, ld_w, last, parent, E, (const bf16_t *)h1, ld_h1, H1,
+                       (const bf16_t *)h2, ld_h2, H2, (bf16_t *)xh1, ld_xh1, off_h1, (bf16_t *)xh2, ld_xh2, off_h2);
 }
 void k_gather_rows_f32(hipStream_t st, const float *in, int64_t ld, const int32_t *src_row, int R, int C, float *out) {
     hipLaunchKernelGGL(gather_rows_f32_kernel, dim3(R), dim3(256), 0, st, in, ld, src_row, R, C, out);

@@ -58,6 +58,10 @@ struct lrcn_ctx {
     void *W1cat = nullptr, *W2cat = nullptr, *st_xh1 = nullptr, *st_xh2 = nullptr;
     int64_t ldXH1 = 0, ldXH2 = 0;
     void *W2x = nullptr, *W2h = nullptr, *W2xT = nullptr, *W2hT = nullptr;
+    float *smax_part = nullptr;             // [maxB][2 ceil(V / 256)][SMAX_REC]: the logits GEMM's softmax / top-K records of a batched decode step (round 6), lazily
+    void *alt_gi[2] = {nullptr, nullptr};   // LRCN_OPT_FUSED_UPDATE: the second set's gate-interleaved copies (round 6), written by the Adam kernel
+    bool gi_live = false;                   // a training call has taken the cell-epilogue route: the fused update keeps the interleaved copies current
+    bool shadow_has_gi = false;             // ... and the current set's were made by it
     void *W1h_gi = nullptr, *W2h_gi = nullptr;  // recurrent weights with (unit, gate)-interleaved rows (gemm_8p.hip LSTM_FWD epilogue), lazily
     void *Wpd = nullptr, *WpT = nullptr, *Wcd = nullptr, *WeT = nullptr, *Wod = nullptr, *WoT = nullptr;
     // LRCN_OPT_FUSED_UPDATE: the second set of the 14 training shadows above.  The Adam kernel of a train step writes the NEXT step's
@@ -346,6 +350,10 @@ ShadowSet alt_shadows(const lrcn_ctx *c) {
 void swap_shadow_sets(lrcn_ctx *c) {
     void **cur[14] = {&c->W1x, &c->W1h, &c->W1xT, &c->W1hT, &c->W2x, &c->W2h, &c->W2xT, &c->W2hT, &c->Wpd, &c->WpT, &c->Wcd, &c->WeT, &c->Wod, &c->WoT};
     for (int i = 0; i < 14; ++i) std::swap(*cur[i], c->alt[i]);
+    if (c->alt_gi[0]) {
+        std::swap(c->W1h_gi, c->alt_gi[0]);
+        std::swap(c->W2h_gi, c->alt_gi[1]);
+    }
 }
 int ensure_alt_shadows(lrcn_ctx *c) {
     if (c->alt[0]) return LRCN_OK;
@@ -358,9 +366,21 @@ int ensure_alt_shadows(lrcn_ctx *c) {
     for (int i = 0; i < 14; ++i) DALLOC(c, c->alt[i], bytes[i]);  // zero-filled: the K padding must hold zeros
     return LRCN_OK;
 }
+// the gate-interleaved recurrent weights of BOTH sets (the cell-epilogue route of a training step under LRCN_OPT_FUSED_UPDATE)
+int ensure_gi_sets(lrcn_ctx *c) {
+    const bool two = c->nl == 2;
+    if (!c->W1h_gi) DALLOC(c, c->W1h_gi, c->esz * 4 * c->H1 * c->ldH1);
+    if (two && !c->W2h_gi) DALLOC(c, c->W2h_gi, c->esz * 4 * c->H2 * c->ldH2);
+    if (c->opt_fused) {
+        if (!c->alt_gi[0]) DALLOC(c, c->alt_gi[0], c->esz * 4 * c->H1 * c->ldH1);
+        if (two && !c->alt_gi[1]) DALLOC(c, c->alt_gi[1], c->esz * 4 * c->H2 * c->ldH2);
+    }
+    return LRCN_OK;
+}
 
 // the six parameter matrices of the model -> descriptors of their shadows in `w` (memory images: see the comments per line)
-void plan_matrices(const lrcn_ctx *c, const float *const p[9], const ShadowSet &w, bool b, PrepPlan &plan, int only_a = -1, int only_b = -1) {
+void plan_matrices(const lrcn_ctx *c, const float *const p[9], const ShadowSet &w, bool b, PrepPlan &plan, int only_a = -1, int only_b = -1,
+                   void *const *gi = nullptr) {   // gi: {W1h, W2h} destinations with (unit, gate)-interleaved rows, or NULL
     const int E = c->E, H1 = c->H1, H2 = c->H2, h = c->h, V = c->V, X1 = c->X1;
     const bool two = c->nl == 2;
     auto add = [&](int k, int R, int C, int cs, void *dA, int64_t ldA, void *dB, int64_t ldB, void *tA, int64_t ldtA, void *tB, int64_t ldtB) {
@@ -373,9 +393,16 @@ void plan_matrices(const lrcn_ctx *c, const float *const p[9], const ShadowSet &
     };
     (void)E;
     // W1: memory [4H1][X1 + H1] -> W1x | W1h (and their transposes [X1][ld4H1] | [H1][ld4H1] for the backward dX GEMMs)
+    auto with_gi = [&](int k, void *dst, int64_t ld, int H) {   // the descriptor just added (if `only` kept it) also writes the interleaved copy
+        if (!dst || (only_a >= 0 && k != only_a && k != only_b)) return;
+        PrepDesc &d = plan.d[plan.n - 1];
+        d.dG = dst; d.ldG = ld; d.giH = H;
+    };
     add(0, 4 * H1, X1 + H1, X1, w.W1x, c->ldX1, w.W1h, c->ldH1, b ? w.W1xT : nullptr, c->ld4H1, b ? w.W1hT : nullptr, c->ld4H1);
+    with_gi(0, gi ? gi[0] : nullptr, c->ldH1, H1);
     if (two) {
         add(2, 4 * H2, 2 * H2, H2, w.W2x, c->ldH2, w.W2h, c->ldH2, b ? w.W2xT : nullptr, c->ld4H2, b ? w.W2hT : nullptr, c->ld4H2);
+        with_gi(2, gi ? gi[1] : nullptr, c->ldH2, H2);
         add(4, h, H1, H1, w.Wpd, c->ldH1, nullptr, 0, b ? w.WpT : nullptr, c->ldh, nullptr, 0);  // Wproj (H1 x h): memory [h][H1]
     }
     add(5, h, LRCN_CNNOUT, LRCN_CNNOUT, w.Wcd, LRCN_CNNOUT, nullptr, 0, nullptr, 0, nullptr, 0);   // Wcnn: memory [h][4096]
@@ -390,7 +417,12 @@ int prepare_weights(lrcn_ctx *c, const float *const p[9], bool need_bwd, bool ca
     hipStream_t st = c->stream;
     const bool two = c->nl == 2;
     // LRCN_OPT_FUSED_UPDATE: the previous train step's Adam kernel already wrote this set from these very parameters
-    if (c->opt_fused && c->shadow_valid && !cat && !gi) {
+    if (gi) {
+        int rg = ensure_gi_sets(c);
+        if (rg) return rg;
+        c->gi_live = true;   // from now on the fused update writes the interleaved copies with the other shadows
+    }
+    if (c->opt_fused && c->shadow_valid && !cat && (!gi || c->shadow_has_gi)) {
         bool same = true;
         for (int k = 0; k < 9; ++k) same = same && c->shadow_p[k] == p[k];
         if (same) return LRCN_OK;
@@ -398,19 +430,8 @@ int prepare_weights(lrcn_ctx *c, const float *const p[9], bool need_bwd, bool ca
     c->shadow_valid = false;
     c->refresh_groups = 0;  // a full shadow pass supersedes a per-group refresh sequence that was left unfinished
     PrepPlan plan{};
-    if (gi) {
-        if (!c->W1h_gi) DALLOC(c, c->W1h_gi, c->esz * 4 * H1 * c->ldH1);
-        if (two && !c->W2h_gi) DALLOC(c, c->W2h_gi, c->esz * 4 * H2 * c->ldH2);
-    }
-    plan_matrices(c, p, cur_shadows(c), need_bwd, plan);
-    if (gi) {
-        PrepDesc &d = plan.d[0];
-        d.dG = c->W1h_gi; d.ldG = c->ldH1; d.giH = H1;
-        if (two) {
-            PrepDesc &d2 = plan.d[1];
-            d2.dG = c->W2h_gi; d2.ldG = c->ldH2; d2.giH = H2;
-        }
-    }
+    void *const gi_cur[2] = {c->W1h_gi, c->W2h_gi};
+    plan_matrices(c, p, cur_shadows(c), need_bwd, plan, -1, -1, gi ? gi_cur : nullptr);
     if (cat) {  // batched decode: W1 / W2 with the x and h column blocks each padded to whole K-steps, side by side
         // cat_perm: the rows in (unit, gate)-interleaved order, for the decode step with the cell math in the GEMM's epilogue
         auto add = [&](const float *src, int R, int C, int cs, void *dA, int64_t ldA, void *dB, int64_t ldB, int permH) {
@@ -438,7 +459,8 @@ int adam_fused(lrcn_ctx *c, float *const p[9], const float *const g[9], float *c
     ctx_sizes(c, sz);
     PrepPlan plan{};
     const int ka = group < 0 ? -1 : kGroup[group][0], kb = group < 0 ? -1 : kGroup[group][1];
-    plan_matrices(c, p, alt_shadows(c), true, plan, ka, kb);
+    if (c->gi_live && (r = ensure_gi_sets(c))) return r;
+    plan_matrices(c, p, alt_shadows(c), true, plan, ka, kb, c->gi_live ? c->alt_gi : nullptr);
     for (int i = 0; i < plan.n; ++i) {
         PrepDesc &d = plan.d[i];
         int k = 0;
@@ -470,6 +492,7 @@ void fused_update_done(lrcn_ctx *c, float *const p[9]) {  // every tensor's Adam
     swap_shadow_sets(c);
     for (int k = 0; k < 9; ++k) c->shadow_p[k] = p[k];
     c->shadow_valid = true;
+    c->shadow_has_gi = c->gi_live && c->alt_gi[0] != nullptr;
 }
 
 // One LSTM layer over all S steps.  Gx f32 [M][4H] holds the input-side pre-activations (+bias) on entry and the full
@@ -512,7 +535,12 @@ bool lstm_fused_on(lrcn_ctx *c, int B, int H, int64_t ldH, int64_t ld4H) {
 bool lstm_epi_on(lrcn_ctx *c, int B) {
     const char *k = getenv("LRCN_LSTM_EPI"), *kb = getenv("LRCN_BG_ROUTE");
     return c->dt == GEMM_T_BF16 && c->vgg_wg_cap >= 8 && c->vgg_loaded && B >= 256 && B <= 512 && !(c->H1 & 3) && !(c->H2 & 3) &&
-           (k && k[0] == '1') && !(kb && kb[0] == '0');
+           (k && (k[0] == '1' || k[0] == 'f')) && !(kb && kb[0] == '0');
+}
+// LRCN_LSTM_EPI=f: the forward recurrence only (its launch has 32 workgroups -- one per free CU; the backward dh GEMM has N = H: 8 tiles)
+bool lstm_epi_bwd_on(lrcn_ctx *c, int B, int H) {
+    const char *k = getenv("LRCN_LSTM_EPI");
+    return lstm_epi_on(c, B) && k && k[0] == '1' && H >= 128;   // its GEMM has N = H columns: at least one 128-column tile
 }
 int lstm_layer_fwd(lrcn_ctx *c, int S, int B, int H, int64_t ldH, int64_t ld4H, float *Gx, const void *Wh, void *acts,
                    float *Call, void *Hall, const void *Wh_gi = nullptr) {
@@ -564,7 +592,7 @@ int lstm_layer_bwd(lrcn_ctx *c, int S, int B, int H, int64_t ld4H, const void *a
                    const void *WhT, void *dZ) {
     const int dt = c->dt;
     SegScope seg(c, LRCN_SEG_REC_BWD, c->stream, (double)(S - 1) * 4.0 * H * H * c->esz);
-    if (!lstm_fused_on(c, B, H, round_up64(H, 64), ld4H) && lstm_epi_on(c, B)) {
+    if (!lstm_fused_on(c, B, H, round_up64(H, 64), ld4H) && lstm_epi_bwd_on(c, B, H)) {
         // cell backward of the last step, then one launch per step: dh_rec = dZ[s] Wh with the cell backward of s-1 in its epilogue
         k_lstm_bwd(c->stream, dt, boff(acts, (int64_t)(S - 1) * B * ld4H, c->esz), ld4H, S > 1 ? Call + (int64_t)(S - 2) * B * H : nullptr,
                    Call + (int64_t)(S - 1) * B * H, dHall + (int64_t)(S - 1) * B * H, H, nullptr, 0, c->dc, 1, B, H,
@@ -920,8 +948,8 @@ bool decode_epi_on(const lrcn_ctx *c, int B) {
     const char *k = getenv("LRCN_DECODE_EPI");  // read per call (the tests switch it inside one process)
     return !(k && k[0] == '0') && c->dt == GEMM_T_BF16 && B >= 256 && !(c->H1 & 3) && !(c->H2 & 3);
 }
-int decode_gates_epi(lrcn_ctx *c, const void *xh, int64_t ldxh, const void *Wcat, int K, const float *bias, int B, int H, float *cstate,
-                     void *h_out, int64_t ld_h_out, float *h_f32) {
+int decode_gates_epi(lrcn_ctx *c, const void *xh, int64_t ldxh, const void *Wcat, int K, const float *bias, int B, int H, const float *c_prev,
+                     const int32_t *c_prev_idx, float *c_out, void *h_out, int64_t ld_h_out) {
     // h_out must NOT be the h columns of `xh`: every tile of this launch reads them as A-operand columns, and tiles of one row block run in
     // different rounds (2.5 rounds of 256 x 128 tiles at 5120 x 4000), so an in-place h(t) would reach tiles that still need h(t-1).
     GemmArgs g{};
@@ -936,34 +964,76 @@ int decode_gates_epi(lrcn_ctx *c, const void *xh, int64_t ldxh, const void *Wcat
     g.zero_page = c->zero_page;
     g.lstm.H = H; g.lstm.ld_a = 4 * H; g.lstm.ld_h = ld_h_out;
     g.lstm.Gx = bias; g.lstm.gx_bcast = 1;
-    g.lstm.c_prev = cstate; g.lstm.c_out = cstate;   // in place: every element is read and written by the same thread
+    // the cell state of row r continues its PARENT hypothesis' (lrcn.jl:673-676): read through c_prev_idx (round 6; NULL = the first step,
+    // zero state) into the other buffer of the pair -- no gather launch between the steps
+    g.lstm.c_prev = c_prev; g.lstm.c_prev_idx = c_prev_idx; g.lstm.c_out = c_out;
     g.lstm.acts = nullptr;
     g.lstm.h_new = h_out;
-    g.lstm.h_f32 = h_f32;
+    g.lstm.h_f32 = nullptr;
     hipError_t e = launch_gemm_8p(c->stream, g);
     if (e != hipSuccess) FAIL(c, LRCN_EHIP, "decode step (gate GEMM + cell epilogue): %s", hipGetErrorString(e));
     return LRCN_OK;
 }
 
-int step_decode(lrcn_ctx *c, const float *const p[9], int B, const DropSpec &d2, bool epi = false) {
+// The logits GEMM of a batched decode step with softmax + top-K in its epilogue (gemm_8p.hip GEMM_OUT_SMAX_TOPK; round 6): x * w[end-1] .+ w[end]
+// (lrcn.jl:550) is reduced tile by tile to per-row records and merged by k_softmax_topk_merge -- the B x V f32 logits (218 MB per step at
+// 5120 x 10640) are never written, and softmax_topk_rows_kernel's pass over them disappears.  LRCN_DECODE_SMAX=0: GEMM + that kernel.
+bool decode_smax_on(const lrcn_ctx *c, int B, int K) {
+    const char *k = getenv("LRCN_DECODE_SMAX");  // read per call (the tests switch it inside one process)
+    return !(k && k[0] == '0') && c->dt == GEMM_T_BF16 && B >= 256 && K < SMAX_KC && c->V >= 256 && !(c->V & 3) && c->H2 > 64;  // (>= 2 K-tiles)
+}
+int decode_logits_smax(lrcn_ctx *c, const void *hT, int64_t ldh, const float *bias, int B, int K) {
+    const int V = c->V, H2 = c->H2, nrec = 2 * ((V + 255) / 256);
+    if (!c->smax_part) DALLOC(c, c->smax_part, sizeof(float) * (size_t)c->maxB * nrec * SMAX_REC);
+    GemmArgs g{};
+    g.dtype = c->dt;
+    g.A = hT; g.lda = ldh;
+    g.B = c->Wod; g.ldb = c->ldH2;
+    g.M = B; g.N = V;
+    g.K = (int)round_up64(H2, 64);
+    if (g.K > ldh || g.K > c->ldH2) FAIL(c, LRCN_EINVAL, "decode logits: K = %d exceeds the operand rows", g.K);
+    g.bias = bias;
+    g.a_mode = GEMM_A_PLAIN;
+    g.out_mode = GEMM_OUT_SMAX_TOPK;
+    g.zero_page = c->zero_page;
+    g.smax.part = c->smax_part; g.smax.nrec = nrec;
+    hipError_t e = launch_gemm_8p(c->stream, g);
+    if (e != hipSuccess) FAIL(c, LRCN_EHIP, "decode step (logits GEMM + softmax / top-K epilogue): %s", hipGetErrorString(e));
+    if (!k_softmax_topk_merge(c->stream, c->smax_part, nrec, B, K, c->st_topi, c->st_topv)) FAIL(c, LRCN_EINVAL, "softmax / top-K merge: K = %d, %d records", K, nrec);
+    return LRCN_OK;
+}
+
+int step_decode(lrcn_ctx *c, const float *const p[9], int B, const DropSpec &d2, bool epi = false, const int32_t *parent = nullptr, bool first = false,
+                int smax_K = 0) {   // smax_K > 0 (epi only): the logits end as st_topi / st_topv (decode_logits_smax) instead of st_logits
     const int dt = c->dt, H1 = c->H1, H2 = c->H2, h = c->h, V = c->V;
     hipStream_t st = c->stream;
     void *h1T = boff(c->st_xh1, c->ldX1, c->esz), *h2T = boff(c->st_xh2, c->ldH2, c->esz);
     if (epi) {
         // the cell epilogue writes h(t) to st_h1 / st_h2 (never into the [x | h] operand it is still reading); k_gather_state rebuilds
         // the h blocks of st_xh1 / st_xh2 from the f32 states for the next step
-        int r = decode_gates_epi(c, c->st_xh1, c->ldXH1, c->W1cat, (int)c->ldX1 + H1, p[1], B, H1, c->st_f32[1], c->st_h1, c->ldH1, c->st_f32[0]);
+        // (epi: cell states ping-pong st_f32[1] -> st2_f32[1] / st_f32[3] -> st2_f32[3], read through `parent`; the caller swaps the pairs)
+        int r = decode_gates_epi(c, c->st_xh1, c->ldXH1, c->W1cat, (int)c->ldX1 + H1, p[1], B, H1, first ? nullptr : c->st_f32[1], parent, c->st2_f32[1],
+                                 c->st_h1, c->ldH1);
         if (r) return r;
         if (c->nl == 1) {
-            GEMM(c, dt, c->st_h1, c->ldH1, c->Wod, c->ldH2, c->st_logits, c->ldV, B, V, H2, p[8], true);
+            if (smax_K > 0) {
+                if ((r = decode_logits_smax(c, c->st_h1, c->ldH1, p[8], B, smax_K))) return r;
+            } else {
+                GEMM(c, dt, c->st_h1, c->ldH1, c->Wod, c->ldH2, c->st_logits, c->ldV, B, V, H2, p[8], true);
+            }
             KCHK(c, "step_decode (1 layer, cell epilogue)");
             return LRCN_OK;
         }
         GEMM(c, dt, c->st_h1, c->ldH1, c->Wpd, c->ldH1, c->st_xh2, c->ldXH2, B, h, H1, nullptr, false);
         k_concat_x2(st, dt, c->st_xh2, c->ldXH2, c->xcnn, c->ldh, 1, B, h, h, d2);
-        r = decode_gates_epi(c, c->st_xh2, c->ldXH2, c->W2cat, (int)c->ldH2 + H2, p[3], B, H2, c->st_f32[3], c->st_h2, c->ldH2, c->st_f32[2]);
+        r = decode_gates_epi(c, c->st_xh2, c->ldXH2, c->W2cat, (int)c->ldH2 + H2, p[3], B, H2, first ? nullptr : c->st_f32[3], parent, c->st2_f32[3],
+                             c->st_h2, c->ldH2);
         if (r) return r;
-        GEMM(c, dt, c->st_h2, c->ldH2, c->Wod, c->ldH2, c->st_logits, c->ldV, B, V, H2, p[8], true);
+        if (smax_K > 0) {
+            if ((r = decode_logits_smax(c, c->st_h2, c->ldH2, p[8], B, smax_K))) return r;
+        } else {
+            GEMM(c, dt, c->st_h2, c->ldH2, c->Wod, c->ldH2, c->st_logits, c->ldV, B, V, H2, p[8], true);
+        }
         KCHK(c, "step_decode (cell epilogue)");
         return LRCN_OK;
     }
@@ -1417,7 +1487,8 @@ int lrcn_refresh_shadows_group(lrcn_ctx *c, const float *const p[9], int group, 
     if (r) return r;
     if (c->refresh_groups == 0) c->shadow_valid = false;  // first group of a step: the current set describes the OLD parameters from now on
     PrepPlan plan{};
-    plan_matrices(c, p, alt_shadows(c), true, plan, kGroup[group][0], kGroup[group][1]);
+    if (c->gi_live && (r = ensure_gi_sets(c))) return r;
+    plan_matrices(c, p, alt_shadows(c), true, plan, kGroup[group][0], kGroup[group][1], c->gi_live ? c->alt_gi : nullptr);
     if (plan.n > 0) {  // LRCN-1f has no W2 / Wproj: an empty group is only counted
         k_prepare_weights(stream ? reinterpret_cast<hipStream_t>(stream) : c->stream, c->dt, plan);
         KCHK(c, "refresh_shadows_group");
@@ -1790,6 +1861,7 @@ int lrcn_beam_search_batch(lrcn_ctx *c, const float *const p[9], const float *fe
     const int R = N * K, Lh = nword + 2;
     hipStream_t st = c->stream;
     const bool epi = decode_epi_on(c, R);
+    const bool smax = epi && decode_smax_on(c, R, K);
     int r = prepare_weights(c, p, false, true, false, epi);
     if (r) return r;
     // input = input * param[end-3] per image (lrcn.jl:611), each row repeated for the image's K hypotheses
@@ -1810,17 +1882,30 @@ int lrcn_beam_search_batch(lrcn_ctx *c, const float *const p[9], const float *fe
     DropSpec none{};
     int cur = 0;
     for (int current = 1; current <= nword + 1; ++current) {
-        k_embed_gather(st, dt, c->WeT, c->ldE, c->bs_last, 1, R, E, none, c->st_xh1, c->ldXH1);  // lrcn.jl:650
-        r = step_decode(c, p, R, none, epi);                                                // :651, all N*K hypotheses batched
-        if (r) return r;
-        if (!k_softmax_topk_rows(st, c->st_logits, c->ldV, R, V, K, c->st_topi, c->st_topv)) {  // :652, :655-656 in one pass
+        if (epi) {
+            // one launch: embedding of every hypothesis' last token (lrcn.jl:650) + h1 / h2 of its parent (:673-676) into the [x | h] operands
+            const bool two = c->nl == 2;
+            k_decode_prep(st, c->WeT, c->ldE, c->bs_last, current > 1 ? c->st_parent : nullptr, R, E, c->st_h1, c->ldH1, H1, two ? c->st_h2 : nullptr,
+                          c->ldH2, H2, c->st_xh1, c->ldXH1, c->ldX1, two ? c->st_xh2 : nullptr, c->ldXH2, c->ldH2);
+            r = step_decode(c, p, R, none, true, current > 1 ? c->st_parent : nullptr, current == 1, smax ? K : 0);   // :651, all N*K hypotheses batched
+            if (r) return r;
+            std::swap(c->st_f32[1], c->st2_f32[1]);
+            if (two) std::swap(c->st_f32[3], c->st2_f32[3]);
+        } else {
+            k_embed_gather(st, dt, c->WeT, c->ldE, c->bs_last, 1, R, E, none, c->st_xh1, c->ldXH1);  // lrcn.jl:650
+            r = step_decode(c, p, R, none, false);                                          // :651, all N*K hypotheses batched
+            if (r) return r;
+        }
+        if (smax) {
+            // :652, :655-656 happened in the logits GEMM's epilogue + merge
+        } else if (!k_softmax_topk_rows(st, c->st_logits, c->ldV, R, V, K, c->st_topi, c->st_topv)) {  // :652, :655-656 in one pass
             k_softmax_rows(st, c->st_logits, c->ldV, R, V, c->st_prob, c->ldV);
             k_topk_rows(st, c->st_prob, c->ldV, R, V, K, c->st_topi, c->st_topv);
         }
         k_beam_update(st, c->st_topi, c->st_topv, c->bs_seq[cur], c->bs_seq[cur ^ 1], c->bs_p, c->st_parent, c->bs_last, c->bs_done,
                       c->bs_ndone, c->bs_res_tok, c->bs_res_len, c->bs_res_p, N, K, Lh, current, nword, LRCN_EOS);
         cur ^= 1;
-        {   // :673-676: the four states follow their parents; the T copies of h1 / h2 for the next step's GEMMs ride along
+        if (!epi) {   // :673-676: the four states follow their parents; the T copies of h1 / h2 for the next step's GEMMs ride along
             void *const hT[4] = {boff(c->st_xh1, c->ldX1, c->esz), nullptr, boff(c->st_xh2, c->ldH2, c->esz), nullptr};
             const int64_t ldT[4] = {c->ldXH1, 0, c->ldXH2, 0};
             k_gather_state(st, dt, c->st_f32, c->st2_f32, hT, ldT, Hs, c->st_parent, R);

@@ -100,3 +100,62 @@ def test_5120_hypotheses_beside_a_concurrent_vgg_forward(monkeypatch):
     assert busy, "the VGG forwards finished before the decode: nothing ran beside it"
     vctx.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("smax", ["1", "0"])
+def test_fused_softmax_topk_follows_probabilities_in_a_tie_group_across_records(smax, monkeypatch):
+    """Round 6: from 256 hypotheses the logits GEMM reduces its tiles to per-row records {max, sum exp, 6 best logits} of 128 columns each and
+    a merge kernel ranks them (gemm_8p.hip GEMM_OUT_SMAX_TOPK, kernels.hip softmax_topk_merge_kernel) -- the f32 logits are never written.
+    The reference ranks float32 PROBABILITIES with a stable sort (lrcn.jl:652-656), so distinct logits whose probabilities round to one
+    float form a tie group whose LOWEST column wins.  Wout = 0 makes the logits = bout exactly; columns 300 < 400 < 500 (two different
+    128-column records) get x, nextafter(x), nextafter(nextafter(x)): a logit-ranked top-1 returns 500, the reference 300 -- at every step
+    and for every one of the 256 images.  LRCN_DECODE_SMAX=0: the same decode through GEMM + softmax_topk_rows_kernel."""
+    E = H = 128
+    V, K, nword, N = 600, 1, 4, 256
+    m = orc.init_weights(E, H, H, V, seed=1)
+    m.p["Wout"][:] = 0.0
+    bout = np.full(V, -4.0, np.float32)
+    bout[0] = -9.0
+    x = np.float32(1e-3)
+    bout[300] = x
+    bout[400] = np.nextafter(x, np.float32(1.0))
+    bout[500] = np.nextafter(bout[400], np.float32(1.0))
+    m.p["bout"][:] = bout[None, :]
+    lse = np.log(np.exp(bout.astype(np.float64)).sum())
+    pf = np.exp(bout.astype(np.float64) - lse).astype(np.float32)
+    assert bout[300] < bout[400] < bout[500] and pf[300] == pf[400] == pf[500]
+    feats = (np.random.default_rng(0).standard_normal((N, 4096)) * 0.05).astype(np.float32)
+    ctx = L.Context(E, H, H, V, max_B=N * K, max_T=1, lstm_dtype=lrcn_amd.LRCN_BF16)
+    monkeypatch.setenv("LRCN_DECODE_SMAX", smax)
+    got = L.beam_search_batch(ctx, L.model_from_arrays(m.p), L.to_jl(feats), K, nword)
+    want = [1] + [300] * (nword + 1)
+    assert all(t == want for t, _ in got), [t for t, _ in got if t != want][:3]
+    ref_p = float(pf[300]) ** (nword + 1)
+    assert all(abs(p - ref_p) <= 1e-4 * ref_p for _, p in got)
+    ctx.close()
+
+
+@pytest.mark.parametrize("V,K", [(10640, 5), (7732, 3), (1028, 5), (256, 2)])
+def test_fused_softmax_topk_equals_the_row_kernel(V, K, monkeypatch):
+    """The same decode with the logits' softmax / top-K in the GEMM epilogue and through softmax_topk_rows_kernel, on random (not peaky)
+    distributions at V = the benchmark's, V = 7732 (a last tile of 52 columns: one record with 52 valid columns, one with none), 1028 (4
+    columns in the fifth tile) and 256 (one tile): the first step -- identical inputs on both sides, no state yet -- must return the same K
+    tokens per image and probabilities to 1e-5 (sums in another order); nword = 1 so that nothing else enters."""
+    E = H = 128
+    N = 300 // K + 1
+    while N * K < 256:
+        N += 1
+    m = orc.init_weights(E, H, H, V, seed=V)
+    m.p["Wout"] *= 4.0
+    m.p["bout"][:] = (np.random.default_rng(V).standard_normal((1, V)) * 1.5).astype(np.float32)
+    feats = (np.random.default_rng(1).standard_normal((N, 4096)) * 0.05).astype(np.float32)
+    ctx = L.Context(E, H, H, V, max_B=N * K, max_T=1, lstm_dtype=lrcn_amd.LRCN_BF16)
+    param = L.model_from_arrays(m.p)
+    out = {}
+    for knob in ("1", "0"):
+        monkeypatch.setenv("LRCN_DECODE_SMAX", knob)
+        out[knob] = L.beam_search_batch(ctx, param, L.to_jl(feats), K, 1)
+    for (ta, pa), (tb, pb) in zip(out["1"], out["0"]):
+        assert ta == tb, (ta, tb)
+        assert abs(pa - pb) <= 1e-5 * abs(pb) + 1e-30, (pa, pb)
+    ctx.close()

@@ -60,6 +60,50 @@ def test_fused_update_reproduces_the_separate_passes_bit_for_bit(dtype, n_layers
         np.testing.assert_allclose(a, b, rtol=0, atol=1e-6)
 
 
+@pytest.mark.parametrize("mode", ["train_step", "groups"])
+def test_fused_update_keeps_the_gate_interleaved_copies_of_the_cell_epilogue_route(mode, monkeypatch):
+    """Round 6: at 256..512 rows beside the capped VGG grids a training step may run its forward recurrence as GEMM + cell epilogue
+    (LRCN_LSTM_EPI=f), which reads a THIRD copy of the recurrent weights with (unit, gate)-interleaved rows.  Under
+    LRCN_OPT_FUSED_UPDATE that copy, too, is written by the Adam kernel into the second shadow set (before: the route forced a full
+    shadow pass every step -- 0.26 ms at the benchmark's size, more than the epilogue saved).  Five steps with the option on must follow
+    the trajectory of the option off (which remakes every copy from the parameters at every call)."""
+    monkeypatch.setenv("LRCN_LSTM_EPI", "f")
+    E, H, V, B, T = 72, 136, 301, 256, 4
+    res = []
+    for fused in (False, True):
+        ctx = L.Context(E, H, H, V, max_B=B, max_T=T, lstm_dtype=lrcn_amd.LRCN_BF16, vgg_dtype=lrcn_amd.LRCN_BF16, max_images=1)
+        L.vgg_load(ctx, *L.synthetic_vgg_weights(seed=1))
+        L.vgg_set_wg_cap(ctx, 224)
+        ctx.set_option(_lib.LRCN_OPT_FUSED_UPDATE, 1 if fused else 0)
+        ctx.set_option(_lib.LRCN_OPT_DETERMINISTIC, 1)   # no float atomics: the two trajectories may be compared tightly
+        param = L.initweights(ctx, seed=11)
+        optim = L.initparams(param)
+        grads = L.zeros_like_model(param)
+        rng = np.random.default_rng(5)
+        losses = []
+        for k in range(5):
+            feats = L.to_jl((rng.standard_normal((B, 4096)) * 0.05).astype(np.float32))
+            toks = rng.integers(0, V, size=(T, B)).astype(np.int32)
+            if mode == "train_step":
+                losses.append(L.train_step(ctx, param, optim, grads, feats, toks, pdrop=0.0, want_loss=True))
+            else:
+                _, val = L.lossgradient(ctx, param, feats, toks, grads=grads)
+                optim.t += 1
+                for g in range(5):
+                    L.update_group(ctx, param, grads, optim, g)
+                losses.append(val)
+        torch.cuda.synchronize()
+        res.append((np.array(losses), [L.from_jl(p).copy() for p in param]))
+        ctx.close()
+    (la, pa), (lb, pb) = res
+    assert la[-1] < la[0]
+    # (a STALE interleaved copy -- the previous step's recurrent weights -- moves the loss in its 4th digit; the two update kernels' own
+    # last-bit differences stay below 1e-8)
+    np.testing.assert_allclose(la, lb, rtol=1e-7)
+    for k, (a, b) in enumerate(zip(pa, pb)):
+        np.testing.assert_allclose(a, b, rtol=0, atol=2e-5, err_msg=str(k))   # (Adam turns a last-bit gradient difference into a fraction of lr = 1e-3)
+
+
 def test_first_fused_step_equals_unfused_exactly():
     """One step from identical state: parameters and moments after the fused kernel are bit-identical to adam_kernel's (Wembed excluded:
     its GRADIENT is an atomic sum)."""

@@ -353,6 +353,35 @@ def test_recurrence_kernel_routes_by_batch_size_vs_oracle_bf16(B):
     ctx.close()
 
 
+@pytest.mark.parametrize("B,H,knob", [(256, 200, "1"), (256, 200, "f"), (300, 72, "f"), (300, 72, "1"), (300, 136, "1")])
+def test_cell_epilogue_training_route_partial_tiles_vs_oracle(B, H, knob, monkeypatch):
+    # Round 6: the forward cell epilogue's threads own four consecutive units of a row and request c_prev / Gx before the accumulators
+    # are staged.  H = 200: 800 gate columns = six full 128-column tiles + one of 32 columns (8 units: two unit quads, six masked);
+    # H = 72: one tile of 288 columns -> 128 + 128 + 32; B = 300: a row-block tail of 44 rows.  LRCN_LSTM_EPI=f: forward epilogue with the
+    # two-launch backward recurrence (the route a 256-row training step takes by default since round 6), =1: both (the backward one
+    # needs H >= 128 -- its GEMM has N = H -- and is skipped below that: H = 72 then runs as "f"; H = 136: tiles of 128 + 8 units).
+    rng = np.random.default_rng(B + H)
+    E, V, T = 64, 300, 4
+    m = orc.init_weights(E, H, H, V, seed=5)
+    for n in ("W1", "W2", "Wout", "Wproj"):
+        m.p[n] *= 2.0
+    feats = (rng.standard_normal((B, 4096)) * 0.05).astype(np.float32)
+    tokens = rng.integers(0, V, size=(T, B)).astype(np.int32)
+    mask1 = ((rng.random((T + 1, B, E)) > 0.3) / 0.7).astype(np.float32)
+    mask2 = ((rng.random((T + 1, B, H)) > 0.3) / 0.7).astype(np.float32)
+    ref_loss = orc.loss(m, feats, tokens, mask1=mask1, mask2=mask2)
+    emu_loss, emu_g = emulated_reference(m, feats, tokens, mask1=mask1, mask2=mask2)
+    ctx = L.Context(E, H, H, V, max_B=B, max_T=T, lstm_dtype=lrcn_amd.LRCN_BF16, vgg_dtype=lrcn_amd.LRCN_BF16, max_images=1)
+    L.vgg_load(ctx, *L.synthetic_vgg_weights(seed=1))
+    L.vgg_set_wg_cap(ctx, 224)
+    monkeypatch.setenv("LRCN_LSTM_EPI", knob)
+    monkeypatch.setenv("LRCN_TRACE_ROUTES", "0")
+    grads, val = L.lossgradient(ctx, L.model_from_arrays(m.p), L.to_jl(feats), tokens, mask1=mask1, mask2=mask2)
+    assert abs(val - ref_loss) <= 2e-2 * abs(ref_loss), (B, H, val, ref_loss)
+    assert_bf16_matches_emulation(val, grads, emu_loss, emu_g, "cell epilogue %s, B=%d H=%d" % (knob, B, H))
+    ctx.close()
+
+
 @pytest.mark.parametrize("B,H", [(40, 320), (32, 1000), (100, 512), (21, 100)])
 def test_fused_recurrence_small_batch_forms_equal_ring_forms(B, H, monkeypatch):
     # lstm_fused.hip has two forms of the one-launch-per-timestep kernels: 16 hidden units per workgroup with one LDS-DMA ring per wave
