@@ -9,7 +9,7 @@ enum { GEMM_OUT_PLAIN = 0, GEMM_OUT_CONV = 1, GEMM_OUT_POOL = 2, GEMM_OUT_LSTM_F
 
 // GEMM_OUT_SMAX_TOPK (gemm_8p.hip, bf16, 256 x 256 tiles; round 6): the logits GEMM of a batched beam-decode step whose C never reaches HBM.
 // softmax + sortperm of lrcn.jl:652-656 need, per row, max / sum-exp over all V columns and the K best columns; each tile reduces ITS 256
-// columns (+ bias) to two records per row -- one per 128-column half: {max, sum exp(x - max), the SMAX_KC largest logits and their column ids}
+// columns (+ bias) to two records per row -- 128 columns each, as alternating runs of 32: {max, sum exp(x - max), the SMAX_KC largest logits and their column ids}
 // -- and softmax_topk_merge_kernel (kernels.hip) combines the V / 128 records of a row.  218 MB of f32 logits per step at 5120 x 10640 become
 // 28 MB of records.  A record is SMAX_REC floats (64 bytes): [0] max, [1] sum, [2 .. 2+KC) values, [8 .. 8+KC) column ids (int bits).
 enum { SMAX_KC = 6, SMAX_REC = 16 };

@@ -545,8 +545,8 @@ __device__ __forceinline__ bool gemm8p_tile(const GemmArgs &g, unsigned char *sm
         static_assert(BM == 256 && BN == 256 && SWAP && !F8, "built for the 256 x 256 tile");
         // Two phases, one per 128-column half h of the tile: the waves that own those columns (wc >> 1 == h) stage accumulator + bias as f32
         // (256 rows x 512 bytes = the whole ring; 16-byte chunk c of row r at chunk c ^ (r & 31)), columns past N as -inf; then thread t scans
-        // 64 of them for row t >> 1 (part t & 1) and carries {max, sum exp, SMAX_KC best} over both phases: its 128 columns are
-        // n0 + 128 h + 64 part + [0, 64), h = 0, 1.  Pass A of a phase finds the 64 values' maximum, pass B (a second LDS read: cheaper than 64
+        // 64 of them for row t >> 1 (part t & 1: columns [0, 32) + [64, 96) resp. [32, 64) + [96, 128) of the half) and carries {max, sum exp,
+        // SMAX_KC best} over both phases: 128 columns per record.  Pass A of a phase finds the 64 values' maximum, pass B (a second LDS read: cheaper than 64
         // live registers beside the other half's accumulators) adds exp(x - max) and offers every value that beats the list's last entry.
         // List order: value descending, equal values by ascending column (columns are scanned ascending and only a strictly larger value
         // moves in front of an entry).
@@ -586,10 +586,15 @@ __device__ __forceinline__ bool gemm8p_tile(const GemmArgs &g, unsigned char *sm
             __syncthreads();
             const unsigned char *rowp = smem + srow * 512;
             const int sw = srow & 31;
+            // the thread's 16 chunks of this half: chunk id cid(c) = (c & 7) | (part << 3) | ((c >> 3) << 4), i.e. columns [0, 32) + [64, 96) of the
+            // half for part 0 and [32, 64) + [96, 128) for part 1, ascending in c.  `part` sits in bit 3 of the chunk id because a 16-lane group
+            // of the LDS read holds 8 rows x 2 parts and the rows' swizzle varies bits 0..2: bit 3 keeps the two parts on different banks
+            // (with part in bit 4 -- contiguous 64-column parts -- every read was a two-way conflict).
+            auto cid = [&](int c) { return (c & 7) | (part << 3) | ((c >> 3) << 4); };
             float cm = -INFINITY;
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
-                const f32x4v x = *reinterpret_cast<const f32x4v *>(rowp + (((part * 16 + c) ^ sw) << 4));
+                const f32x4v x = *reinterpret_cast<const f32x4v *>(rowp + ((cid(c) ^ sw) << 4));
                 cm = fmaxf(cm, fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])));
             }
             if (cm > m_run) {   // (cm = -inf -- every column of this part past N -- never enters)
@@ -597,31 +602,36 @@ __device__ __forceinline__ bool gemm8p_tile(const GemmArgs &g, unsigned char *sm
                 m_run = cm;
             }
             if (cm != -INFINITY) {
-                const int cbase = n0 + h * 128 + part * 64;
+                float s4[4] = {0.f, 0.f, 0.f, 0.f};   // four independent partial sums: no 128-long dependent chain of adds
 #pragma unroll 4
                 for (int c = 0; c < 16; ++c) {
-                    const f32x4v x = *reinterpret_cast<const f32x4v *>(rowp + (((part * 16 + c) ^ sw) << 4));
+                    const f32x4v x = *reinterpret_cast<const f32x4v *>(rowp + ((cid(c) ^ sw) << 4));
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const float xv = x[k];
-                        s_run += __expf(xv - m_run);
-                        if (xv > tv[SMAX_KC - 1]) {
-                            float cv = xv;
-                            int ci = cbase + 4 * c + k;
-                            bool ins = false;
+                    for (int k = 0; k < 4; ++k) s4[k] += __expf(x[k] - m_run);
+                    if (fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])) > tv[SMAX_KC - 1]) {   // one test per chunk: most chunks offer nothing
+                        const int cbase = n0 + h * 128 + 4 * cid(c);
 #pragma unroll
-                            for (int j = 0; j < SMAX_KC; ++j) {
-                                ins = ins || cv > tv[j];
-                                if (ins) {
-                                    const float ov = tv[j];
-                                    const int oi = ti[j];
-                                    tv[j] = cv; ti[j] = ci;
-                                    cv = ov; ci = oi;
+                        for (int k = 0; k < 4; ++k) {
+                            const float xv = x[k];
+                            if (xv > tv[SMAX_KC - 1]) {
+                                float cv = xv;
+                                int ci = cbase + k;
+                                bool ins = false;
+#pragma unroll
+                                for (int j = 0; j < SMAX_KC; ++j) {
+                                    ins = ins || cv > tv[j];
+                                    if (ins) {
+                                        const float ov = tv[j];
+                                        const int oi = ti[j];
+                                        tv[j] = cv; ti[j] = ci;
+                                        cv = ov; ci = oi;
+                                    }
                                 }
                             }
                         }
                     }
                 }
+                s_run += (s4[0] + s4[1]) + (s4[2] + s4[3]);
             }
             __syncthreads();   // the ring is overwritten by the next phase / the next tile's DMA
         }

@@ -528,10 +528,19 @@ bool lstm_fused_on(lrcn_ctx *c, int B, int H, int64_t ldH, int64_t ld4H) {
     return !(k && k[0] == '0') && B <= (mb ? atoi(mb) : 128) && lstm_fused_eligible(c->dt, B, H, ldH, ld4H);
 }
 // The recurrent GEMM with the cell math in its epilogue (gemm_8p.hip GEMM_OUT_LSTM_*), for the two-stream training step at 256..512
-// rows per GPU: one launch of 32 (forward) / 8 (backward) workgroups per timestep instead of GEMM + cell kernel.  MEASURED AND LEFT
-// OFF (LRCN_LSTM_EPI=1 turns it on; tests/test_gpu_lstm_parity.py checks it against the CPU oracle): the cell math is HBM/L2 traffic
-// (9 MB per step) that wants many CUs, and inside a 32- or 8-workgroup GEMM it runs at those few CUs' bandwidth -- per timestep,
-// beside the VGG forward: forward 45 us fused vs 27 + 9.6 us, backward 87 us fused vs 55 + 8.7 us; training step 7.49 vs 7.22 ms.
+// rows per GPU: one launch of 32 (forward) / 8 (backward) workgroups per timestep instead of GEMM + cell kernel.  LRCN_LSTM_EPI=f turns
+// the forward one on, =1 both (tests/test_gpu_lstm_parity.py checks them against the CPU oracle).  OFF BY DEFAULT, with numbers:
+//   round 2: one unit per epilogue thread -- per timestep beside the VGG forward, forward 45 us fused vs 27 + 9.6 us as two launches,
+//            backward 87 us vs 55 + 8.7 us; training step 7.49 vs 7.22 ms.
+//   round 6: the forward epilogue rewritten (four units per thread, c_prev / Gx requested before the staging, 16- / 8-byte accesses) and
+//            its gate-interleaved weight copy kept current by the fused update: the forward recurrence's segment goes 1.00 -> 0.83 ms
+//            per step (18.8 us per step and layer: FASTER than the two launches), and the training step does not move or gets slower:
+//            five same-box pairs 6.858 -> 6.942 ms mean (profiles/r06_ab_c4_step_forward_cell_epilogue.txt), with the shader clock the
+//            package holds in the timed region 2.163 -> 2.130 GHz median (bench line hw_held_in_timed_region) -- the convolution launches
+//            beside it slow by what the chain gained, once more.  The backward epilogue stays at 8 workgroups (N = H:
+//            eight 128-column tiles) and 1.94 vs 1.72 ms per step; a 32-workgroup form needs split-K, whose partial sums can only be
+//            combined by a second launch or a grid barrier.
+// The same forward epilogue IS the default of the batched beam decode (decode_gates_epi below), where its GEMMs fill the chip.
 bool lstm_epi_on(lrcn_ctx *c, int B) {
     const char *k = getenv("LRCN_LSTM_EPI"), *kb = getenv("LRCN_BG_ROUTE");
     return c->dt == GEMM_T_BF16 && c->vgg_wg_cap >= 8 && c->vgg_loaded && B >= 256 && B <= 512 && !(c->H1 & 3) && !(c->H2 & 3) &&

@@ -41,6 +41,25 @@ def test_initial_loss_is_ln_V(V, B, T, deck):
     ctx.close()
 
 
+def test_one_update_from_eight_shards_equals_one_update_from_the_full_batch():
+    """VERDICT r5 next-7 (multi-GPU readiness without a second GPU): tools/shard_equivalence.py in the suite.  One training step at BASELINE
+    configs[3]'s size computed as 8 row shards of 32 -- each normalised by the GLOBAL batch (lrcn.jl:564-568), gradients summed, ONE Adam
+    step: what 8 data-parallel ranks compute -- against the same step on all 256 rows in one call: loss before, all nine summed gradients,
+    and the loss AFTER the update (the quantity a training run sees).  Only the transport (RCCL) is not exercised."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import shard_equivalence as se
+    l0_ref, l1_ref, g_ref = se.run(1)
+    l0, l1, g = se.run(8)
+    assert abs(l0 - l0_ref) <= 1e-5 * abs(l0_ref), (l0, l0_ref)
+    assert l1_ref < l0_ref   # the update moved the loss ...
+    assert abs(l1 - l1_ref) <= 5e-6 * abs(l1_ref), (l1, l1_ref)   # ... to the same place (measured 4e-7; a lost shard or a wrong normaliser is 1e-2)
+    for name, a, b in zip("W1 b1 W2 b2 Wproj Wcnn Wembed Wout bout".split(), g, g_ref):
+        rel = np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-300)
+        assert rel < 2e-2, (name, rel)
+
+
 def test_eight_shards_of_32_equal_one_batch_of_256():
     V, B, T = 10640, 256, 11
     ctx, param, feats, tokens = make(V, B, T)

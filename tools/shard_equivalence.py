@@ -44,9 +44,14 @@ def run(N):
     return loss0, loss1, out
 
 
-ref = run(1)
-print("N=1  loss before %.9f  after one update %.9f" % ref[:2])
-for N in (2, 4, 8):
-    l0, l1, g = run(N)
-    rel = [np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-300) for a, b in zip(g, ref[2])]
-    print("N=%d  loss before %.9f  after one update %.9f   gradient rel. diff vs N=1: %s" % (N, l0, l1, " ".join("%.1e" % x for x in rel)))
+def main():
+    ref = run(1)
+    print("N=1  loss before %.9f  after one update %.9f" % ref[:2])
+    for N in (2, 4, 8):
+        l0, l1, g = run(N)
+        rel = [np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-300) for a, b in zip(g, ref[2])]
+        print("N=%d  loss before %.9f  after one update %.9f   gradient rel. diff vs N=1: %s" % (N, l0, l1, " ".join("%.1e" % x for x in rel)))
+
+
+if __name__ == "__main__":
+    main()
