@@ -173,7 +173,7 @@ PEAK_HBM_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PEAK_PCIE_GBS = 64.0      # PCIe Gen5 x16, one direction
 
 
-def sub_reports(segs, n_steps):
+def sub_reports(segs, n_steps, rec=None):
     """lrcn_profile_segment's accumulators -> roofline.sub: per HBM-bound segment of SURVEY 8(d) the achieved GB/s on its ALGORITHMIC bytes
     (28 B/param for update!, one read of the recurrent weight block per timestep, (T+1) B E elements for the embedding gather, its dual's
     rows in + dense gradient out, 1 B + one element per pixel value for the preprocessing pass, the crops' bytes for the upload), the
@@ -189,6 +189,12 @@ def sub_reports(segs, n_steps):
         gbs = by / ms / 1e6
         out[names[k]] = {"GB/s": round(gbs, 1), "frac_of_peak": round(gbs / peak, 4), "peak_GB/s": peak, "ms_per_step": round(ms / n_steps, 4),
                          "algorithmic_MB_per_step": round(by / n_steps / 1e6, 3), "brackets": int(n)}
+        if rec and k in ("rec_fwd", "rec_bwd"):
+            # SURVEY 8(d) lists the recurrence as a weight stream, but from 256 rows per GPU it is a chain of 2 (B x 4H x H) contractions on the
+            # CUs the capped convolution grids leave free: what bounds it is THEIR matrix-pipe share and the launch chain, so that is stated too
+            tf = rec["gflop_per_step"] / (ms / n_steps)   # GFLOP per ms = TFLOP/s
+            out[names[k]].update({"bound_in_fact": "mfma on %d free CUs + launch chain (DESIGN section 4), not hbm" % rec["free_cus"],
+                                  "TFLOP/s": round(tf, 1), "frac_of_free_cu_mfma_peak": round(tf / (PEAK_BF16_TFLOPS * rec["free_cus"] / 256.0), 4)})
     return out
 
 
@@ -618,7 +624,9 @@ def rank_main(a, world, rank, local_rank):
         L.profile(ctx, 2)
         run(n_sub)
         torch.cuda.synchronize()
-        sub = sub_reports(L.profile_segments(ctx), n_sub)
+        free = 256 - (trainer.vgg_cap if getattr(trainer, "vgg_cap", 0) else 224)
+        rec = {"gflop_per_step": a.layers * T * 2.0 * B * 4 * H * H / 1e9, "free_cus": free} if (a.dtype == "bf16" and B >= 256 and free > 0) else None
+        sub = sub_reports(L.profile_segments(ctx), n_sub, rec)
         L.profile(ctx, 0)
         torch.cuda.synchronize()
     tt = torch.tensor([dt_s], device="cuda", dtype=torch.float64)

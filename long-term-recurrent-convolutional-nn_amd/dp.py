@@ -321,6 +321,7 @@ class DataParallelTrainer:
             env = os.environ.get("LRCN_VGG_WG_CAP")
             cap = int(env) if env is not None else vgg_wg_cap_for(param[0].device, int(rows) if rows else B_global // max(world, 1), int(vgg_chunk))
             self.ops.set_vgg_wg_cap(cap)
+            self.vgg_cap = cap   # (bench.py: the CUs left to the LSTM chain = 256 - cap)
         self._feats_buf = [None, None]  # ping-pong outputs of the side-stream VGG (one chunk each)
         # the library's weight-gradient stream must not share a hardware queue with the VGG side stream either (its dW GEMMs would run in
         # order with the convolutions): hand it a probed one.  LRCN_DP_WG_STREAM_PROBE=0: leave the library's own.

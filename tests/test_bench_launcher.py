@@ -306,6 +306,11 @@ def test_sub_reports_and_rungs_are_plain_functions():
     assert abs(sub["adam"]["GB/s"] - 4464.0) < 1.0 and sub["adam"]["peak_GB/s"] == 8000.0 and abs(sub["adam"]["frac_of_peak"] - 0.558) < 1e-3
     assert sub["upload"]["peak_GB/s"] == 64.0 and abs(sub["upload"]["GB/s"] - 55.0) < 0.1   # the upload is priced against PCIe, not HBM
     assert abs(sub["adam"]["ms_per_step"] - 0.25) < 1e-9 and abs(sub["adam"]["algorithmic_MB_per_step"] - 1116.0) < 1e-6
+    assert "TFLOP/s" not in sub["recurrence_weight_stream_fwd"]
+    # round 6: at 256 rows beside the capped convolution grids the recurrence is also priced as what it is -- contractions on the free CUs
+    sub = bench.sub_reports(segs, 8, {"gflop_per_step": 45.056, "free_cus": 32})
+    r = sub["recurrence_weight_stream_fwd"]
+    assert abs(r["TFLOP/s"] - 45.1) < 0.1 and abs(r["frac_of_free_cu_mfma_peak"] - 45.056 / 314.5) < 1e-3 and "mfma on 32 free CUs" in r["bound_in_fact"]
     names = [r[0] for r in launch.default_rungs("torch")]
     assert names == ["default", "plain"] and [r[0] for r in launch.default_rungs("auto")] == ["abi", "default", "plain"]
     plain = dict(launch.default_rungs("abi"))["plain"]
