@@ -283,12 +283,12 @@ def parse_args(argv=None):
                          "32 rows); --replicated-update selects the replicated form there")
     ap.add_argument("--replicated-update", action="store_true", help="--emulate-world N: replicated update! (the whole Adam on this rank) instead of "
                     "the sharded one")
-    ap.add_argument("--spinup-ms", type=float, default=2000.0,
+    ap.add_argument("--spinup-ms", type=float, default=150.0,
                     help="set-up, before the W warm-up steps: keep the GPU busy with VGG forwards of the benchmark's own crops for this long.  "
-                         "The chip needs load after idle before its clocks settle (round 3: steps 1..15 after idle run 7.5 -> 7.0 ms, 150 ms of spin-up; "
-                         "round 6: as the FIRST process on a fresh box five leases with 150 ms ran 6.95-7.29 ms at 2.10-2.11 GHz held, the second and third "
-                         "process on the same boxes and three fresh leases with 3 s 6.79-7.10 at 2.14-2.17 GHz: profiles/r06b_*, r06c_*); these are NOT "
-                         "training steps (no lossgradient, no update!), lie outside the timed region and are reported in the line (config.setup_spinup).  0 = off")
+                         "The chip needs ~100 ms of load after idle before its clocks settle (round 3: steps 1..15 after idle run 7.5 -> 7.0 ms); "
+                         "these are NOT training steps (no lossgradient, no update!), lie outside the timed region and are reported in the line "
+                         "(config.setup_spinup).  Longer does not help (round 6, fresh single-command leases: 150 ms 6.95 6.96 6.98 7.20 7.29 ms, "
+                         "2 s 6.75 6.99 7.00 7.02 7.09 ms -- what differs between leases is the box: profiles/r06b_*, r06d_*).  0 = off")
     ap.add_argument("--watchdog-s", type=float, default=float(os.environ.get("LRCN_BENCH_WATCHDOG_S", "900")),
                     help="self-launched jobs: kill the ranks and fail if they have not finished after this many seconds")
     a = ap.parse_args(argv)
