@@ -2115,7 +2115,9 @@ int conv_layer_fp8(lrcn_ctx *c, const void *in, const VggLayer &L, int N, void *
     g.zero_page = c->zero_page;
     g.wg_cap = c->vgg_wg_cap;
     g.tile_ctr = (c->vgg_wg_cap >= 8 && c->vgg_wg_cap <= 512) ? tile_ctr : nullptr;
-    hipError_t e = launch_conv_chunked(c->stream, g, N, 1, c->conv_chunk_bytes);
+    // the e4m3 kernel addresses its A operand with SIGNED 32-bit element offsets (gemm_8p_f8_ok: M * Cin < 2^31), half of what the bf16 / f32
+    // descriptors reach: cut at 2 GiB minus a margin (round 6: 1536 and 2048 images failed at conv2_2 -- 3.3 GB of e4m3 input in one launch)
+    hipError_t e = launch_conv_chunked(c->stream, g, N, 1, c->conv_chunk_bytes > 0 ? c->conv_chunk_bytes : 0x7F000000ll);
     if (e != hipSuccess) FAIL(c, LRCN_EHIP, "fp8 conv layer S=%d Cin=%d Cout=%d: %s", L.S, L.Cin, L.Cout, hipGetErrorString(e));
     return LRCN_OK;
 }

@@ -205,3 +205,25 @@ def test_vgg_forward_with_layer_inputs_beyond_4GiB_equals_256_image_chunks(biase
         part = L.from_jl(L.convnet_u8(ctx, imgs[s0:s0 + 256]))
         assert rel_max_err(big[s0:s0 + 256], part) <= 1e-3, s0
     ctx.close()
+
+
+def test_fp8_vgg_forward_beyond_2GiB_of_e4m3_input_equals_chunks(biased_vgg):
+    # Round 6: the e4m3 convolution kernel addresses its input with signed 32-bit element offsets, so a layer input of 2 GiB or more
+    # (conv2_2 from 1338 images: 1.6 MB of e4m3 each) must be cut into launches of whole images like the bf16 layers are at 4 GiB; before,
+    # 1536 and 2048 images per forward ended in "fp8 conv layer S=112 ...: invalid argument".  1536 images == three forwards of 512
+    # (same calibration, same kernels and tiles per image; fc6 / fc7 split K differently: 1e-3).
+    w, _ = biased_vgg
+    N = 1536
+    g = torch.Generator(device="cuda")
+    g.manual_seed(78)
+    imgs = torch.randint(0, 256, (N, 224, 224, 3), generator=g, device="cuda", dtype=torch.uint8)
+    outs = {}
+    for n in (N, 512):
+        ctx = L.Context(8, 8, 8, 17, max_B=2, max_T=1, vgg_dtype=lrcn_amd.LRCN_FP8, max_images=n)
+        L.vgg_load(ctx, *w)
+        L.vgg_calibrate(ctx, imgs[:32])
+        outs[n] = np.concatenate([L.from_jl(L.convnet_u8(ctx, imgs[s0:s0 + n])).copy() for s0 in range(0, N, n)])
+        ctx.close()
+    assert np.isfinite(outs[N]).all()
+    assert rel_max_err(outs[N], outs[512]) <= 1e-3
+

@@ -46,7 +46,7 @@ def compare(a, b, N):
     return same
 
 
-@pytest.mark.parametrize("N", [1024, 819])   # 5120 rows = 20 full row blocks; 4095 rows = an M tail in the last of 16
+@pytest.mark.parametrize("N", [1024, 819, 2048])   # 5120 rows = 20 full row blocks; 4095 rows = an M tail in the last of 16; 10240 = the C5 bench's chunk
 def test_5120_hypotheses_cell_epilogue_equals_gemm_plus_cell_kernel_and_the_oracle(N, monkeypatch):
     m = decisive_model()
     feats = (np.random.default_rng(N).standard_normal((N, 4096)) * 0.05).astype(np.float32)

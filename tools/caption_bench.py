@@ -171,7 +171,7 @@ def main():
     t_vgg = time.perf_counter() - t1
     if rank == 0:
         import bench as _bench
-        traffic, traffic_note = _bench.pmc_traffic_file("pmc_traffic_caption_bench_c5.json") if (a.vgg == "fp8" and N == 1024) else (None, "no PMC pass for this configuration")
+        traffic, traffic_note = _bench.pmc_traffic_file("pmc_traffic_caption_bench_c5.json") if (a.vgg == "fp8" and N == 2048) else (None, "no PMC pass for this configuration")
         cpu = cpu_baseline_c5(vgg_w, param, K, nword, V) if (world == 1 and not a.no_cpu_baseline) else None
         fixture = None
         if world == 1 and not a.no_fixture:
