@@ -318,3 +318,26 @@ def test_sub_reports_and_rungs_are_plain_functions():
     a = bench.parse_args(["--emulate-world", "8"])
     assert a.emulate_world == 8 and not a.replicated_update and bench.metric_name(a).startswith("EMULATED")
     assert bench.metric_name(bench.parse_args([])) == bench.HEADLINE_METRIC
+
+
+def test_hw_sampler_without_the_sysfs_nodes_is_not_an_error(tmp_path):
+    """bench.HwSampler (round 6: shader clock and socket power held in the timed region) reads amdgpu hwmon nodes; where they do not exist -- this
+    container, another driver -- the line carries {"available": false} and nothing raises.  With a directory that looks like a hwmon node it
+    samples on its thread and reports medians in MHz / W."""
+    import time as _time
+    sys.path.insert(0, ROOT)
+    import bench
+    h = bench.HwSampler(0)
+    h.start()
+    assert h.stop() == {"available": False}
+    (tmp_path / "freq1_input").write_text("2150000000\n")
+    (tmp_path / "power1_input").write_text("1300000000\n")
+    (tmp_path / "power1_cap").write_text("1400000000\n")
+    h = bench.HwSampler(0, period_s=0.001)
+    h.dir, h.bdf = str(tmp_path), "test"
+    h.start()
+    _time.sleep(0.05)
+    r = h.stop()
+    assert r["available"] and r["sclk_mhz"]["median"] == 2150.0 and r["socket_power_w"]["median"] == 1300.0 and r["power_cap_w"] == 1400.0
+    assert r["sclk_mhz"]["n"] >= 5
+
