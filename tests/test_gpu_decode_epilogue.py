@@ -136,8 +136,8 @@ def test_fused_softmax_topk_follows_probabilities_in_a_tie_group_across_records(
     ctx.close()
 
 
-@pytest.mark.parametrize("V,K", [(10640, 5), (7732, 3), (1028, 5), (256, 2)])
-def test_fused_softmax_topk_equals_the_row_kernel(V, K, monkeypatch):
+@pytest.mark.parametrize("V,K,layers", [(10640, 5, 2), (7732, 3, 2), (1028, 5, 2), (256, 2, 2), (304, 4, 1), (2052, 5, 1)])
+def test_fused_softmax_topk_equals_the_row_kernel(V, K, layers, monkeypatch):
     """The same decode with the logits' softmax / top-K in the GEMM epilogue and through softmax_topk_rows_kernel, on random (not peaky)
     distributions at V = the benchmark's, V = 7732 (a last tile of 52 columns: one record with 52 valid columns, one with none), 1028 (4
     columns in the fifth tile) and 256 (one tile): the first step -- identical inputs on both sides, no state yet -- must return the same K
@@ -146,16 +146,16 @@ def test_fused_softmax_topk_equals_the_row_kernel(V, K, monkeypatch):
     N = 300 // K + 1
     while N * K < 256:
         N += 1
-    m = orc.init_weights(E, H, H, V, seed=V)
+    m = orc.init_weights(E, H, H, V, seed=V, n_layers=layers)   # layers = 1: LRCN-1f ([embedding | x_cnn | h] operand, logits from h1)
     m.p["Wout"] *= 4.0
     m.p["bout"][:] = (np.random.default_rng(V).standard_normal((1, V)) * 1.5).astype(np.float32)
     feats = (np.random.default_rng(1).standard_normal((N, 4096)) * 0.05).astype(np.float32)
-    ctx = L.Context(E, H, H, V, max_B=N * K, max_T=1, lstm_dtype=lrcn_amd.LRCN_BF16)
+    ctx = L.Context(E, H, H, V, max_B=N * K, max_T=1, lstm_dtype=lrcn_amd.LRCN_BF16, n_layers=layers)
     param = L.model_from_arrays(m.p)
     out = {}
     for knob in ("1", "0"):
         monkeypatch.setenv("LRCN_DECODE_SMAX", knob)
-        out[knob] = L.beam_search_batch(ctx, param, L.to_jl(feats), K, 1)
+        out[knob] = L.beam_search_batch(ctx, param, L.to_jl(feats), K, 3 if layers == 1 else 1)   # (1f: a few steps, so that parent-indexed states matter)
     for (ta, pa), (tb, pb) in zip(out["1"], out["0"]):
         assert ta == tb, (ta, tb)
         assert abs(pa - pb) <= 1e-5 * abs(pb) + 1e-30, (pa, pb)
