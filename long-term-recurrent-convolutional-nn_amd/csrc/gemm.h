@@ -75,6 +75,7 @@ struct GemmArgs {
                             // fewer tiles instead of stretching the whole launch; NULL = static round-robin walk
     unsigned long long *stamps;  // kernel-development: per-tile s_memtime stamps of gemm8p_tile's segments (8 per tile), or NULL
     int splitk_forced;      // launch_gemm_8p(.., splitk): take the caller's slice count as it is (gemm.hip's 8p-bg-splitk route)
+    int splitk_no_reduce;   // ... and leave the f32 slabs [slices][M][N] in ws for the caller's next kernel to sum (no reduce launch, C untouched)
     int deterministic;      // 1: no float-atomic split-K (gemm_glds.hip takes one K range per tile; gemm_8p's slab split-K is ordered anyway)
     int dbg;                // kernel-development ablation flags (LRCN_DBG env): 8 = gemm_8p.hip does not issue the next tile's first K-tile early
     const void *zero_page;  // >= 256 zero bytes, 16-byte aligned (source of padding rows for the direct-to-LDS path) or NULL

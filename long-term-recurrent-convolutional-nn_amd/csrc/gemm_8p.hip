@@ -1252,6 +1252,7 @@ hipError_t launch_gemm_8p(hipStream_t stream, const GemmArgs &g0, int splitk) {
         if (!g.splitk_forced && gemm_8p_splitk(g, &blocks) != splitk) return hipErrorInvalidValue;
         hipError_t e = g.a_mode == GEMM_A_CONV3 ? dispatch<GEMM_A_CONV3, true>(stream, g, 1, splitk) : dispatch<GEMM_A_PLAIN, true>(stream, g, 1, splitk);
         if (e != hipSuccess) return e;
+        if (g.splitk_no_reduce) return hipSuccess;   // the caller's next kernel sums the slabs (lstm_bwd_kernel's dh_b slabs)
         return launch_splitk_reduce(stream, g, splitk);
     } else {
         splitk = 1;

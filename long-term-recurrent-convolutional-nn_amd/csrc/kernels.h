@@ -37,7 +37,7 @@ void k_lstm_fwd(hipStream_t st, int dtype, const float *G, int64_t ld_g, const f
 // dc_prev.  Writes dZ (T) [B][4H].
 void k_lstm_bwd(hipStream_t st, int dtype, const void *acts, int64_t ld_a, const float *c_prev, const float *c_new,
                 const float *dh_a, int64_t ld_dha, float *dh_b, int dh_b_read, float *dc, int dc_zero, int B, int H, void *dz,
-                int64_t ld_dz);
+                int64_t ld_dz, int nslab = 0);   // nslab > 0: dh_b = [nslab][B][H] partial sums, summed here
 
 // Small-batch fused recurrent steps (lstm_fused.hip; bf16, B <= 64): one launch = the recurrent GEMM of a timestep + the cell
 // update (forward) / the dh GEMM of step s + the cell backward of step s-1.

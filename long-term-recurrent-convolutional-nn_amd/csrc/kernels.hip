@@ -232,14 +232,17 @@ __global__ void lstm_fwd_kernel(const float *G, int64_t ld_g, const float *c_pre
 
 template <typename T>
 __global__ void lstm_bwd_kernel(const T *acts, int64_t ld_a, const float *c_prev, const float *c_new, const float *dh_a,
-                                int64_t ld_dha, float *dh_b, int dh_b_read, float *dc, int dc_zero, int B, int H, T *dz, int64_t ld_dz) {
+                                int64_t ld_dha, float *dh_b, int dh_b_read, float *dc, int dc_zero, int B, int H, T *dz, int64_t ld_dz, int nslab) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
     if (j >= H) return;
     const T *a = acts + (int64_t)b * ld_a;
     const float f = to_f32(a[j]), i = to_f32(a[H + j]), o = to_f32(a[2 * H + j]), g = to_f32(a[3 * H + j]);
     const float tc = tanhf(c_new[(int64_t)b * H + j]);
     float dh = dh_a[(int64_t)b * ld_dha + j];
-    if (dh_b) {  // recurrent dh from step s+1; left zeroed for the split-K GEMM that accumulates step s-1's into it
+    if (nslab > 0) {  // recurrent dh from step s+1 as the K slices' partial sums [nslab][B][H] of a split-K GEMM without a reduce launch, summed
+        if (dh_b_read)  // here in slice order (fixed: deterministic); the slabs are overwritten whole by step s-1's GEMM, nothing to zero
+            for (int q = 0; q < nslab; ++q) dh += dh_b[((int64_t)q * B + b) * H + j];
+    } else if (dh_b) {  // recurrent dh from step s+1; left zeroed for the split-K GEMM that accumulates step s-1's into it
         if (dh_b_read) dh += dh_b[(int64_t)b * H + j];
         dh_b[(int64_t)b * H + j] = 0.0f;
     }
@@ -1399,9 +1402,9 @@ void k_lstm_fwd(hipStream_t st, int dtype, const float *G, int64_t ld_g, const f
                                          (T *)acts, ld_a, c_new, (T *)h_new, ld_h, h_new_f32));
 }
 void k_lstm_bwd(hipStream_t st, int dtype, const void *acts, int64_t ld_a, const float *c_prev, const float *c_new,
-                const float *dh_a, int64_t ld_dha, float *dh_b, int dh_b_read, float *dc, int dc_zero, int B, int H, void *dz, int64_t ld_dz) {
+                const float *dh_a, int64_t ld_dha, float *dh_b, int dh_b_read, float *dc, int dc_zero, int B, int H, void *dz, int64_t ld_dz, int nslab) {
     DISPATCH_T(dtype, hipLaunchKernelGGL(lstm_bwd_kernel<T>, dim3(cdiv(H, 256), B), dim3(256), 0, st, (const T *)acts, ld_a,
-                                         c_prev, c_new, dh_a, ld_dha, dh_b, dh_b_read, dc, dc_zero, B, H, (T *)dz, ld_dz));
+                                         c_prev, c_new, dh_a, ld_dha, dh_b, dh_b_read, dc, dc_zero, B, H, (T *)dz, ld_dz, nslab));
 }
 void k_concat_x2(hipStream_t st, int dtype, void *x2, int64_t ld_x2, const float *xcnn, int64_t ld_xc, int S, int B, int nl, int nr,
                  DropSpec d) {

@@ -643,6 +643,43 @@ int lstm_layer_bwd(lrcn_ctx *c, int S, int B, int H, int64_t ld4H, const void *a
         KCHK(c, "lstm_layer_bwd (fused)");
         return LRCN_OK;
     }
+    // Beside the capped convolution grids at 256..512 rows the dh GEMM (M = B, N = H, K = 4H) has EIGHT 256 x 128 tiles: 8 of the 32 free CUs,
+    // 3 MB of operand ingest each (55 us per timestep).  Round 6: n = 4 K-slices per tile = 32 workgroups, each writing its partial tile to an
+    // f32 slab; the NEXT cell kernel sums the slabs (no reduce launch, fixed order: deterministic).  Four same-box pairs
+    // (profiles/r06_ab_bwd_slabs.txt): the backward recurrence's segment 1.86 -> 0.87 ms per step, the step 7.270 -> 7.241 ms (the
+    // convolution launches slow by 2.8 % beside the busier chain -- a shorter chain is returned as clock, DESIGN section 7 -- but never by
+    // more than the chain gained).  LRCN_BWD_SLABS=0 / 2..8: off / another slice count.
+    {
+        static const char *ksl = getenv("LRCN_BWD_SLABS");
+        const int nsl = ksl ? atoi(ksl) : 4;
+        const int Kp = (int)round_up64(4 * H, 64);
+        if (nsl >= 2 && nsl <= 8 && dt == GEMM_T_BF16 && c->vgg_wg_cap >= 8 && c->vgg_loaded && B >= 256 && B <= 512 && !(H & 3) && H >= 128 &&
+            Kp / 64 >= 8 * nsl && Kp <= ld4H && (size_t)nsl * B * H * sizeof(float) <= c->gemm_ws_bytes && c->gemm_ws) {
+            float *slabs = reinterpret_cast<float *>(c->gemm_ws);
+            for (int s = S - 1; s >= 0; --s) {
+                k_lstm_bwd(c->stream, dt, boff(acts, (int64_t)s * B * ld4H, c->esz), ld4H, s ? Call + (int64_t)(s - 1) * B * H : nullptr,
+                           Call + (int64_t)s * B * H, dHall + (int64_t)s * B * H, H, slabs, s < S - 1, c->dc, s == S - 1, B, H,
+                           boff(dZ, (int64_t)s * B * ld4H, c->esz), ld4H, nsl);
+                if (s > 0) {
+                    GemmArgs g{};
+                    g.dtype = dt;
+                    g.A = boff(dZ, (int64_t)s * B * ld4H, c->esz); g.lda = ld4H;
+                    g.B = WhT; g.ldb = ld4H;
+                    g.M = B; g.N = H; g.K = Kp;
+                    g.C = slabs; g.ldc = H; g.c_f32 = 1;   // (unused: the slabs are the output)
+                    g.a_mode = GEMM_A_PLAIN; g.out_mode = GEMM_OUT_PLAIN;
+                    g.zero_page = c->zero_page;
+                    g.ws = c->gemm_ws; g.ws_bytes = c->gemm_ws_bytes;
+                    g.cfg_pref = 2;
+                    g.splitk_forced = 1; g.splitk_no_reduce = 1;
+                    hipError_t e = launch_gemm_8p(c->stream, g, nsl);
+                    if (e != hipSuccess) FAIL(c, LRCN_EHIP, "lstm bwd step (split-K slabs): %s", hipGetErrorString(e));
+                }
+            }
+            KCHK(c, "lstm_layer_bwd (K slices summed by the cell kernel)");
+            return LRCN_OK;
+        }
+    }
     for (int s = S - 1; s >= 0; --s) {
         k_lstm_bwd(c->stream, dt, boff(acts, (int64_t)s * B * ld4H, c->esz), ld4H, s ? Call + (int64_t)(s - 1) * B * H : nullptr,
                    Call + (int64_t)s * B * H, dHall + (int64_t)s * B * H, H, c->dhrec, s < S - 1, c->dc, s == S - 1, B, H,

@@ -382,6 +382,36 @@ def test_cell_epilogue_training_route_partial_tiles_vs_oracle(B, H, knob, monkey
     ctx.close()
 
 
+@pytest.mark.parametrize("B,H,nsl", [(256, 256, 2), (300, 512, 4), (256, 1000, 4)])
+def test_backward_recurrence_with_k_slices_summed_by_the_cell_kernel_vs_oracle(B, H, nsl, monkeypatch):
+    # Round 6, LRCN_BWD_SLABS=n (default 4 at 256..512 rows beside the VGG forward; 0 = off): beside the capped convolution grids the backward dh GEMM of a
+    # 256..512-row step is cut into n K-slices per 256 x 128 tile, each slice's partial tile goes to an f32 slab, and the FOLLOWING cell
+    # kernel sums the slabs (no reduce launch; lrcn.jl:528-538's dual).  Same arithmetic in another summation order: loss and
+    # all nine gradients against the bf16-emulating oracle, like every other route.  H = 1000: 63 K-tiles in slices of 15 / 16 / 16 / 16.
+    rng = np.random.default_rng(B + H)
+    E, V, T = 64, 300, 3
+    m = orc.init_weights(E, H, H, V, seed=5)
+    for n in ("W1", "W2", "Wout", "Wproj"):
+        m.p[n] *= 2.0
+    feats = (rng.standard_normal((B, 4096)) * 0.05).astype(np.float32)
+    tokens = rng.integers(0, V, size=(T, B)).astype(np.int32)
+    ref_loss = orc.loss(m, feats, tokens)
+    emu_loss, emu_g = emulated_reference(m, feats, tokens)
+    ctx = L.Context(E, H, H, V, max_B=B, max_T=T, lstm_dtype=lrcn_amd.LRCN_BF16, vgg_dtype=lrcn_amd.LRCN_BF16, max_images=1)
+    L.vgg_load(ctx, *L.synthetic_vgg_weights(seed=1))
+    L.vgg_set_wg_cap(ctx, 224)
+    monkeypatch.setenv("LRCN_BWD_SLABS", str(nsl))
+    grads, val = L.lossgradient(ctx, L.model_from_arrays(m.p), L.to_jl(feats), tokens)
+    assert abs(val - ref_loss) <= 2e-2 * abs(ref_loss), (B, H, val, ref_loss)
+    assert_bf16_matches_emulation(val, grads, emu_loss, emu_g, "backward K slices %d, B=%d H=%d" % (nsl, B, H))
+    monkeypatch.setenv("LRCN_BWD_SLABS", "0")
+    grads0, val0 = L.lossgradient(ctx, L.model_from_arrays(m.p), L.to_jl(feats), tokens)
+    for n, a, b in zip(orc.PARAM_NAMES, grads, grads0):   # and against the unsliced route: only the summation order differs
+        a, b = L.from_jl(a).astype(np.float64), L.from_jl(b).astype(np.float64)
+        assert np.linalg.norm(a - b) <= 3e-3 * np.linalg.norm(b) + 1e-12, n
+    ctx.close()
+
+
 @pytest.mark.parametrize("B,H", [(40, 320), (32, 1000), (100, 512), (21, 100)])
 def test_fused_recurrence_small_batch_forms_equal_ring_forms(B, H, monkeypatch):
     # lstm_fused.hip has two forms of the one-launch-per-timestep kernels: 16 hidden units per workgroup with one LDS-DMA ring per wave
