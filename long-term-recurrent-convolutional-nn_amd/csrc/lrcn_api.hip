@@ -644,14 +644,15 @@ int lstm_layer_bwd(lrcn_ctx *c, int S, int B, int H, int64_t ld4H, const void *a
         return LRCN_OK;
     }
     // Beside the capped convolution grids at 256..512 rows the dh GEMM (M = B, N = H, K = 4H) has EIGHT 256 x 128 tiles: 8 of the 32 free CUs,
-    // 3 MB of operand ingest each (55 us per timestep).  Round 6: n = 4 K-slices per tile = 32 workgroups, each writing its partial tile to an
-    // f32 slab; the NEXT cell kernel sums the slabs (no reduce launch, fixed order: deterministic).  Four same-box pairs
-    // (profiles/r06_ab_bwd_slabs.txt): the backward recurrence's segment 1.86 -> 0.87 ms per step, the step 7.270 -> 7.241 ms (the
-    // convolution launches slow by 2.8 % beside the busier chain -- a shorter chain is returned as clock, DESIGN section 7 -- but never by
-    // more than the chain gained).  LRCN_BWD_SLABS=0 / 2..8: off / another slice count.
+    // 3 MB of operand ingest each (55 us per timestep).  LRCN_BWD_SLABS=n (2..8; round 6): n K-slices per tile = 8 n workgroups, each writing
+    // its partial tile to an f32 slab; the NEXT cell kernel sums the slabs (no reduce launch, fixed order: deterministic).  With n = 4, four
+    // same-box pairs (profiles/r06_ab_bwd_slabs.txt): the backward recurrence's segment 1.86 -> 0.87 ms per step, the step 7.270 -> 7.241 ms
+    // (-0.4 %: inside a lease's spread), the convolution launches beside the busier chain 0.571 -> 0.587 ms (+2.8 %, roofline.frac -0.013).
+    // OFF BY DEFAULT like the forward cell epilogue: the LSTM chain is not what bounds the step, and a shorter chain is returned as a lower
+    // clock for the convolutions; the route is kept, tested against the oracle, for a configuration where the chain matters.
     {
         static const char *ksl = getenv("LRCN_BWD_SLABS");
-        const int nsl = ksl ? atoi(ksl) : 4;
+        const int nsl = ksl ? atoi(ksl) : 0;
         const int Kp = (int)round_up64(4 * H, 64);
         if (nsl >= 2 && nsl <= 8 && dt == GEMM_T_BF16 && c->vgg_wg_cap >= 8 && c->vgg_loaded && B >= 256 && B <= 512 && !(H & 3) && H >= 128 &&
             Kp / 64 >= 8 * nsl && Kp <= ld4H && (size_t)nsl * B * H * sizeof(float) <= c->gemm_ws_bytes && c->gemm_ws) {

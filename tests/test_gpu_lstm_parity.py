@@ -384,7 +384,7 @@ def test_cell_epilogue_training_route_partial_tiles_vs_oracle(B, H, knob, monkey
 
 @pytest.mark.parametrize("B,H,nsl", [(256, 256, 2), (300, 512, 4), (256, 1000, 4)])
 def test_backward_recurrence_with_k_slices_summed_by_the_cell_kernel_vs_oracle(B, H, nsl, monkeypatch):
-    # Round 6, LRCN_BWD_SLABS=n (default 4 at 256..512 rows beside the VGG forward; 0 = off): beside the capped convolution grids the backward dh GEMM of a
+    # Round 6, LRCN_BWD_SLABS=n (opt-in, like LRCN_LSTM_EPI): beside the capped convolution grids the backward dh GEMM of a
     # 256..512-row step is cut into n K-slices per 256 x 128 tile, each slice's partial tile goes to an f32 slab, and the FOLLOWING cell
     # kernel sums the slabs (no reduce launch; lrcn.jl:528-538's dual).  Same arithmetic in another summation order: loss and
     # all nine gradients against the bf16-emulating oracle, like every other route.  H = 1000: 63 K-tiles in slices of 15 / 16 / 16 / 16.
