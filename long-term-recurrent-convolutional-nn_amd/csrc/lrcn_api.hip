@@ -651,7 +651,7 @@ int lstm_layer_bwd(lrcn_ctx *c, int S, int B, int H, int64_t ld4H, const void *a
     // OFF BY DEFAULT like the forward cell epilogue: the LSTM chain is not what bounds the step, and a shorter chain is returned as a lower
     // clock for the convolutions; the route is kept, tested against the oracle, for a configuration where the chain matters.
     {
-        static const char *ksl = getenv("LRCN_BWD_SLABS");
+        const char *ksl = getenv("LRCN_BWD_SLABS");   // read per call (the tests switch it inside one process)
         const int nsl = ksl ? atoi(ksl) : 0;
         const int Kp = (int)round_up64(4 * H, 64);
         if (nsl >= 2 && nsl <= 8 && dt == GEMM_T_BF16 && c->vgg_wg_cap >= 8 && c->vgg_loaded && B >= 256 && B <= 512 && !(H & 3) && H >= 128 &&

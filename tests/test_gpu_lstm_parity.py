@@ -406,9 +406,12 @@ def test_backward_recurrence_with_k_slices_summed_by_the_cell_kernel_vs_oracle(B
     assert_bf16_matches_emulation(val, grads, emu_loss, emu_g, "backward K slices %d, B=%d H=%d" % (nsl, B, H))
     monkeypatch.setenv("LRCN_BWD_SLABS", "0")
     grads0, val0 = L.lossgradient(ctx, L.model_from_arrays(m.p), L.to_jl(feats), tokens)
+    differs = False
     for n, a, b in zip(orc.PARAM_NAMES, grads, grads0):   # and against the unsliced route: only the summation order differs
         a, b = L.from_jl(a).astype(np.float64), L.from_jl(b).astype(np.float64)
         assert np.linalg.norm(a - b) <= 3e-3 * np.linalg.norm(b) + 1e-12, n
+        differs = differs or (n in ("W1", "W2") and not np.array_equal(a, b))
+    assert differs, "the K-sliced route left no trace in dW1 / dW2: it was not taken"
     ctx.close()
 
 
