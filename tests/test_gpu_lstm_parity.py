@@ -375,7 +375,6 @@ def test_cell_epilogue_training_route_partial_tiles_vs_oracle(B, H, knob, monkey
     L.vgg_load(ctx, *L.synthetic_vgg_weights(seed=1))
     L.vgg_set_wg_cap(ctx, 224)
     monkeypatch.setenv("LRCN_LSTM_EPI", knob)
-    monkeypatch.setenv("LRCN_TRACE_ROUTES", "0")
     grads, val = L.lossgradient(ctx, L.model_from_arrays(m.p), L.to_jl(feats), tokens, mask1=mask1, mask2=mask2)
     assert abs(val - ref_loss) <= 2e-2 * abs(ref_loss), (B, H, val, ref_loss)
     assert_bf16_matches_emulation(val, grads, emu_loss, emu_g, "cell epilogue %s, B=%d H=%d" % (knob, B, H))
