@@ -649,7 +649,7 @@ int lstm_layer_bwd(lrcn_ctx *c, int S, int B, int H, int64_t ld4H, const void *a
     // same-box pairs (profiles/r06_ab_bwd_slabs.txt): the backward recurrence's segment 1.86 -> 0.87 ms per step, the step 7.270 -> 7.241 ms
     // (-0.4 %: inside a lease's spread), the convolution launches beside the busier chain 0.571 -> 0.587 ms (+2.8 %, roofline.frac -0.013).
     // OFF BY DEFAULT like the forward cell epilogue: the LSTM chain is not what bounds the step, and a shorter chain is returned as a lower
-    // clock for the convolutions; the route is kept, tested against the oracle, for a configuration where the chain matters.
+    // clock for the convolutions; the route is kept, tested against the CPU oracle, for a configuration where the chain matters.
     {
         const char *ksl = getenv("LRCN_BWD_SLABS");   // read per call (the tests switch it inside one process)
         const int nsl = ksl ? atoi(ksl) : 0;
