@@ -578,6 +578,9 @@ def rank_main(a, world, rank, local_rank):
             L.convnet_u8(ctx, imgs_dev[0])
             torch.cuda.synchronize()
             spun += 1
+    # (constructed here, not between the warm-up's barrier and the timed region: finding the device's hwmon node takes milliseconds of host
+    # time, and every millisecond the GPU idles there is paid by the first timed step -- it ran 7.4-7.5 ms against 6.8-6.9 for the rest)
+    hw = HwSampler(local_rank) if rank == 0 and os.environ.get("LRCN_BENCH_HW_SAMPLER", "1")[:1] != "0" else None
     run(a.warmup)
     barrier()
     beat("warm-up done")
@@ -591,7 +594,6 @@ def rank_main(a, world, rank, local_rank):
     e0 = torch.cuda.Event(enable_timing=True)
     e0.record()
     step_ev.append(e0)
-    hw = HwSampler(local_rank) if rank == 0 and os.environ.get("LRCN_BENCH_HW_SAMPLER", "1")[:1] != "0" else None
     if hw:
         hw.start()
     t0 = time.perf_counter()
