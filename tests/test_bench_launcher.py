@@ -333,8 +333,9 @@ def test_hw_sampler_without_the_sysfs_nodes_is_not_an_error(tmp_path):
     (tmp_path / "freq1_input").write_text("2150000000\n")
     (tmp_path / "power1_input").write_text("1300000000\n")
     (tmp_path / "power1_cap").write_text("1400000000\n")
-    h = bench.HwSampler(0, period_s=0.001)
-    h.dir, h.bdf = str(tmp_path), "test"
+    h = bench.HwSampler(0, period_s=0.001, hwmon_dir=str(tmp_path))
+    _time.sleep(0.02)
+    assert h.samples == []   # the thread exists but records nothing before start()
     h.start()
     _time.sleep(0.05)
     r = h.stop()
