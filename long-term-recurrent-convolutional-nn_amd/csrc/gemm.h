@@ -36,6 +36,7 @@ struct LstmEpi {
     void *acts;             // FWD: out (NULL: not kept -- a decode step has no backward pass), BWD: in -- activated gates [M][ld_a], columns [f | i | o | g]
     void *h_new;            // FWD: [M][ld_h]
     int gx_bcast;           // FWD: 1 = Gx is ONE row [4H] added to every row (the bias of a decode step whose GEMM contracts [x | h] itself)
+    const int *gx_idx;      // FWD, optional (gx_bcast = 0): row r adds Gx row gx_idx[r] -- a TABLE of input-side pre-activations (per token, per image)
     float *h_f32;           // FWD, optional: [M][H] f32 copy of h (the ABI's state arrays)
     const float *dh_ext;    // BWD: [M][H] dh of step s-1 from the layer above / the loss
     float *dc;              // BWD: [M][H] in/out

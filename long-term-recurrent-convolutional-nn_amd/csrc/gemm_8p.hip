@@ -434,6 +434,7 @@ __device__ __forceinline__ bool gemm8p_tile(const GemmArgs &g, unsigned char *sm
             for (int j = 0; j < 4; ++j) {
                 const int row = m0 + r64 + 64 * j;
                 const bool ok = uok && row < M;
+                const int64_t grow = (ok && e.gx_idx) ? e.gx_idx[row] : row;   // Gx as a table (per token / per image), or one row per GEMM row
                 if (ok && e.c_prev) {
                     const int64_t prow = e.c_prev_idx ? e.c_prev_idx[row] : row;
                     cpv[j] = *reinterpret_cast<const f32x4v *>(e.c_prev + prow * H + u0);
@@ -442,7 +443,7 @@ __device__ __forceinline__ bool gemm8p_tile(const GemmArgs &g, unsigned char *sm
                 }
 #pragma unroll
                 for (int gt = 0; gt < 4; ++gt) {   // (statically indexed copies: a run-time row index would put the array in scratch)
-                    if (!e.gx_bcast) gxv[j][gt] = ok ? *reinterpret_cast<const f32x4v *>(e.Gx + (int64_t)row * 4 * H + (int64_t)gt * H + u0) : z4;
+                    if (!e.gx_bcast) gxv[j][gt] = ok ? *reinterpret_cast<const f32x4v *>(e.Gx + grow * 4 * H + (int64_t)gt * H + u0) : z4;
                     else if (j > 0) gxv[j][gt] = gxv[0][gt];
                 }
             }

@@ -207,6 +207,10 @@ bool k_softmax_topk_merge(hipStream_t st, const float *part, int nrec, int R, in
 void k_decode_prep(hipStream_t st, const void *wembT, int64_t ld_w, const int32_t *last, const int32_t *parent, int R, int E, const void *h1,
                    int64_t ld_h1, int H1, const void *h2, int64_t ld_h2, int H2, void *xh1, int64_t ld_xh1, int64_t off_h1, void *xh2, int64_t ld_xh2,
                    int64_t off_h2);
+// decode step with input-projection tables: the parents' bf16 h into the gate GEMMs' operands; out[r] = r / K (the image of a hypothesis row)
+void k_decode_prep_h(hipStream_t st, const int32_t *parent, int R, const void *h1, int64_t ld_h1, int H1, const void *h2, int64_t ld_h2, int H2,
+                     void *a1, int64_t ld_a1, void *a2, int64_t ld_a2, int64_t off_h2);
+void k_row_div(hipStream_t st, int32_t *out, int R, int K);
 void k_gather_state(hipStream_t st, int dtype, const float *const in[4], float *const out[4], void *const hT[4], const int64_t ldT[4],
                     const int C[4], const int32_t *parent, int R);
 

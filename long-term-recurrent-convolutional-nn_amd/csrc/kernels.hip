@@ -1345,6 +1345,25 @@ __global__ __launch_bounds__(256) void decode_prep_kernel(const bf16_t *wembT, i
     }
 }
 
+// The prep launch of the decode step with input-projection TABLES (lrcn_api.hip decode_tables; round 6): the gate GEMMs contract the hidden
+// state alone, so only the parents' h move -- h1[parent] into the rows of A1, h2[parent] into the h block of A2 = [h1 Wproj | h2].
+__global__ __launch_bounds__(256) void decode_prep_h_kernel(const int32_t *parent, const bf16_t *h1, int64_t ld_h1, int H1, const bf16_t *h2,
+                                                            int64_t ld_h2, int H2, bf16_t *a1, int64_t ld_a1, bf16_t *a2, int64_t ld_a2, int64_t off_h2) {
+    const int r = blockIdx.x, pr = parent[r];
+    auto copy = [&](const bf16_t *src, bf16_t *dst, int n) {
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
+        uint4 *d4 = reinterpret_cast<uint4 *>(dst);
+        for (int i = threadIdx.x; i < n / 8; i += 256) d4[i] = s4[i];
+        for (int i = (n & ~7) + threadIdx.x; i < n; i += 256) dst[i] = src[i];
+    };
+    copy(h1 + (int64_t)pr * ld_h1, a1 + (int64_t)r * ld_a1, H1);
+    copy(h2 + (int64_t)pr * ld_h2, a2 + (int64_t)r * ld_a2 + off_h2, H2);
+}
+__global__ void row_div_kernel(int32_t *out, int R, int K) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < R) out[r] = r / K;
+}
+
 __global__ void gather_rows_f32_kernel(const float *in, int64_t ld, const int32_t *src_row, int R, int C, float *out) {
     const int r = blockIdx.x;
     const float *s = in + (int64_t)src_row[r] * ld;
@@ -1634,6 +1653,14 @@ void k_decode_prep(hipStream_t st, const void *wembT, int64_t ld_w, const int32_
                    int64_t off_h2) {
     hipLaunchKernelGGL(decode_prep_kernel, dim3(R), dim3(256), 0, st, (const bf16_t *)wembT, ld_w, last, parent, E, (const bf16_t *)h1, ld_h1, H1,
                        (const bf16_t *)h2, ld_h2, H2, (bf16_t *)xh1, ld_xh1, off_h1, (bf16_t *)xh2, ld_xh2, off_h2);
+}
+void k_decode_prep_h(hipStream_t st, const int32_t *parent, int R, const void *h1, int64_t ld_h1, int H1, const void *h2, int64_t ld_h2, int H2,
+                     void *a1, int64_t ld_a1, void *a2, int64_t ld_a2, int64_t off_h2) {
+    hipLaunchKernelGGL(decode_prep_h_kernel, dim3(R), dim3(256), 0, st, parent, (const bf16_t *)h1, ld_h1, H1, (const bf16_t *)h2, ld_h2, H2,
+                       (bf16_t *)a1, ld_a1, (bf16_t *)a2, ld_a2, off_h2);
+}
+void k_row_div(hipStream_t st, int32_t *out, int R, int K) {
+    hipLaunchKernelGGL(row_div_kernel, dim3((R + 255) / 256), dim3(256), 0, st, out, R, K);
 }
 void k_gather_rows_f32(hipStream_t st, const float *in, int64_t ld, const int32_t *src_row, int R, int C, float *out) {
     hipLaunchKernelGGL(gather_rows_f32_kernel, dim3(R), dim3(256), 0, st, in, ld, src_row, R, C, out);

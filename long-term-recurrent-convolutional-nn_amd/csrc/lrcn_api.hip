@@ -58,6 +58,12 @@ struct lrcn_ctx {
     void *W1cat = nullptr, *W2cat = nullptr, *st_xh1 = nullptr, *st_xh2 = nullptr;
     int64_t ldXH1 = 0, ldXH2 = 0;
     void *W2x = nullptr, *W2h = nullptr, *W2xT = nullptr, *W2hT = nullptr;
+    // batched decode with input-projection TABLES (round 6; decode_tables_on): T1 [V][4H1] = Wembed W1x + b1 per TOKEN, U2 [images][4H2] =
+    // x_cnn W2x(right half) + b2 per IMAGE (f32, gate-block columns), the gate GEMMs' operands A1 = h1[parent] and A2 = [h1 Wproj | h2[parent]],
+    // W2's matching weights (x_cnn columns left out, rows interleaved) and the image of every hypothesis row; all lazily allocated
+    float *dec_T1 = nullptr, *dec_U2 = nullptr;
+    void *dec_A1 = nullptr, *dec_A2 = nullptr, *dec_W2c = nullptr, *dec_Aimg = nullptr;
+    int32_t *dec_img = nullptr;
     float *smax_part = nullptr;             // [maxB][2 ceil(V / 256)][SMAX_REC]: the logits GEMM's softmax / top-K records of a batched decode step (round 6), lazily
     void *alt_gi[2] = {nullptr, nullptr};   // LRCN_OPT_FUSED_UPDATE: the second set's gate-interleaved copies (round 6), written by the Adam kernel
     bool gi_live = false;                   // a training call has taken the cell-epilogue route: the fused update keeps the interleaved copies current
@@ -411,17 +417,19 @@ void plan_matrices(const lrcn_ctx *c, const float *const p[9], const ShadowSet &
 }
 
 // f32 column-major params -> K-contiguous shadows in T (direct and transposed).  See DESIGN.md "shadow weights".
-int prepare_weights(lrcn_ctx *c, const float *const p[9], bool need_bwd, bool cat = false, bool gi = false, bool cat_perm = false) {
+int prepare_weights(lrcn_ctx *c, const float *const p[9], bool need_bwd, bool cat = false, bool gi = false, bool cat_perm = false,
+                    bool dec_tables = false) {   // dec_tables: the interleaved recurrent copies + W2 without its x_cnn columns (a decode call: not sticky)
     const int dt = c->dt, H1 = c->H1, H2 = c->H2, X1 = c->X1;
     if (!p[0] || !p[1] || !p[5] || !p[6] || !p[7] || !p[8] || (c->nl == 2 && (!p[2] || !p[3] || !p[4]))) FAIL(c, LRCN_EINVAL, "null parameter tensor");
     hipStream_t st = c->stream;
     const bool two = c->nl == 2;
     // LRCN_OPT_FUSED_UPDATE: the previous train step's Adam kernel already wrote this set from these very parameters
-    if (gi) {
+    if (gi || dec_tables) {
         int rg = ensure_gi_sets(c);
         if (rg) return rg;
-        c->gi_live = true;   // from now on the fused update writes the interleaved copies with the other shadows
+        if (gi) c->gi_live = true;   // from now on the fused update writes the interleaved copies with the other shadows
     }
+    if (dec_tables) gi = true;
     if (c->opt_fused && c->shadow_valid && !cat && (!gi || c->shadow_has_gi)) {
         bool same = true;
         for (int k = 0; k < 9; ++k) same = same && c->shadow_p[k] == p[k];
@@ -432,6 +440,17 @@ int prepare_weights(lrcn_ctx *c, const float *const p[9], bool need_bwd, bool ca
     PrepPlan plan{};
     void *const gi_cur[2] = {c->W1h_gi, c->W2h_gi};
     plan_matrices(c, p, cur_shadows(c), need_bwd, plan, -1, -1, gi ? gi_cur : nullptr);
+    if (dec_tables && c->nl == 2) {
+        // W2 (memory [4H2][2 H2]: columns [h1 Wproj (h) | x_cnn (h) | h2 (H2)]) -> dec_W2c [4H2][ldh + ldH2] = [proj columns | h2 columns], rows
+        // (unit, gate)-interleaved: two descriptors over the same source, each with one live side
+        const int64_t ld = c->ldh + c->ldH2;
+        PrepDesc &a = plan.d[plan.n++];
+        a = PrepDesc{};
+        a.src = p[2]; a.R = 4 * H2; a.C = 2 * H2; a.cs = c->h; a.dA = c->dec_W2c; a.ldA = ld; a.permH = H2;
+        PrepDesc &b = plan.d[plan.n++];
+        b = PrepDesc{};
+        b.src = p[2]; b.R = 4 * H2; b.C = 2 * H2; b.cs = H2; b.dB = boff(c->dec_W2c, c->ldh, c->esz); b.ldB = ld; b.permH = H2;
+    }
     if (cat) {  // batched decode: W1 / W2 with the x and h column blocks each padded to whole K-steps, side by side
         // cat_perm: the rows in (unit, gate)-interleaved order, for the decode step with the cell math in the GEMM's epilogue
         auto add = [&](const float *src, int R, int C, int cs, void *dA, int64_t ldA, void *dB, int64_t ldB, int permH) {
@@ -996,7 +1015,8 @@ bool decode_epi_on(const lrcn_ctx *c, int B) {
     return !(k && k[0] == '0') && c->dt == GEMM_T_BF16 && B >= 256 && !(c->H1 & 3) && !(c->H2 & 3);
 }
 int decode_gates_epi(lrcn_ctx *c, const void *xh, int64_t ldxh, const void *Wcat, int K, const float *bias, int B, int H, const float *c_prev,
-                     const int32_t *c_prev_idx, float *c_out, void *h_out, int64_t ld_h_out) {
+                     const int32_t *c_prev_idx, float *c_out, void *h_out, int64_t ld_h_out, const int32_t *gx_idx = nullptr) {
+    // bias: ONE row [4H] for every row, or -- gx_idx given -- a table of input-side pre-activations of which row r adds row gx_idx[r]
     // h_out must NOT be the h columns of `xh`: every tile of this launch reads them as A-operand columns, and tiles of one row block run in
     // different rounds (2.5 rounds of 256 x 128 tiles at 5120 x 4000), so an in-place h(t) would reach tiles that still need h(t-1).
     GemmArgs g{};
@@ -1010,7 +1030,7 @@ int decode_gates_epi(lrcn_ctx *c, const void *xh, int64_t ldxh, const void *Wcat
     g.out_mode = GEMM_OUT_LSTM_FWD;
     g.zero_page = c->zero_page;
     g.lstm.H = H; g.lstm.ld_a = 4 * H; g.lstm.ld_h = ld_h_out;
-    g.lstm.Gx = bias; g.lstm.gx_bcast = 1;
+    g.lstm.Gx = bias; g.lstm.gx_bcast = gx_idx ? 0 : 1; g.lstm.gx_idx = gx_idx;
     // the cell state of row r continues its PARENT hypothesis' (lrcn.jl:673-676): read through c_prev_idx (round 6; NULL = the first step,
     // zero state) into the other buffer of the pair -- no gather launch between the steps
     g.lstm.c_prev = c_prev; g.lstm.c_prev_idx = c_prev_idx; g.lstm.c_out = c_out;
@@ -1047,6 +1067,63 @@ int decode_logits_smax(lrcn_ctx *c, const void *hT, int64_t ldh, const float *bi
     hipError_t e = launch_gemm_8p(c->stream, g);
     if (e != hipSuccess) FAIL(c, LRCN_EHIP, "decode step (logits GEMM + softmax / top-K epilogue): %s", hipGetErrorString(e));
     if (!k_softmax_topk_merge(c->stream, c->smax_part, nrec, B, K, c->st_topi, c->st_topv)) FAIL(c, LRCN_EINVAL, "softmax / top-K merge: K = %d, %d records", K, nrec);
+    return LRCN_OK;
+}
+
+// The batched decode step with input-projection TABLES (round 6).  [x | h] W of lrcn.jl:529 is x Wx + h Wh, and in a decode x is not free:
+// LSTM-1's x is the embedding of one of V tokens, LSTM-2's is [h1 Wproj | x_cnn] with x_cnn fixed per image (lrcn.jl:546, :611).  So
+// T1 = Wembed W1x + b1 (V x 4H1: 85 GFLOP once per call -- what ONE step spent on it for its 5120 rows) and U2 = x_cnn W2x[right half] + b2
+// (one row per image) are made once, each step's gate GEMMs contract h (K = 1024) resp. [h1 Wproj | h2] (K = 1536) instead of 2048, and the
+// cell epilogue adds row last_token / row image of the tables (LstmEpi::gx_idx).  63 of a step's 282 GFLOP at 5120 hypotheses are not done,
+// the embedding gather and the concat launch disappear.  Same products, f32 accumulation in two chains instead of one.  Memory for FLOPs:
+// T1 is 170 MB of the 288 GB.  LRCN_DECODE_TABLES=0: the [x | h] form.
+bool decode_tables_on(const lrcn_ctx *c, int B) {
+    const char *k = getenv("LRCN_DECODE_TABLES");  // read per call (the tests switch it inside one process)
+    return !(k && k[0] == '0') && c->nl == 2 && decode_epi_on(c, B) && c->H1 > 64 && c->H2 > 64;
+}
+int decode_tables_alloc(lrcn_ctx *c) {
+    const size_t es = c->esz;
+    if (!c->dec_T1) DALLOC(c, c->dec_T1, sizeof(float) * (size_t)c->V * 4 * c->H1);
+    if (!c->dec_U2) DALLOC(c, c->dec_U2, sizeof(float) * (size_t)c->maxB * 4 * c->H2);
+    if (!c->dec_A1) DALLOC(c, c->dec_A1, es * (size_t)c->maxB * c->ldH1);
+    if (!c->dec_A2) DALLOC(c, c->dec_A2, es * (size_t)c->maxB * (c->ldh + c->ldH2));
+    if (!c->dec_W2c) DALLOC(c, c->dec_W2c, es * (size_t)4 * c->H2 * (c->ldh + c->ldH2));
+    if (!c->dec_Aimg) DALLOC(c, c->dec_Aimg, es * (size_t)c->maxB * c->ldH2);
+    if (!c->dec_img) DALLOC(c, c->dec_img, sizeof(int32_t) * (size_t)c->maxB);
+    return LRCN_OK;
+}
+// once per decode call, after prepare_weights(dec_tables) and the image embedding (dxcnn [N][ldh] f32): the two tables and the row -> image map
+int decode_tables_build(lrcn_ctx *c, const float *const p[9], int N, int K) {
+    const int dt = c->dt, E = c->E, H1 = c->H1, H2 = c->H2, h = c->h, V = c->V;
+    hipStream_t st = c->stream;
+    GEMM(c, dt, c->WeT, c->ldE, c->W1x, c->ldX1, c->dec_T1, 4 * H1, V, 4 * H1, E, p[1], true);                 // per token
+    HIPCHK(c, hipMemsetAsync(c->dec_Aimg, 0, c->esz * (size_t)N * c->ldH2, st));
+    DropSpec none{};
+    k_concat_x2(st, dt, c->dec_Aimg, c->ldH2, c->dxcnn, c->ldh, 1, N, h, h, none);                              // [0 | x_cnn] per image
+    GEMM(c, dt, c->dec_Aimg, c->ldH2, c->W2x, c->ldH2, c->dec_U2, 4 * H2, N, 4 * H2, H2, p[3], true);           // per image
+    k_row_div(st, c->dec_img, N * K, K);
+    HIPCHK(c, hipMemsetAsync(c->dec_A1, 0, c->esz * (size_t)N * K * c->ldH1, st));                              // zero initial h1 / h2 and K padding
+    HIPCHK(c, hipMemsetAsync(c->dec_A2, 0, c->esz * (size_t)N * K * (c->ldh + c->ldH2), st));
+    KCHK(c, "decode tables");
+    return LRCN_OK;
+}
+int step_decode_tables(lrcn_ctx *c, const float *const p[9], int B, const int32_t *parent, bool first, int smax_K) {
+    const int dt = c->dt, H1 = c->H1, H2 = c->H2, h = c->h, V = c->V;
+    const int64_t ldA2 = c->ldh + c->ldH2;
+    if (!first) k_decode_prep_h(c->stream, parent, B, c->st_h1, c->ldH1, H1, c->st_h2, c->ldH2, H2, c->dec_A1, c->ldH1, c->dec_A2, ldA2, c->ldh);
+    int r = decode_gates_epi(c, c->dec_A1, c->ldH1, c->W1h_gi, H1, c->dec_T1, B, H1, first ? nullptr : c->st_f32[1], parent, c->st2_f32[1], c->st_h1,
+                             c->ldH1, c->bs_last);
+    if (r) return r;
+    GEMM(c, dt, c->st_h1, c->ldH1, c->Wpd, c->ldH1, c->dec_A2, ldA2, B, h, H1, nullptr, false);   // x = s[1] * w[end-4] (lrcn.jl:544) into A2's left block
+    r = decode_gates_epi(c, c->dec_A2, ldA2, c->dec_W2c, (int)ldA2, c->dec_U2, B, H2, first ? nullptr : c->st_f32[3], parent, c->st2_f32[3], c->st_h2,
+                         c->ldH2, c->dec_img);
+    if (r) return r;
+    if (smax_K > 0) {
+        if ((r = decode_logits_smax(c, c->st_h2, c->ldH2, p[8], B, smax_K))) return r;
+    } else {
+        GEMM(c, dt, c->st_h2, c->ldH2, c->Wod, c->ldH2, c->st_logits, c->ldV, B, V, H2, p[8], true);
+    }
+    KCHK(c, "step_decode (tables)");
     return LRCN_OK;
 }
 
@@ -1909,7 +1986,10 @@ int lrcn_beam_search_batch(lrcn_ctx *c, const float *const p[9], const float *fe
     hipStream_t st = c->stream;
     const bool epi = decode_epi_on(c, R);
     const bool smax = epi && decode_smax_on(c, R, K);
-    int r = prepare_weights(c, p, false, true, false, epi);
+    const bool tables = epi && decode_tables_on(c, R);
+    int r = tables ? decode_tables_alloc(c) : LRCN_OK;
+    if (r) return r;
+    r = prepare_weights(c, p, false, !tables, false, epi, tables);
     if (r) return r;
     // input = input * param[end-3] per image (lrcn.jl:611), each row repeated for the image's K hypotheses
     k_transpose(st, dt, 1, feats, N, LRCN_CNNOUT, N, c->F, LRCN_CNNOUT, 0);
@@ -1928,8 +2008,14 @@ int lrcn_beam_search_batch(lrcn_ctx *c, const float *const p[9], const float *fe
     k_beam_init(st, c->bs_seq[0], c->bs_last, c->bs_p, R, Lh, LRCN_BOS);  // histories = [bos], probabilities 1, next input = bos
     DropSpec none{};
     int cur = 0;
+    if (tables && (r = decode_tables_build(c, p, N, K))) return r;
     for (int current = 1; current <= nword + 1; ++current) {
-        if (epi) {
+        if (tables) {
+            r = step_decode_tables(c, p, R, current > 1 ? c->st_parent : nullptr, current == 1, smax ? K : 0);
+            if (r) return r;
+            std::swap(c->st_f32[1], c->st2_f32[1]);
+            std::swap(c->st_f32[3], c->st2_f32[3]);
+        } else if (epi) {
             // one launch: embedding of every hypothesis' last token (lrcn.jl:650) + h1 / h2 of its parent (:673-676) into the [x | h] operands
             const bool two = c->nl == 2;
             k_decode_prep(st, c->WeT, c->ldE, c->bs_last, current > 1 ? c->st_parent : nullptr, R, E, c->st_h1, c->ldH1, H1, two ? c->st_h2 : nullptr,

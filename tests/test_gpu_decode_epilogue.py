@@ -160,3 +160,41 @@ def test_fused_softmax_topk_equals_the_row_kernel(V, K, layers, monkeypatch):
         assert ta == tb, (ta, tb)
         assert abs(pa - pb) <= 1e-5 * abs(pb) + 1e-30, (pa, pb)
     ctx.close()
+
+
+@pytest.mark.parametrize("N,Kb", [(1024, 5), (300, 1), (87, 3)])
+def test_decode_with_input_projection_tables_equals_the_concatenated_operand_form(N, Kb, monkeypatch):
+    """Round 6: by default the batched decode's gate GEMMs contract the hidden state only -- h Wh for LSTM-1, [h1 Wproj | h2] for LSTM-2 -- and
+    the input-side pre-activations come from tables made once per call: Wembed W1x + b1 per TOKEN, x_cnn W2x + b2 per IMAGE (lrcn.jl:529:
+    [x h] W = x Wx + h Wh; :546, :611).  LRCN_DECODE_TABLES=0 is the [x | h] form of round 5.  Same bf16 products, f32 sums in two chains
+    instead of one: on decisive distributions the captions agree (a near-tie may fall the other way) and so do the probabilities; the
+    table form also agrees with the bf16-emulating oracle's per-image decode.  300 x 1 / 87 x 3: row-block tails, beam widths 1 and 3."""
+    m = decisive_model(seed=6)
+    feats = (np.random.default_rng(N + Kb).standard_normal((N, 4096)) * 0.05).astype(np.float32)
+    ctx = L.Context(E, H, H, V, max_B=N * Kb, max_T=2, lstm_dtype=lrcn_amd.LRCN_BF16)
+    param = L.model_from_arrays(m.p)
+    out = {}
+    for knob in ("1", "0", "1"):
+        monkeypatch.setenv("LRCN_DECODE_TABLES", knob)
+        r = L.beam_search_batch(ctx, param, L.to_jl(feats), Kb, NWORD)
+        if knob in out:
+            assert [t for t, _ in r] == [t for t, _ in out[knob]], "the table decode does not repeat itself"
+        out[knob] = r
+    same = sum(a[0] == b[0] for a, b in zip(out["1"], out["0"]))
+    assert same >= N - max(1, N // 50), (same, N)
+    for (ta, pa), (tb, pb) in zip(out["1"], out["0"]):
+        if ta == tb:
+            assert abs(pa - pb) <= 2e-2 * abs(pb) + 1e-30, (pa, pb)
+        else:
+            assert abs(np.log(pa + 1e-300) - np.log(pb + 1e-300)) < 0.3, (pa, pb)
+    agree = 0
+    picks = [0, N // 2, N - 1]
+    for i in picks:
+        with orc.emulate_bf16():
+            rt, rp = orc.beam_search(m, feats[i], Kb, NWORD)
+        if out["1"][i][0] == list(rt):
+            agree += 1
+            assert abs(out["1"][i][1] - rp) <= 5e-2 * abs(rp) + 1e-30
+    assert agree >= len(picks) - 1, agree
+    ctx.close()
+
