@@ -247,7 +247,11 @@ int lrcn_beam_search(lrcn_ctx *ctx, const float *const params[9], const float *f
 /* The same decode for N images at once (new: the reference decodes image by image): feats N x 4096 column-major, N*K <= max_B.
  * The N*K hypotheses are the rows of one batched lrcn() step; softmax, top-K, candidate ordering (stable, descending), history
  * update and the stop test run on the device.  Host outputs: out_tokens [N][nword + 2] (bos first), out_len [N], out_prob [N]
- * (may be NULL).  Per image identical to lrcn_beam_search. */
+ * (may be NULL).  Per image identical to lrcn_beam_search.
+ * From 256 hypotheses in bf16 the step takes its memory-for-FLOPs form: the context allocates, at the first such call,
+ * a table of input-side pre-activations per TOKEN (V x 4 H1 f32: 170 MB at V = 10640, H = 1000) and per hypothesis row capacity
+ * (max_B x 4 H2 f32), the gate GEMMs contract the hidden state only, and the N*K x V logits are reduced to per-tile records inside the
+ * logits GEMM (they never reach memory).  Ranking is lrcn.jl:652-656's -- float32 probabilities, stable, lower column first in a tie group. */
 #define LRCN_BEAM_MAXLEN 258
 int lrcn_beam_search_batch(lrcn_ctx *ctx, const float *const params[9], const float *feats, int N, int K, int nword,
                            int32_t *out_tokens, int *out_len, float *out_prob);
