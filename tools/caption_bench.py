@@ -144,6 +144,8 @@ def main():
             ev = nxt
         return outs
 
+    import bench as _bench_mod   # the clock / power sampler of the training line (sysfs hwmon; a pre-started thread, 10 ms period)
+    hw = _bench_mod.HwSampler(local) if rank == 0 and os.environ.get("LRCN_BENCH_HW_SAMPLER", "1")[:1] != "0" else None
     run(2)
     torch.cuda.synchronize()
     if world > 1:
@@ -151,10 +153,13 @@ def main():
     import ctypes as C
     _lib = lrcn_amd._lib
     _lib.check(ctx._h, _lib.lib().lrcn_profile(ctx._h, 1))   # HIP events around the 12 convolution launches of every VGG forward
+    if hw:
+        hw.start()
     t0 = time.perf_counter()
     outs = run(a.iters)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    hw_held = hw.stop() if hw else None
     conv_ms, conv_n = C.c_double(), C.c_int64()
     _lib.check(ctx._h, _lib.lib().lrcn_profile_get(ctx._h, C.byref(conv_ms), C.byref(conv_n)))
     _lib.check(ctx._h, _lib.lib().lrcn_profile(ctx._h, 0))
@@ -195,6 +200,7 @@ def main():
                                      "images_per_gpu_per_pass": N, "beam_chunk": a.chunk, "vgg_overlapped": bool(a.overlap), "parallelism": "replicas x%d" % world,
                                      "ms_vgg_forward_alone": t_vgg * 1e3, "mean_caption_len": float(np.mean([len(t) for t, _ in outs]))},
                           "rccl": {"world": world, "backend": "none (replicas: one barrier + a max over ranks of the elapsed time)"},
+                          "hw_held_in_timed_region": hw_held,
                           **({"cpu_baseline": cpu} if cpu else {}),
                           **({"parity": {"c5_fixture": fixture, "tolerance": "BASELINE.md section 3: top caption identical on >= 95 % of fixture images (else "
                                                                               "BLEU within +-0.5); asserted by tests/test_gpu_config5.py"}} if fixture else {}),
